@@ -1,0 +1,145 @@
+"""Pins the CPU oracle (oracle/nk_oracle.c) to golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  CPU only."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import golden, sub, golden_phonon, rel_err
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+import nk_oracle as O  # noqa: E402
+
+c_dp, c_ip = O.c_dp, O.c_ip
+
+
+def P(a, t=c_dp):
+    return a.ctypes.data_as(t)
+
+
+@pytest.mark.parametrize('name', ['box200', 'box200ttp', 'box5000', 'cyl'])
+def test_find_boundary(name):
+    g = sub(golden('mesh'), name)
+    mesh = O.make_mesh(g)
+    x = np.ascontiguousarray(g['ray_x']); v = np.ascontiguousarray(g['ray_v'])
+    n = x.shape[0]
+    xc = np.zeros((n, 3)); tc = np.zeros(n); fc = np.zeros(n, dtype=np.int32)
+    O.lib().nko_find_boundary(C.byref(mesh), C.c_int64(n), P(x), P(v), P(xc), P(tc), P(fc, c_ip))
+    assert np.array_equal(fc, g['ray_fc'])
+    hit = fc >= 0
+    assert rel_err(tc[hit], g['ray_tc'][hit]) < 1e-12
+    assert np.all(np.isinf(tc[~hit]))
+    assert np.allclose(xc[hit], g['ray_xc'][hit], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', ['box200', 'box5000', 'cyl'])
+def test_classifier(name):
+    g = sub(golden('mesh'), name)
+    sv = O.make_subvols(g['subvol_center'], g['subvol_volume'], 0, int(g['slice_axis']), 1)
+    x = np.ascontiguousarray(g['cls_x'])
+    out = np.zeros(x.shape[0], dtype=np.int32)
+    O.lib().nko_classify(C.byref(sv), C.c_int64(x.shape[0]), P(x), P(out, c_ip))
+    assert np.array_equal(out, g['cls_id'])
+
+
+def test_material_functions():
+    g = golden('phonon')
+    ph = golden_phonon()
+    mat = O.make_material(ph.tables())
+    n = g['s_T'].shape[0]
+    L = O.lib()
+    mode = np.ascontiguousarray(g['s_q'] * ph.number_of_branches + g['s_j'], dtype=np.int32)
+    om = np.ascontiguousarray(ph.omega.ravel()[mode])
+    out = np.zeros(n)
+    L.nko_occupation(C.byref(mat), C.c_int64(n), P(np.ascontiguousarray(g['s_T'])), P(om), P(out))
+    assert rel_err(out, g['s_occ']) < 1e-13
+    L.nko_lifetime(C.byref(mat), C.c_int64(n), P(np.ascontiguousarray(g['s_T'])), P(mode, c_ip), P(out))
+    assert rel_err(out, g['s_tau']) < 1e-12
+    # feed the reference's own E(T) table so the inverse is compared like for like
+    t = ph.tables()
+    t['energy_array'] = g['energy_array']
+    mat2 = O.make_material(t)
+    L.nko_T_of_E(C.byref(mat2), C.c_int64(n), P(np.ascontiguousarray(g['s_E'])), P(out))
+    assert rel_err(out, g['s_T_of_E']) < 1e-13
+    L.nko_E_of_T(C.byref(mat2), C.c_int64(n), P(np.ascontiguousarray(g['s_Tw'])), P(out))
+    assert rel_err(out, g['s_E_of_T']) < 1e-13
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10."""
+    L = O.lib()
+    u32 = C.c_uint32
+
+    def run(ctr, key):
+        c = (u32 * 4)(*ctr); k = (u32 * 2)(*key); o = (u32 * 4)()
+        L.nko_philox4x32_10(c, k, o)
+        return [int(v) for v in o]
+    assert run([0, 0, 0, 0], [0, 0]) == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert run([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+    assert run([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
+        [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+def _empty_rough():
+    z = np.zeros(0)
+    return O.make_rough(np.zeros(0, dtype=np.int32), z, np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32), z)
+
+
+def oracle_from_step_golden(variant):
+    gm = sub(golden('mesh'), 'box200ttp')
+    gs = sub(golden('step'), variant)
+    ph = golden_phonon()
+    J = ph.number_of_branches
+    mat = O.make_material(ph.tables())
+    mesh = O.make_mesh(gm)
+    interp = {'lin': 1, 'near': 0, 'fixed': 1, 'tref': 1}[variant]
+    sv = O.make_subvols(gm['subvol_center'], gm['subvol_volume'], 0, int(gm['slice_axis']), interp)
+    M = ph.number_of_qpoints * J
+    res = O.make_reservoirs(gm['res_facets'], gs['res_facet_temperature'], np.zeros((2, M)), np.zeros((2, M)))
+    par = O.make_params(dt=1.0, norm_fixed=(variant == 'fixed'), particle_density=float(gs['particle_density']),
+                        T_ref=(300.0 if variant == 'tref' else None), seed=1)
+    n = gs['pre_positions'].shape[0]
+    store = O.ParticleStore(n + 16)
+    store.load(gs['pre_positions'], gs['pre_modes'][:, 0] * J + gs['pre_modes'][:, 1], gs['pre_occupation'],
+               gs['pre_n_timesteps'], gs['pre_collision_facets'])
+    sim = O.OracleSim(mat, mesh, sv, res, _empty_rough(), par, store, gs['pre_subvol_temperature'])
+    return sim, gs, gm, ph
+
+
+@pytest.mark.parametrize('variant', ['lin', 'near', 'fixed', 'tref'])
+def test_frozen_step(variant):
+    """drift -> boundary_scattering -> refresh_temperatures -> lifetime_scattering -> heat flux on a frozen
+    reference state (BCs T T P: no random numbers are consumed)."""
+    sim, gs, gm, ph = oracle_from_step_golden(variant)
+    L, r = sim.L, sim.ref
+    J = ph.number_of_branches
+    L.nko_drift(r(sim.mat), r(sim.p), r(sim.P.s))
+    L.nko_boundary_scattering(r(sim.mat), r(sim.mesh), r(sim.sv), r(sim.res), r(sim.rough), r(sim.p),
+                              P(sim.T_sv), C.c_int64(0), r(sim.P.s), P(sim.N_leaving, O.c_lp),
+                              P(sim.res_energy), P(sim.res_flux))
+    n = sim.P.N
+    assert n == gs['mid_positions'].shape[0]
+    assert np.array_equal(sim.N_leaving, gs['mid_N_leaving'])
+    assert np.array_equal(sim.P.mode[:n], gs['mid_modes'][:, 0] * J + gs['mid_modes'][:, 1])
+    assert np.array_equal(sim.P.facet[:n], gs['mid_collision_facets'])
+    assert np.allclose(sim.P.pos[:n], gs['mid_positions'], rtol=1e-12, atol=1e-9)
+    assert np.allclose(sim.P.n_ts[:n], gs['mid_n_timesteps'], rtol=1e-9, atol=1e-9)
+    assert rel_err(sim.P.occ[:n], gs['mid_occupation']) < 1e-13
+    assert rel_err(sim.res_energy, gs['mid_res_energy_balance']) < 1e-10
+    assert np.allclose(sim.res_flux, gs['mid_res_heat_flux'], rtol=1e-10, atol=1e-12)
+
+    L.nko_refresh_temperatures(r(sim.mat), r(sim.sv), r(sim.p), r(sim.P.s), P(sim.T_sv), P(sim.E_sv),
+                               P(sim.N_sv, O.c_lp), P(sim.E_raw))
+    assert np.array_equal(sim.N_sv, gs['post_subvol_N_p'])
+    assert np.array_equal(sim.P.sv[:n], gs['post_subvol_id'])
+    assert np.allclose(sim.P.energy[:n], gs['energies'], rtol=1e-9, atol=1e-16)
+    assert rel_err(sim.E_sv, gs['post_subvol_energy']) < 1e-12
+    assert np.allclose(sim.T_sv, gs['post_subvol_temperature'], rtol=0, atol=1e-7)
+    assert np.allclose(sim.P.temp[:n], gs['post_temperatures'], rtol=0, atol=1e-7)
+
+    L.nko_lifetime_scattering(r(sim.mat), r(sim.p), r(sim.P.s))
+    assert rel_err(sim.P.occ[:n], gs['post_occupation']) < 1e-9
+    L.nko_heat_flux(r(sim.mat), r(sim.sv), r(sim.p), r(sim.P.s), P(sim.N_sv, O.c_lp), P(sim.flux))
+    assert np.allclose(sim.flux, gs['heat_flux'], rtol=1e-8, atol=1e-3)
