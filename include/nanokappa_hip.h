@@ -1,0 +1,198 @@
+/* nanokappa_hip.h -- C ABI of libnanokappa_hip.so: the MI355X (gfx950) engine for Nano-kappa's
+ * Population timestep loop.
+ *
+ * The reference (brunohs1993/Nanokappa) is pure Python with no FFI layer; the boundary this
+ * library replaces is the body of `Population.run_timestep` (classes/Population.py:1724-1769)
+ * and the helpers it calls.  Each entry point names the reference interface it stands for.
+ * Python binds it with ctypes (nanokappa_amd/_lib.py); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Conventions: plain pointers + sizes, caller owns every host buffer (the library copies, never
+ * frees caller memory), the library owns device memory.  Every function returns 0 on success or a
+ * negative nk_status; nk_last_error() gives the text.  A context is used from one host thread.
+ * Units are the reference's: angstrom, ps, K, eV, rad/ps.  All real data is IEEE double.
+ */
+#ifndef NANOKAPPA_HIP_H
+#define NANOKAPPA_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct nk_ctx nk_ctx;
+
+enum nk_status {
+    NK_OK = 0,
+    NK_ERR_HIP = -1,        /* a HIP runtime call failed */
+    NK_ERR_ARG = -2,        /* invalid argument / call order */
+    NK_ERR_CAPACITY = -3,   /* particle capacity exceeded (raise it with nk_reserve) */
+    NK_ERR_COMM = -4,       /* RCCL failure */
+    NK_ERR_NODEVICE = -5    /* no usable gfx950 device */
+};
+
+/* Phonon tables, reference classes/Phonon.py (attributes read by Population: omega :165-167,
+ * group_vel :181-183, lifetime :326-336, temperature_function / crystal_energy_function :372-390,
+ * normalise_to_density :392-401, number_of_active_modes :126) */
+typedef struct {
+    int32_t Q, J, NT;
+    const double *omega;         /* [Q*J]    rad/ps */
+    const double *group_vel;     /* [Q*J*3]  angstrom/ps */
+    const double *T_grid;        /* [NT]     K, ascending */
+    const double *lifetime;      /* [NT*Q*J] ps; 0 means "relax fully" */
+    int32_t nE;                  /* length of the E(T) table */
+    double T_fill_lo, T_fill_hi; /* clamp values of T(E) outside the table */
+    const double *T_array;       /* [nE] */
+    const double *energy_array;  /* [nE] eV/angstrom^3, ascending */
+    double hbar, kb;             /* classes/Constants.py:7-8 */
+    double QV;                   /* number_of_qpoints * volume_unitcell */
+    int32_t active_modes;
+} nk_material;
+
+/* Triangle mesh + boundary conditions, reference classes/Mesh.py:205-242, :314-327 and
+ * classes/Geometry.py:652-709 (bound_cond), :711-726 (connected_facets) */
+typedef struct {
+    int32_t F;                     /* triangular faces */
+    const double *normals;         /* [F*3] face_normals */
+    const double *k;               /* [F]   face_k */
+    const double *bounds_lo;       /* [F*3] face_bounds[0] */
+    const double *bounds_hi;       /* [F*3] face_bounds[1] */
+    const double *basis;           /* [F*9] face_basis_matrix (F,3,3) */
+    const double *origins;         /* [F*3] face_origins */
+    const int32_t *face_facet;     /* [F]   face_facets */
+    const double *vertices;        /* [F*9] corners of each face (surface sampling, Mesh.py:939) */
+    const double *face_area;       /* [F] */
+    int32_t Fc;                    /* facets (groups of coplanar adjacent faces) */
+    const int8_t *facet_bc;        /* [Fc] 'T', 'F', 'P' or 'R' */
+    const int32_t *facet_partner;  /* [Fc] periodic partner facet, -1 if none */
+    const double *facet_centroid;  /* [Fc*3] */
+    const double *facet_normal;    /* [Fc*3] */
+    const int32_t *facet_face_off; /* [Fc+1] CSR: faces of each facet */
+    const int32_t *facet_face_idx;
+    double tol;                    /* Mesh.tol (1e-10) */
+    double bbox[6];                /* Geometry.bounds: lo xyz, hi xyz */
+    int32_t nS;                    /* volume simplices for Mesh.sample_volume (Mesh.py:890-904) */
+    const double *simplex_pts;     /* [nS*12] */
+    const double *simplex_vol;     /* [nS] */
+} nk_mesh;
+
+/* Subvolumes, reference classes/Geometry.py:446-544 and SubvolClassifier :1198-1213 */
+typedef struct {
+    int32_t S;
+    int32_t kind;            /* 0 slice (centres ascending along `axis`), 1 general nearest centre */
+    int32_t axis;
+    int32_t interp;          /* per-particle T: 0 interp1d 'nearest' on slices, 1 'linear' on slices,
+                                2 nearest centre (Population.py:570-573, :694-702) */
+    const double *centers;   /* [S*3] */
+    const double *volumes;   /* [S] */
+} nk_subvols;
+
+/* Reservoirs, reference Population.py:323-354 (initialise_reservoirs), :146-161 (enter_probability) */
+typedef struct {
+    int32_t R;
+    const int32_t *facet;      /* [R] facet index of each reservoir */
+    const double *T;           /* [R] imposed temperature */
+    const double *enter_prob;  /* [R*Q*J] */
+    const double *counter;     /* [R*Q*J] initial res_counter (Population.py:343) */
+    int32_t gen;               /* 0 'constant', 1 'fixed_rate' (Population.py:358-455) */
+} nk_reservoirs;
+
+/* Rough facets, reference Population.py:852-877 (specularity), :1042-1461 (specular map),
+ * :879-939 (creation_roulette), :1017-1040 (degeneracies) */
+typedef struct {
+    int32_t Fr;
+    const int32_t *facet;       /* [Fr] */
+    const double *specularity;  /* [Fr*Q*J] */
+    const uint8_t *true_spec;   /* [Fr*Q*J] */
+    const int32_t *spec_map;    /* [Fr*Q*J] flat out-mode (q*J+j), -1 where not specular */
+    const double *roulette;     /* [Fr*Q*J] cumulative, last = 1 */
+    const int32_t *degen_j2;    /* [Q*J] partner branch for the 'k' model, or NULL */
+} nk_rough;
+
+/* Scalars of Population.__init__ (Population.py:41-95) */
+typedef struct {
+    double dt;                /* --timestep */
+    int32_t norm_fixed;       /* --energy_normal: 0 'mean', 1 'fixed' */
+    double particle_density;
+    int32_t T_ref_local;      /* --reference_temp local */
+    double T_ref;
+    int32_t flux_every;       /* tally the subvolume heat flux every this many steps (n_dt_to_conv = 10) */
+    int32_t contains_every;   /* contains_check period (100, Population.py:1729-1734); 0 = never */
+} nk_params;
+
+/* Per-step results of nk_step; every pointer may be NULL.  Row r describes the r-th step of the call.
+ * Raw sums are un-normalised (the host applies Population.py:719-728 / :738-747 scalings where the
+ * library has not already done so).  All sums are over ALL ranks once nk_comm_init was called. */
+typedef struct {
+    double *T_sv;        /* [nsteps*S]   subvol_temperature after the step (Population.py:692) */
+    double *E_sv;        /* [nsteps*S]   subvol_energy, normalised + reference (Population.py:724-728) */
+    double *E_raw;       /* [nsteps*S]   sum_i hbar*omega_i*dn_i per subvolume (Population.py:715-717) */
+    double *N_sv;        /* [nsteps*S]   subvol_N_p (Population.py:679) */
+    double *flux_raw;    /* [nsteps*S*3] sum_i v_i*e_i (Population.py:736); NaN on steps without flux tally */
+    double *N_leaving;   /* [nsteps*R]   particles absorbed by each reservoir (Population.py:1585) */
+    double *res_energy;  /* [nsteps*R]   this step's increment of res_energy_balance (Population.py:1595) */
+    double *res_flux;    /* [nsteps*R*3] this step's increment of res_heat_flux (Population.py:1602) */
+    double *N_emitted;   /* [nsteps]     particles that entered from reservoirs (Population.py:370) */
+} nk_tally;
+
+/* Kernel timing of the last nk_step call, from HIP events on the library's stream. */
+typedef struct {
+    double step_kernel_ms;   /* mean duration of the fused advect-scatter-tally kernel */
+    double emit_kernel_ms;   /* mean duration of the reservoir emission kernel */
+    double total_ms;         /* wall time of the whole call on the stream */
+    int64_t slots;           /* particle slots swept by the last step kernel */
+    int64_t live;            /* live particles after the call (this rank) */
+} nk_timing;
+
+/* lifetime: `Population.__init__` / end of run */
+int nk_create(nk_ctx **out, int device_id, uint64_t seed);
+void nk_destroy(nk_ctx *ctx);
+const char *nk_last_error(const nk_ctx *ctx);        /* ctx may be NULL: error of a failed nk_create */
+
+/* setup tables (copied to HBM) */
+int nk_set_material(nk_ctx *ctx, const nk_material *m);
+int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m);
+int nk_set_subvolumes(nk_ctx *ctx, const nk_subvols *s, const double *T_sv_init /* [S] */);
+int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r);
+int nk_set_rough(nk_ctx *ctx, const nk_rough *r);
+int nk_set_params(nk_ctx *ctx, const nk_params *p);
+
+/* particle state: Population.initialise_all_particles (Population.py:186-321) hands over positions, modes
+ * and occupations; n_ts/facet/pid may be NULL (then nk_init_boundaries computes the first two, and pid = index
+ * + pid_offset) */
+int nk_reserve(nk_ctx *ctx, int64_t capacity);
+int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y, const double *z,
+                        const int32_t *mode, const double *occ, const double *n_ts, const int32_t *facet,
+                        const uint64_t *pid, uint64_t pid_offset);
+/* Population.timesteps_to_boundary for the whole population (Population.py:310-314) */
+int nk_init_boundaries(nk_ctx *ctx);
+/* Population.run_timestep x nsteps (Population.py:1724-1769) without the file output */
+int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out);
+/* live particles, in slot order; arrays may be NULL; *N_out receives the count (call with capacity 0 to query) */
+int nk_download_particles(nk_ctx *ctx, int64_t capacity, double *x, double *y, double *z, int32_t *mode,
+                          double *occ, double *n_ts, int32_t *facet, uint64_t *pid, int64_t *N_out);
+int nk_get_subvol_temperature(nk_ctx *ctx, double *T_sv /* [S] */);
+int nk_set_subvol_temperature(nk_ctx *ctx, const double *T_sv /* [S] */);
+int nk_get_step(nk_ctx *ctx, int64_t *step);
+int nk_get_timing(nk_ctx *ctx, nk_timing *t);
+
+/* multi-GPU: one context per rank; tallies are all-reduced (sum, f64) over RCCL every step */
+int nk_comm_unique_id(void *id128 /* 128 bytes out */);
+int nk_comm_init(nk_ctx *ctx, const void *id128, int rank, int nranks);
+
+/* device versions of the reference's primitives, for parity tests (tests/ -m gpu) */
+int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x /* [n*3] */, const double *v /* [n*3] */,
+                     double *xc, double *tc, int32_t *fc);                       /* Mesh.py:806-856 */
+int nk_classify(nk_ctx *ctx, int64_t n, const double *x, int32_t *id);           /* Geometry.py:1212 */
+int nk_eval(nk_ctx *ctx, int32_t what, int64_t n, const double *a, const int32_t *mode, double *out);
+/* what: 0 occupation(T=a[i], omega[mode[i]]) Phonon.py:338; 1 lifetime(T=a[i], mode[i]) Phonon.py:336;
+ *       2 T(E=a[i]) Phonon.py:387; 3 E(T=a[i]) Phonon.py:390; 4 per-particle T at x=a[3i..] Population.py:696 */
+int nk_reflect(nk_ctx *ctx, int64_t n, const int32_t *facet, const int32_t *mode_in, const double *col_pos,
+               const double *n_in, const double *omega_in, const double *r_spec, const double *r_deg,
+               const double *r_diff, int32_t *mode_out, double *n_out, double *omega_out); /* Population.py:941-1015 */
+int nk_uniform2(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *u0, double *u1);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

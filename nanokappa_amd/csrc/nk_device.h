@@ -1,0 +1,371 @@
+// nk_device.h -- device-side data model and per-particle physics of the MI355X engine.
+//
+// One particle = one lane.  Particle state is SoA in HBM (x, y, z, occupation, time-to-boundary as
+// doubles; mode and next facet as int32; a 64-bit particle id that keys the counter-based RNG).
+// Small read-only tables (faces, facets, slice centres, subvolume temperatures) and the tally bins
+// live in LDS; per-mode tables are gathered from L2 / Infinity Cache.
+//
+// Reference semantics cited as file:line under the reference checkout (classes/Population.py etc.).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NK_WG 256          // threads per workgroup (4 waves of 64)
+#define NK_NREP 8          // LDS replicas of the tally bins (lane & 7) to thin same-address atomics
+#define NK_FACE_DOUBLES 20 // doubles per face record
+#define NK_LDS_FACES 256   // meshes up to this many faces keep their face table in LDS
+
+// RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")
+#define NK_TAG_REFLECT 0x00000u
+#define NK_TAG_EMIT 0x10000u
+#define NK_TAG_RESAMP 0x20000u
+#define NK_TAG_DICE 0x30000u
+
+struct NkFacet {          // 80 bytes
+    double cx, cy, cz;    // centroid
+    double nx, ny, nz;    // outward normal
+    int32_t bc;           // 'T','F','P','R'
+    int32_t partner;      // periodic partner facet or -1
+    int32_t res;          // reservoir index or -1
+    int32_t rough;        // rough-facet index or -1
+    int32_t pad[4];
+};
+
+// Everything a kernel needs, passed by value (pointers are device pointers).
+struct NkDev {
+    // ---- material
+    int32_t Q, J, NT, M;              // M = Q*J
+    const double4 *modetab;           // [M] {omega, vx, vy, vz}
+    const double *tau;                // [NT*M]
+    const double *Tgrid;              // [NT]
+    int32_t nE;
+    const double *Tarr, *Earr;        // [nE]
+    double Tfill_lo, Tfill_hi;
+    double hbar, kb, QV;
+    double active_modes;
+    // ---- mesh
+    int32_t F, Fc;
+    const double *faces;              // [F*NK_FACE_DOUBLES]
+    const int32_t *face_facet;        // [F]
+    const NkFacet *facets;            // [Fc]
+    double tol;
+    double bbox[6];
+    const double *face_verts;         // [F*9]
+    const int32_t *facet_face_off;    // [Fc+1]
+    const int32_t *facet_face_idx;
+    const double *facet_face_cdf;     // per facet, cumulative area fraction of its faces (same CSR)
+    int32_t nS;
+    const double *simplex_pts;        // [nS*12]
+    const double *simplex_cdf;        // [nS]
+    // ---- subvolumes
+    int32_t S, sv_kind, sv_axis, sv_interp;
+    const double *centers;            // [S*3]
+    const double *sv_volume;          // [S]
+    double sv_lo, sv_invL;            // slice fast path: first edge and 1/slice_length
+    double *T_sv;                     // [S] current subvolume temperatures (updated by k_update)
+    // ---- reservoirs
+    int32_t R, res_gen;
+    const int32_t *res_facet;         // [R]
+    const double *res_T;              // [R]
+    const double *enter_prob;         // [R*M]
+    double *res_counter;              // [R*M]
+    // ---- rough facets
+    int32_t Fr;
+    const double *specularity;        // [Fr*M]
+    const uint8_t *true_spec;         // [Fr*M]
+    const int32_t *spec_map;          // [Fr*M]
+    const double *roulette;           // [Fr*M]
+    const int32_t *degen_j2;          // [M] or null
+    // ---- parameters
+    double dt;
+    int32_t norm_fixed, T_ref_local;
+    double particle_density, T_ref;
+    uint64_t seed;
+    int32_t rank, nranks;
+    // ---- particles (SoA, capacity `cap`)
+    int64_t cap;
+    double *x, *y, *z, *occ, *nts;
+    int32_t *mode, *facet;
+    uint64_t *pid;
+    // ---- bookkeeping in device memory
+    int64_t *n_slots;                 // high-water slot count
+    int32_t *free_list;               // [cap] stack of dead slots
+    int32_t *free_top;                // entries on the stack
+    int32_t *alloc_count;             // slots requested by the emission kernel this step
+    int32_t *overflow;                // set when a particle had to be dropped for lack of capacity
+    double *partials;                 // [rows][NB] per-workgroup tally rows
+    int32_t NB;                       // bins per row = 5*S + 5*R + 1
+};
+
+// ------------------------------------------------------------------------------------------------ RNG
+// Philox4x32-10, counter = {pid_lo, pid_hi, step, tag}, key = seed.  Stateless: nothing is stored per particle.
+__device__ __forceinline__ void nk_philox(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                          uint32_t o[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__device__ __forceinline__ double nk_u53(uint32_t hi, uint32_t lo) {
+    uint64_t w = ((uint64_t)hi << 32) | lo;
+    return (double)(w >> 11) * (1.0 / 9007199254740992.0);
+}
+__device__ __forceinline__ void nk_uniform2_dev(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double &u0,
+                                                double &u1) {
+    uint32_t o[4];
+    nk_philox((uint32_t)pid, (uint32_t)(pid >> 32), step, tag, (uint32_t)seed, (uint32_t)(seed >> 32), o);
+    u0 = nk_u53(o[0], o[1]);
+    u1 = nk_u53(o[2], o[3]);
+}
+
+// ------------------------------------------------------------------------------------- small helpers
+// np.searchsorted(a, x, side='left') / 'right'
+__device__ __forceinline__ int nk_ss_left(const double *a, int n, double x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] < x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+__device__ __forceinline__ int nk_ss_right(const double *a, int n, double x) {
+    int lo = 0, hi = n;
+    while (lo < hi) { int mid = (lo + hi) >> 1; if (a[mid] <= x) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// Bose-Einstein occupation, Phonon.py:338-345
+__device__ __forceinline__ double nk_occupation(const NkDev &d, double T, double omega) {
+    if (!(T > 0.0) || !(omega > 0.0)) return 0.0;
+    return 1.0 / (exp(omega * d.hbar / (T * d.kb)) - 1.0);
+}
+// scipy interp1d(kind='linear') evaluation rule on a sorted table
+__device__ __forceinline__ double nk_interp_lin(const double *xs, const double *ys, int n, double x) {
+    int idx = nk_ss_left(xs, n, x);
+    idx = idx < 1 ? 1 : (idx > n - 1 ? n - 1 : idx);
+    double xlo = xs[idx - 1], xhi = xs[idx], ylo = ys[idx - 1], yhi = ys[idx];
+    return (yhi - ylo) / (xhi - xlo) * (x - xlo) + ylo;
+}
+// temperature_function (Phonon.py:387) and crystal_energy_function (Phonon.py:390)
+__device__ __forceinline__ double nk_T_of_E(const NkDev &d, double E) {
+    if (E < d.Earr[0]) return d.Tfill_lo;
+    if (E > d.Earr[d.nE - 1]) return d.Tfill_hi;
+    return nk_interp_lin(d.Earr, d.Tarr, d.nE, E);
+}
+__device__ __forceinline__ double nk_E_of_T(const NkDev &d, double T) {
+    if (T < d.Tarr[0]) return d.Earr[0];
+    if (T > d.Tarr[d.nE - 1]) return d.Earr[d.nE - 1];
+    return nk_interp_lin(d.Tarr, d.Earr, d.nE, T);
+}
+// lifetime_function = RegularGridInterpolator((T,q,j), tau) at integer (q,j): linear in tau along T (Phonon.py:336).
+// Out-of-table T gives NaN (the reference raises ValueError there).
+__device__ __forceinline__ double nk_lifetime(const NkDev &d, double T, int mode) {
+    const int NT = d.NT;
+    const double *g = d.Tgrid;
+    if (!(T >= g[0]) || !(T <= g[NT - 1])) return __builtin_nan("");
+    // uniform-grid guess, then the exact searchsorted fix-up
+    int i = (int)((T - g[0]) / (g[1] - g[0]));
+    i = i < 0 ? 0 : (i > NT - 1 ? NT - 1 : i);
+    while (i < NT && g[i] < T) ++i;          // i = number of grid points < T  (searchsorted left)
+    while (i > 0 && g[i - 1] >= T) --i;
+    i -= 1;
+    i = i < 0 ? 0 : (i > NT - 2 ? NT - 2 : i);
+    double y = (T - g[i]) / (g[i + 1] - g[i]);
+    double t0 = d.tau[(int64_t)i * d.M + mode], t1 = d.tau[(int64_t)(i + 1) * d.M + mode];
+    return t0 * (1.0 - y) + t1 * y;
+}
+
+// --------------------------------------------------------------------------------- subvolume lookups
+// `cen` points at the S*3 centres (LDS copy inside the hot kernels), `Tsv` at the S temperatures.
+// SubvolClassifier.predict, Geometry.py:1198-1213: nearest centre.
+__device__ __forceinline__ int nk_classify(const NkDev &d, const double *cen, double x, double y, double z) {
+    const int S = d.S;
+    if (d.sv_kind == 0) {
+        const int a = d.sv_axis;
+        double xa = a == 0 ? x : (a == 1 ? y : z);
+        int s = (int)floor((xa - d.sv_lo) * d.sv_invL);
+        s = s < 0 ? 0 : (s > S - 1 ? S - 1 : s);
+        while (s + 1 < S && fabs(xa - cen[3 * (s + 1) + a]) < fabs(xa - cen[3 * s + a])) ++s;
+        while (s > 0 && fabs(xa - cen[3 * (s - 1) + a]) <= fabs(xa - cen[3 * s + a])) --s;
+        return s;
+    }
+    int best = 0;
+    double dbest = __builtin_inf();
+    for (int s = 0; s < S; ++s) {
+        double dx = x - cen[3 * s], dy = y - cen[3 * s + 1], dz = z - cen[3 * s + 2];
+        double dd = dx * dx + dy * dy + dz * dz;
+        if (dd < dbest) { dbest = dd; best = s; }
+    }
+    return best;
+}
+// per-particle temperature, Population.py:570-571, :694-702
+__device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen, const double *Tsv, double x, double y,
+                                              double z, int sv_hint) {
+    const int S = d.S;
+    if (d.sv_interp == 2 || S == 1) return Tsv[sv_hint >= 0 ? sv_hint : nk_classify(d, cen, x, y, z)];
+    const int a = d.sv_axis;
+    double xa = a == 0 ? x : (a == 1 ? y : z);
+    int g = (int)floor((xa - d.sv_lo) * d.sv_invL);
+    g = g < 0 ? 0 : (g > S - 1 ? S - 1 : g);
+    if (d.sv_interp == 1) {
+        int idx = g;                                  // searchsorted(centres, xa, 'left')
+        while (idx < S && cen[3 * idx + a] < xa) ++idx;
+        while (idx > 0 && cen[3 * (idx - 1) + a] >= xa) --idx;
+        idx = idx < 1 ? 1 : (idx > S - 1 ? S - 1 : idx);
+        double xlo = cen[3 * (idx - 1) + a], xhi = cen[3 * idx + a], ylo = Tsv[idx - 1], yhi = Tsv[idx];
+        return (yhi - ylo) / (xhi - xlo) * (xa - xlo) + ylo;
+    }
+    // interp1d 'nearest': bounds b[i] = c[i+1]/2 + c[i]/2, idx = #(b < xa)
+    int idx = g;
+    while (idx < S - 1 && (cen[3 * (idx + 1) + a] / 2.0 + cen[3 * idx + a] / 2.0) < xa) ++idx;
+    while (idx > 0 && !((cen[3 * idx + a] / 2.0 + cen[3 * (idx - 1) + a] / 2.0) < xa)) --idx;
+    return Tsv[idx];
+}
+
+// -------------------------------------------------------------------------------------- ray casting
+// Mesh.find_boundary, Mesh.py:806-856: nearest valid triangle hit; first index wins ties; miss -> inf, -1.
+// Face record: n(3) k lo(3) hi(3) o(3) iu(3) iw(3) pad -> 20 doubles; iu/iw are the first two rows of the inverse of
+// face_basis_matrix, so (u, w) = rows . (c - o) is the solve() of Mesh.py:840.
+__device__ __forceinline__ void nk_find_boundary(const double *faces, const int32_t *face_facet, int F, double tol,
+                                                 double x, double y, double z, double vx, double vy, double vz,
+                                                 double &tc, int &fc) {
+    double tbest = __builtin_inf();
+    int fbest = -1;
+    for (int f = 0; f < F; ++f) {
+        const double *p = faces + f * NK_FACE_DOUBLES;
+        double num = x * p[0] + y * p[1] + z * p[2] + p[3];
+        double den = vx * p[0] + vy * p[1] + vz * p[2];
+        double t = -num / den;
+        if (!(t >= tol) || isinf(t)) continue;
+        double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
+        if (!(cx >= p[4] - tol) || !(cy >= p[5] - tol) || !(cz >= p[6] - tol) || !(cx <= p[7] + tol) ||
+            !(cy <= p[8] + tol) || !(cz <= p[9] + tol))
+            continue;
+        double bx = cx - p[10], by = cy - p[11], bz = cz - p[12];
+        double u = p[13] * bx + p[14] * by + p[15] * bz;
+        double w = p[16] * bx + p[17] * by + p[18] * bz;
+        double q = 1.0 - (u + w);
+        if (!(u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && q >= -tol && q <= 1.0 + tol)) continue;
+        if (t < tbest) { tbest = t; fbest = f; }
+    }
+    tc = tbest;
+    fc = fbest < 0 ? -1 : face_facet[fbest];
+}
+
+// ---------------------------------------------------------------------------------- rough reflection
+// select_reflected_modes + pick_diffuse_modes, Population.py:941-1015.
+__device__ __forceinline__ void nk_reflect(const NkDev &d, const double *cen, const double *Tsv, int rough_idx, int mode_in,
+                                           double cx, double cy, double cz, double n_in, double omega_in, double r_spec,
+                                           double r_deg, double r_diff, int &mode_out, double &n_out, double &omega_out) {
+    int64_t idx = (int64_t)rough_idx * d.M + mode_in;
+    bool spec = d.true_spec[idx] && (r_spec <= d.specularity[idx]);
+    if (spec) {
+        int out = d.spec_map[idx];
+        if (d.degen_j2) {
+            int j2 = d.degen_j2[out];
+            if (j2 > -1 && r_deg >= 0.5) out = (out / d.J) * d.J + j2;
+        }
+        mode_out = out; n_out = n_in; omega_out = omega_in;         // keeps the incoming omega
+    } else {
+        const double *roul = d.roulette + (int64_t)rough_idx * d.M;
+        double r = r_diff * roul[d.M - 1];
+        int flat = nk_ss_left(roul, d.M, r);
+        if (flat > d.M - 1) flat = d.M - 1;
+        mode_out = flat;
+        omega_out = d.modetab[flat].x;
+        double T = nk_interp_T(d, cen, Tsv, cx, cy, cz, -1);
+        n_out = nk_occupation(d, T, omega_out);
+    }
+}
+
+// --------------------------------------------------------------------------------- tally bins in LDS
+// Layout (doubles unless noted): E[NREP][S], flux[NREP][3S], resb[4R] (energy, fx, fy, fz), then uint32 N[NREP][S],
+// nleave[R], emitted[1].
+struct NkBins {
+    double *E, *flux, *resb;
+    unsigned int *N, *nleave, *misc;
+};
+
+// One particle's life inside a timestep after the free drift: Population.boundary_scattering (Population.py:1546-1683)
+// restated per particle.  On entry (x,y,z) is the end-of-step position of the free drift and nts < 0.
+struct NkParticle {
+    double x, y, z, occ, nts, omega, vx, vy, vz;
+    int mode, facet;
+    bool alive;
+};
+
+__device__ __forceinline__ void nk_events(const NkDev &d, const double *faces, const int32_t *face_facet,
+                                          const NkFacet *facets, const double *cen, const double *Tsv, NkBins &b,
+                                          NkParticle &p, uint64_t pid, uint32_t step) {
+    const double dt = d.dt;
+    double cts = 0.0;
+    uint32_t ev = 0;
+    while (cts < 1.0) {
+        double rem = 1.0 - cts;
+        if (rem > p.nts) {
+            int fi = p.facet < 0 ? d.Fc - 1 : p.facet;      // a miss indexes the last facet
+            const NkFacet fc = facets[fi];
+            if (fc.bc == 'T' || fc.bc == 'F') {             // I. absorbed by a reservoir, Population.py:1568-1608
+                int r = p.facet < 0 ? -1 : fc.res;
+                if (r >= 0) {
+                    double Tr = d.T_ref_local ? d.res_T[r] : d.T_ref;
+                    double e = d.hbar * p.omega * (p.occ - nk_occupation(d, Tr, p.omega));
+                    double vn = p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz;
+                    atomicAdd(&b.nleave[r], 1u);
+                    atomicAdd(&b.resb[4 * r + 0], -e);
+                    atomicAdd(&b.resb[4 * r + 1], e * p.vx / vn);
+                    atomicAdd(&b.resb[4 * r + 2], e * p.vy / vn);
+                    atomicAdd(&b.resb[4 * r + 3], e * p.vz / vn);
+                }
+                p.alive = false;
+                return;
+            }
+            double tcol = p.nts * dt;
+            double cx = p.x + p.vx * tcol, cy = p.y + p.vy * tcol, cz = p.z + p.vz * tcol;
+            double px = p.x, py = p.y, pz = p.z;
+            if (cts == 0.0) { px -= p.vx * dt; py -= p.vy * dt; pz -= p.vz * dt; }   // Population.py:1472-1474
+            double dist = sqrt((cx - px) * (cx - px) + (cy - py) * (cy - py) + (cz - pz) * (cz - pz));
+            double vnorm = sqrt(p.vx * p.vx + p.vy * p.vy + p.vz * p.vz);
+            cts += dist / (vnorm * dt);                                              // Population.py:1482 / :1514
+            if (fc.bc == 'P') {                                                      // II. periodic, :1463-1489
+                const NkFacet pf = facets[fc.partner];
+                p.x = cx + (pf.cx - fc.cx); p.y = cy + (pf.cy - fc.cy); p.z = cz + (pf.cz - fc.cz);
+            } else {                                                                 // III. rough, :1491-1544
+                double r0, r1;
+                nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);
+                p.x = cx; p.y = cy; p.z = cz;
+                int mo; double no, oo;
+                nk_reflect(d, cen, Tsv, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, r0, r1, r1, mo, no, oo);
+                p.mode = mo; p.occ = no; p.omega = oo;
+                double4 rec = d.modetab[mo];
+                p.vx = rec.y; p.vy = rec.z; p.vz = rec.w;
+            }
+            double tc; int fcn;
+            nk_find_boundary(faces, face_facet, d.F, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
+            p.nts = tc / dt;
+            p.facet = fcn;
+            if (++ev > 4096u) cts = 1.0;                     // the reference would spin
+        } else {                                             // IV. drift the remainder, :1673-1681
+            p.x += p.vx * dt * rem; p.y += p.vy * dt * rem; p.z += p.vz * dt * rem;
+            p.nts -= rem;
+            cts = 1.0;
+        }
+    }
+}
+
+// Population.calculate_energy's per-particle part (Population.py:704-717) + the heat-flux sum (:734-736).
+__device__ __forceinline__ void nk_tally_one(const NkDev &d, const double *cen, const double *Tsv, NkBins &b,
+                                         const NkParticle &p, bool do_flux, int rep) {
+    int s = nk_classify(d, cen, p.x, p.y, p.z);
+    double Tr = d.T_ref_local ? Tsv[s] : d.T_ref;
+    double e = d.hbar * p.omega * (p.occ - nk_occupation(d, Tr, p.omega));
+    atomicAdd(&b.E[rep * d.S + s], e);
+    atomicAdd(&b.N[rep * d.S + s], 1u);
+    if (do_flux) {
+        double *fl = b.flux + (rep * d.S + s) * 3;
+        atomicAdd(fl + 0, p.vx * e);
+        atomicAdd(fl + 1, p.vy * e);
+        atomicAdd(fl + 2, p.vz * e);
+    }
+}

@@ -1,0 +1,375 @@
+"""ctypes binding of libnanokappa_hip.so (include/nanokappa_hip.h) and a thin `Engine` object.
+
+No CPU fallback: if the library is missing it must be built (`python -c "import __graft_entry__ as g;
+g.build()"` or `make -C nanokappa_amd/csrc`), and `Engine()` raises when no gfx950 device is present.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libnanokappa_hip.so')
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_bp = C.POINTER(C.c_int8)
+c_up = C.POINTER(C.c_uint8)
+c_u64p = C.POINTER(C.c_uint64)
+
+
+class NkError(RuntimeError):
+    pass
+
+
+class nk_material(C.Structure):
+    _fields_ = [('Q', C.c_int32), ('J', C.c_int32), ('NT', C.c_int32),
+                ('omega', c_dp), ('group_vel', c_dp), ('T_grid', c_dp), ('lifetime', c_dp),
+                ('nE', C.c_int32), ('T_fill_lo', C.c_double), ('T_fill_hi', C.c_double),
+                ('T_array', c_dp), ('energy_array', c_dp),
+                ('hbar', C.c_double), ('kb', C.c_double), ('QV', C.c_double), ('active_modes', C.c_int32)]
+
+
+class nk_mesh(C.Structure):
+    _fields_ = [('F', C.c_int32), ('normals', c_dp), ('k', c_dp), ('bounds_lo', c_dp), ('bounds_hi', c_dp),
+                ('basis', c_dp), ('origins', c_dp), ('face_facet', c_ip), ('vertices', c_dp), ('face_area', c_dp),
+                ('Fc', C.c_int32), ('facet_bc', c_bp), ('facet_partner', c_ip), ('facet_centroid', c_dp),
+                ('facet_normal', c_dp), ('facet_face_off', c_ip), ('facet_face_idx', c_ip),
+                ('tol', C.c_double), ('bbox', C.c_double * 6),
+                ('nS', C.c_int32), ('simplex_pts', c_dp), ('simplex_vol', c_dp)]
+
+
+class nk_subvols(C.Structure):
+    _fields_ = [('S', C.c_int32), ('kind', C.c_int32), ('axis', C.c_int32), ('interp', C.c_int32),
+                ('centers', c_dp), ('volumes', c_dp)]
+
+
+class nk_reservoirs(C.Structure):
+    _fields_ = [('R', C.c_int32), ('facet', c_ip), ('T', c_dp), ('enter_prob', c_dp), ('counter', c_dp),
+                ('gen', C.c_int32)]
+
+
+class nk_rough(C.Structure):
+    _fields_ = [('Fr', C.c_int32), ('facet', c_ip), ('specularity', c_dp), ('true_spec', c_up),
+                ('spec_map', c_ip), ('roulette', c_dp), ('degen_j2', c_ip)]
+
+
+class nk_params(C.Structure):
+    _fields_ = [('dt', C.c_double), ('norm_fixed', C.c_int32), ('particle_density', C.c_double),
+                ('T_ref_local', C.c_int32), ('T_ref', C.c_double), ('flux_every', C.c_int32),
+                ('contains_every', C.c_int32)]
+
+
+class nk_tally(C.Structure):
+    _fields_ = [('T_sv', c_dp), ('E_sv', c_dp), ('E_raw', c_dp), ('N_sv', c_dp), ('flux_raw', c_dp),
+                ('N_leaving', c_dp), ('res_energy', c_dp), ('res_flux', c_dp), ('N_emitted', c_dp)]
+
+
+class nk_timing(C.Structure):
+    _fields_ = [('step_kernel_ms', C.c_double), ('emit_kernel_ms', C.c_double), ('total_ms', C.c_double),
+                ('slots', C.c_int64), ('live', C.c_int64)]
+
+
+EXPORTS = ['nk_create', 'nk_destroy', 'nk_last_error', 'nk_set_material', 'nk_set_mesh', 'nk_set_subvolumes',
+           'nk_set_reservoirs', 'nk_set_rough', 'nk_set_params', 'nk_reserve', 'nk_upload_particles',
+           'nk_init_boundaries', 'nk_step', 'nk_download_particles', 'nk_get_subvol_temperature',
+           'nk_set_subvol_temperature', 'nk_get_step', 'nk_get_timing', 'nk_comm_unique_id', 'nk_comm_init',
+           'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2']
+
+_lib = None
+
+
+def load_library():
+    """Load libnanokappa_hip.so; raises NkError with build instructions when it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NkError('%s not found: build it with `make -C %s` (needs hipcc); there is no CPU fallback'
+                      % (LIB_PATH, os.path.join(_HERE, 'csrc')))
+    L = C.CDLL(LIB_PATH)
+    L.nk_last_error.restype = C.c_char_p
+    L.nk_last_error.argtypes = [C.c_void_p]
+    L.nk_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_uint64]
+    L.nk_destroy.argtypes = [C.c_void_p]
+    L.nk_destroy.restype = None
+    for name, st in (('nk_set_material', nk_material), ('nk_set_mesh', nk_mesh), ('nk_set_reservoirs', nk_reservoirs),
+                     ('nk_set_rough', nk_rough), ('nk_set_params', nk_params)):
+        getattr(L, name).argtypes = [C.c_void_p, C.POINTER(st)]
+    L.nk_set_subvolumes.argtypes = [C.c_void_p, C.POINTER(nk_subvols), c_dp]
+    L.nk_reserve.argtypes = [C.c_void_p, C.c_int64]
+    L.nk_upload_particles.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_ip, c_u64p, C.c_uint64]
+    L.nk_init_boundaries.argtypes = [C.c_void_p]
+    L.nk_step.argtypes = [C.c_void_p, C.c_int32, C.POINTER(nk_tally)]
+    L.nk_download_particles.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_ip, c_u64p,
+                                        C.POINTER(C.c_int64)]
+    L.nk_get_subvol_temperature.argtypes = [C.c_void_p, c_dp]
+    L.nk_set_subvol_temperature.argtypes = [C.c_void_p, c_dp]
+    L.nk_get_step.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+    L.nk_get_timing.argtypes = [C.c_void_p, C.POINTER(nk_timing)]
+    L.nk_comm_unique_id.argtypes = [C.c_void_p]
+    L.nk_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.nk_find_boundary.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_ip]
+    L.nk_classify.argtypes = [C.c_void_p, C.c_int64, c_dp, c_ip]
+    L.nk_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int64, c_dp, c_ip, c_dp]
+    L.nk_reflect.argtypes = [C.c_void_p, C.c_int64, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp]
+    L.nk_uniform2.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, c_dp, c_dp]
+    _lib = L
+    return L
+
+
+def _d(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _p(a, t=c_dp):
+    return None if a is None else a.ctypes.data_as(t)
+
+
+def bc_codes(bound_cond):
+    """'T'/'P'/'R' strings (Geometry.bound_cond) or int8 codes -> int8 codes."""
+    a = np.asarray(bound_cond)
+    if a.dtype.kind in 'US':
+        return np.array([ord(str(c)[0]) for c in a], dtype=np.int8)
+    return np.ascontiguousarray(a, dtype=np.int8)
+
+
+def comm_unique_id():
+    """128-byte RCCL unique id (rank 0 creates it, every rank passes it to Engine.comm_init)."""
+    L = load_library()
+    buf = C.create_string_buffer(128)
+    rc = L.nk_comm_unique_id(buf)
+    if rc != 0:
+        raise NkError('nk_comm_unique_id failed: %s' % L.nk_last_error(None).decode())
+    return buf.raw
+
+
+class Engine(object):
+    """One nk_ctx: tables + particle store on one MI355X."""
+
+    def __init__(self, device=0, seed=0):
+        self.L = load_library()
+        h = C.c_void_p()
+        rc = self.L.nk_create(C.byref(h), int(device), C.c_uint64(int(seed)))
+        if rc != 0:
+            raise NkError('nk_create failed (%d): %s' % (rc, self.L.nk_last_error(None).decode()))
+        self.h = h
+        self.S = self.R = self.J = self.M = 0
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.L.nk_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, what):
+        if rc != 0:
+            raise NkError('%s failed (%d): %s' % (what, rc, self.L.nk_last_error(self.h).decode()))
+
+    # ------------------------------------------------------------------ tables
+    def set_material(self, t):
+        """t: Phonon.tables()"""
+        m = nk_material()
+        om, vg, tg, lt = _d(t['omega']), _d(t['group_vel']), _d(t['T_grid']), _d(t['lifetime'])
+        ta, ea = _d(t['T_array']), _d(t['energy_array'])
+        m.Q, m.J = om.shape
+        m.NT = tg.shape[0]
+        m.omega, m.group_vel, m.T_grid, m.lifetime = _p(om), _p(vg), _p(tg), _p(lt)
+        m.nE = ta.shape[0]
+        m.T_fill_lo, m.T_fill_hi = float(tg.min()), float(tg.max())
+        m.T_array, m.energy_array = _p(ta), _p(ea)
+        m.hbar, m.kb, m.QV = float(t['hbar']), float(t['kb']), float(t['QV'])
+        m.active_modes = int(t['active_modes'])
+        self._ck(self.L.nk_set_material(self.h, C.byref(m)), 'nk_set_material')
+        self.J = int(m.J)
+        self.M = int(m.Q * m.J)
+
+    def set_mesh(self, g):
+        """g: mapping with the reference's Mesh/Geometry attribute names (face_normals, face_k, face_bounds,
+        face_basis_matrix, face_origins, face_facets, vertices, faces, face_areas, bound_cond, connected_facets,
+        facet_centroid, facets_normal, facets | facets_flat+facets_len, bounds, simplices*)."""
+        m = nk_mesh()
+        nrm, k = _d(g['face_normals']), _d(g['face_k'])
+        fb = np.asarray(g['face_bounds'], dtype=np.float64)
+        lo, hi = _d(fb[0]), _d(fb[1])
+        basis, org, ff = _d(g['face_basis_matrix']), _d(g['face_origins']), _i(g['face_facets'])
+        verts = _d(np.asarray(g['vertices'])[np.asarray(g['faces'], dtype=int)])
+        area = _d(g['face_areas'])
+        m.F = nrm.shape[0]
+        m.normals, m.k, m.bounds_lo, m.bounds_hi = _p(nrm), _p(k), _p(lo), _p(hi)
+        m.basis, m.origins, m.face_facet, m.vertices, m.face_area = _p(basis), _p(org), _p(ff, c_ip), _p(verts), _p(area)
+        bc = bc_codes(g['bound_cond'])
+        Fc = bc.shape[0]
+        partner = -np.ones(Fc, dtype=np.int32)
+        for a, b in np.asarray(g.get('connected_facets', np.zeros((0, 2))), dtype=int).reshape(-1, 2):
+            partner[a], partner[b] = b, a
+        cen, fn = _d(g['facet_centroid']), _d(g['facets_normal'])
+        if 'facets_flat' in g:
+            flat, ln = _i(g['facets_flat']), np.asarray(g['facets_len'], dtype=int)
+        else:
+            flat, ln = _i(np.concatenate(g['facets'])), np.array([len(f) for f in g['facets']])
+        off = _i(np.concatenate(([0], np.cumsum(ln))))
+        m.Fc = Fc
+        m.facet_bc, m.facet_partner, m.facet_centroid, m.facet_normal = _p(bc, c_bp), _p(partner, c_ip), _p(cen), _p(fn)
+        m.facet_face_off, m.facet_face_idx = _p(off, c_ip), _p(flat, c_ip)
+        m.tol = float(g.get('tol', 1e-10))
+        b = np.asarray(g['bounds'], dtype=np.float64)
+        for d in range(3):
+            m.bbox[d], m.bbox[3 + d] = b[0, d], b[1, d]
+        if 'simplices' in g and len(g['simplices']):
+            sp = _d(np.asarray(g['simplices_points'])[np.asarray(g['simplices'], dtype=int)])
+            sv = _d(g['simplices_volumes'])
+            m.nS = sv.shape[0]
+            m.simplex_pts, m.simplex_vol = _p(sp), _p(sv)
+        else:
+            m.nS = 0
+        self._ck(self.L.nk_set_mesh(self.h, C.byref(m)), 'nk_set_mesh')
+
+    def set_subvolumes(self, centers, volumes, kind, axis, interp, T_sv):
+        s = nk_subvols()
+        c, v, t = _d(centers), _d(volumes), _d(T_sv)
+        s.S = c.shape[0]
+        s.kind, s.axis, s.interp = int(kind), int(axis), int(interp)
+        s.centers, s.volumes = _p(c), _p(v)
+        self._ck(self.L.nk_set_subvolumes(self.h, C.byref(s), _p(t)), 'nk_set_subvolumes')
+        self.S = int(s.S)
+
+    def set_reservoirs(self, facets, T, enter_prob, counter, gen=0):
+        r = nk_reservoirs()
+        f, t, ep, cn = _i(facets), _d(T), _d(enter_prob), _d(counter)
+        r.R = f.shape[0]
+        r.facet, r.T, r.enter_prob, r.counter = _p(f, c_ip), _p(t), _p(ep), _p(cn)
+        r.gen = int(gen)
+        self._ck(self.L.nk_set_reservoirs(self.h, C.byref(r)), 'nk_set_reservoirs')
+        self.R = int(r.R)
+
+    def set_rough(self, facets, specularity, true_spec, spec_map, roulette, degen_j2=None):
+        r = nk_rough()
+        f, sp, ts = _i(facets), _d(specularity), np.ascontiguousarray(true_spec, dtype=np.uint8)
+        sm, ro = _i(spec_map), _d(roulette)
+        dj = None if degen_j2 is None else _i(degen_j2)
+        r.Fr = f.shape[0]
+        r.facet, r.specularity, r.true_spec, r.spec_map, r.roulette = _p(f, c_ip), _p(sp), _p(ts, c_up), _p(sm, c_ip), _p(ro)
+        r.degen_j2 = _p(dj, c_ip)
+        self._ck(self.L.nk_set_rough(self.h, C.byref(r)), 'nk_set_rough')
+
+    def set_params(self, dt=1.0, norm_fixed=False, particle_density=0.0, T_ref=None, flux_every=10, contains_every=100):
+        p = nk_params()
+        p.dt, p.norm_fixed, p.particle_density = float(dt), int(bool(norm_fixed)), float(particle_density)
+        p.T_ref_local = 1 if T_ref is None else 0
+        p.T_ref = 0.0 if T_ref is None else float(T_ref)
+        p.flux_every, p.contains_every = int(flux_every), int(contains_every)
+        self._ck(self.L.nk_set_params(self.h, C.byref(p)), 'nk_set_params')
+
+    # --------------------------------------------------------------- particles
+    def reserve(self, capacity):
+        self._ck(self.L.nk_reserve(self.h, int(capacity)), 'nk_reserve')
+
+    def upload(self, positions, mode, occ, n_ts=None, facet=None, pid=None, pid_offset=0):
+        pos = np.asarray(positions, dtype=np.float64)
+        x, y, z = _d(pos[:, 0]), _d(pos[:, 1]), _d(pos[:, 2])
+        m, o = _i(mode), _d(occ)
+        nt = None if n_ts is None else _d(n_ts)
+        fc = None if facet is None else _i(facet)
+        pi = None if pid is None else np.ascontiguousarray(pid, dtype=np.uint64)
+        self._ck(self.L.nk_upload_particles(self.h, x.shape[0], _p(x), _p(y), _p(z), _p(m, c_ip), _p(o), _p(nt),
+                                            _p(fc, c_ip), _p(pi, c_u64p), C.c_uint64(int(pid_offset))),
+                 'nk_upload_particles')
+
+    def init_boundaries(self):
+        self._ck(self.L.nk_init_boundaries(self.h), 'nk_init_boundaries')
+
+    def step(self, nsteps=1):
+        """Run nsteps timesteps; returns a dict of per-step arrays (see nk_tally in the header)."""
+        S, R = self.S, max(self.R, 0)
+        out = dict(T_sv=np.zeros((nsteps, S)), E_sv=np.zeros((nsteps, S)), E_raw=np.zeros((nsteps, S)),
+                   N_sv=np.zeros((nsteps, S)), flux_raw=np.zeros((nsteps, S, 3)),
+                   N_leaving=np.zeros((nsteps, R)), res_energy=np.zeros((nsteps, R)),
+                   res_flux=np.zeros((nsteps, R, 3)), N_emitted=np.zeros(nsteps))
+        t = nk_tally()
+        for k in out:
+            setattr(t, k, _p(out[k]))
+        self._ck(self.L.nk_step(self.h, int(nsteps), C.byref(t)), 'nk_step')
+        return out
+
+    def download(self):
+        n = C.c_int64(0)
+        self._ck(self.L.nk_download_particles(self.h, 0, None, None, None, None, None, None, None, None, C.byref(n)),
+                 'nk_download_particles')
+        N = int(n.value)
+        x, y, z, occ, nts = (np.zeros(N) for _ in range(5))
+        mode, facet = np.zeros(N, dtype=np.int32), np.zeros(N, dtype=np.int32)
+        pid = np.zeros(N, dtype=np.uint64)
+        if N:
+            self._ck(self.L.nk_download_particles(self.h, N, _p(x), _p(y), _p(z), _p(mode, c_ip), _p(occ), _p(nts),
+                                                  _p(facet, c_ip), _p(pid, c_u64p), C.byref(n)), 'nk_download_particles')
+        return dict(positions=np.stack((x, y, z), axis=1), mode=mode, occupation=occ, n_timesteps=nts, facet=facet, pid=pid)
+
+    def subvol_temperature(self):
+        t = np.zeros(self.S)
+        self._ck(self.L.nk_get_subvol_temperature(self.h, _p(t)), 'nk_get_subvol_temperature')
+        return t
+
+    def set_subvol_temperature(self, T):
+        t = _d(T)
+        self._ck(self.L.nk_set_subvol_temperature(self.h, _p(t)), 'nk_set_subvol_temperature')
+
+    def timing(self):
+        t = nk_timing()
+        self._ck(self.L.nk_get_timing(self.h, C.byref(t)), 'nk_get_timing')
+        return dict(step_kernel_ms=t.step_kernel_ms, emit_kernel_ms=t.emit_kernel_ms, total_ms=t.total_ms,
+                    slots=int(t.slots), live=int(t.live))
+
+    def comm_init(self, unique_id, rank, nranks):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._ck(self.L.nk_comm_init(self.h, buf, int(rank), int(nranks)), 'nk_comm_init')
+
+    # -------------------------------------------------------------------- taps
+    def find_boundary(self, x, v):
+        x, v = _d(x), _d(v)
+        n = x.shape[0]
+        xc, tc, fc = np.zeros((n, 3)), np.zeros(n), np.zeros(n, dtype=np.int32)
+        self._ck(self.L.nk_find_boundary(self.h, n, _p(x), _p(v), _p(xc), _p(tc), _p(fc, c_ip)), 'nk_find_boundary')
+        return xc, tc, fc
+
+    def classify(self, x):
+        x = _d(x)
+        out = np.zeros(x.shape[0], dtype=np.int32)
+        self._ck(self.L.nk_classify(self.h, x.shape[0], _p(x), _p(out, c_ip)), 'nk_classify')
+        return out
+
+    def eval(self, what, a, mode=None):
+        code = {'occupation': 0, 'lifetime': 1, 'T_of_E': 2, 'E_of_T': 3, 'interp_T': 4}[what]
+        a = _d(a)
+        n = a.shape[0]
+        m = None if mode is None else _i(mode)
+        out = np.zeros(n)
+        self._ck(self.L.nk_eval(self.h, code, n, _p(a), _p(m, c_ip), _p(out)), 'nk_eval')
+        return out
+
+    def reflect(self, facet, mode_in, col_pos, n_in, omega_in, r_spec, r_deg, r_diff):
+        f, m, c = _i(facet), _i(mode_in), _d(col_pos)
+        n = f.shape[0]
+        a = [_d(v) for v in (n_in, omega_in, r_spec)]
+        rd = None if r_deg is None else _d(r_deg)
+        rf = _d(r_diff)
+        mo, no, oo = np.zeros(n, dtype=np.int32), np.zeros(n), np.zeros(n)
+        self._ck(self.L.nk_reflect(self.h, n, _p(f, c_ip), _p(m, c_ip), _p(c), _p(a[0]), _p(a[1]), _p(a[2]), _p(rd),
+                                   _p(rf), _p(mo, c_ip), _p(no), _p(oo)), 'nk_reflect')
+        return mo, no, oo
+
+    def uniform2(self, seed, pid, step, tag):
+        u0, u1 = C.c_double(), C.c_double()
+        rc = self.L.nk_uniform2(C.c_uint64(seed), C.c_uint64(pid), C.c_uint32(step), C.c_uint32(tag), C.byref(u0), C.byref(u1))
+        if rc != 0:
+            raise NkError('nk_uniform2 failed')
+        return u0.value, u1.value

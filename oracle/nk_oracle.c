@@ -321,6 +321,10 @@ int64_t nko_emit(const nko_material *mat, const nko_mesh *mesh, nko_reservoirs *
                 find_boundary_one(mesh, x, v, xc, &tc, &fc);
                 P->n_ts[i] = tc / p->dt - dt_in / p->dt;                                 /* :535 */
                 for (int d = 0; d < 3; ++d) P->pos[3 * i + d] = x[d] + v[d] * dt_in;     /* :536 */
+                if (res->dbg_dt_in) res->dbg_dt_in[i] = dt_in;
+                if (res->dbg_x0) { res->dbg_x0[3 * i] = x[0]; res->dbg_x0[3 * i + 1] = x[1]; res->dbg_x0[3 * i + 2] = x[2]; }
+                if (res->dbg_level) res->dbg_level[i] = level;
+                if (res->dbg_res) res->dbg_res[i] = r;
                 P->facet[i] = fc;
                 P->mode[i] = (int32_t)m;
                 P->occ[i] = occupation(mat, res->T[r], mat->omega[m]);                   /* :506 */

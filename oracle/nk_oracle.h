@@ -75,6 +75,11 @@ typedef struct {
     const double *enter_prob;/* [R*Q*J] Population.py:146-161 */
     double *counter;         /* [R*Q*J] state, Population.py:343, :361-365 */
     int32_t gen;             /* 0 constant, 1 fixed_rate */
+    /* optional test taps (NULL = off), indexed by the slot the new particle is appended to */
+    double *dbg_dt_in;       /* [cap]   entry-time offset, Population.py:391-394 */
+    double *dbg_x0;          /* [cap*3] sampled position on the facet, Mesh.py:949 */
+    int32_t *dbg_level;      /* [cap]   which of the mode's particles (1 = deterministic time) */
+    int32_t *dbg_res;        /* [cap]   reservoir index */
 } nko_reservoirs;
 
 typedef struct {

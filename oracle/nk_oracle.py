@@ -45,7 +45,7 @@ class Subvols(C.Structure):
 
 class Reservoirs(C.Structure):
     _fields_ = [('R', C.c_int32), ('facet', c_ip), ('T', c_dp), ('enter_prob', c_dp), ('counter', c_dp),
-                ('gen', C.c_int32)]
+                ('gen', C.c_int32), ('dbg_dt_in', c_dp), ('dbg_x0', c_dp), ('dbg_level', c_ip), ('dbg_res', c_ip)]
 
 
 class Rough(C.Structure):
@@ -183,6 +183,17 @@ def make_reservoirs(facets, T, enter_prob, counter, gen=0):
     _keep(r, f, t, ep, cn)
     r.counter_array = cn
     return r
+
+
+def attach_emission_taps(res, cap):
+    """Allocate the optional debug outputs of nko_emit."""
+    res.tap_dt_in = np.full(cap, np.nan)
+    res.tap_x0 = np.full((cap, 3), np.nan)
+    res.tap_level = np.zeros(cap, dtype=np.int32)
+    res.tap_res = np.zeros(cap, dtype=np.int32)
+    res.dbg_dt_in, res.dbg_x0 = _p(res.tap_dt_in, c_dp), _p(res.tap_x0, c_dp)
+    res.dbg_level, res.dbg_res = _p(res.tap_level, c_ip), _p(res.tap_res, c_ip)
+    return res
 
 
 def make_rough(facets, specularity, true_spec, spec_map, roulette, degen_j2=None):

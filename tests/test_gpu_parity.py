@@ -1,0 +1,161 @@
+"""Parity of the HIP engine (through the C ABI) against the reference goldens and the CPU oracle.
+Needs a real MI355X: run with `pytest -m gpu`."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import golden, sub, golden_phonon, rel_err, case_tables, random_population, make_oracle_sim, make_engine
+
+pytestmark = pytest.mark.gpu
+
+
+def base_engine(name, interp=1, seed=1):
+    from nanokappa_amd.engine import Engine
+    g = sub(golden('mesh'), name)
+    ph = golden_phonon()
+    eng = Engine(0, seed)
+    eng.set_material(ph.tables())
+    eng.set_mesh(g)
+    eng.set_subvolumes(g['subvol_center'], g['subvol_volume'], 0, int(g['slice_axis']), interp,
+                       np.full(g['subvol_center'].shape[0], 300.0))
+    return eng, g, ph
+
+
+@pytest.mark.parametrize('name', ['box200', 'box200ttp', 'box5000', 'cyl'])
+def test_find_boundary(name):
+    eng, g, ph = base_engine(name)
+    xc, tc, fc = eng.find_boundary(g['ray_x'], g['ray_v'])
+    assert np.array_equal(fc, g['ray_fc'])
+    hit = fc >= 0
+    assert rel_err(tc[hit], g['ray_tc'][hit]) < 1e-12
+    assert np.all(np.isinf(tc[~hit]))
+    assert np.allclose(xc[hit], g['ray_xc'][hit], rtol=1e-12, atol=1e-9)
+
+
+@pytest.mark.parametrize('name', ['box200', 'box5000', 'cyl'])
+def test_classifier(name):
+    eng, g, ph = base_engine(name)
+    assert np.array_equal(eng.classify(g['cls_x']), g['cls_id'])
+
+
+def test_material_functions():
+    eng, g, ph = base_engine('box200')
+    gp = golden('phonon')
+    mode = (gp['s_q'] * ph.number_of_branches + gp['s_j']).astype(np.int32)
+    assert rel_err(eng.eval('occupation', gp['s_T'], mode), gp['s_occ']) < 1e-12
+    assert rel_err(eng.eval('lifetime', gp['s_T'], mode), gp['s_tau']) < 1e-12
+    assert rel_err(eng.eval('E_of_T', gp['s_Tw']), ph.crystal_energy_function(gp['s_Tw'])) < 1e-13
+    assert rel_err(eng.eval('T_of_E', gp['s_E']), ph.temperature_function(gp['s_E'])) < 1e-12
+
+
+def test_philox_matches_oracle():
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), '..', 'oracle'))
+    import ctypes as C
+    import nk_oracle as O
+    eng, g, ph = base_engine('box200')
+    for seed, pid, step, tag in [(0, 0, 0, 0), (1234, 77, 5, 0x10001), (2 ** 63 + 5, 2 ** 40 + 3, 999, 0x20002)]:
+        a, b = C.c_double(), C.c_double()
+        O.lib().nko_uniform2(C.c_uint64(seed), C.c_uint64(pid), C.c_uint32(step), C.c_uint32(tag), C.byref(a), C.byref(b))
+        assert eng.uniform2(seed, pid, step, tag) == (a.value, b.value)
+
+
+@pytest.mark.parametrize('model', ['velocity', 'k'])
+def test_reflect(model):
+    ct = case_tables('ttrrp', model)
+    g = sub(golden('reflect'), model)
+    gs = sub(golden('setup'), model)
+    J = ct['J']
+    from nanokappa_amd.engine import Engine
+    eng = Engine(0, 3)
+    eng.set_material(ct['tables'])
+    eng.set_mesh(ct['mesh'])
+    eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], 1, g['subvol_temperature'])
+    degen = None
+    if model == 'k':
+        di = gs['degen_index'].astype(int).ravel()
+        dg = gs['degeneracies'].astype(int).reshape(-1, 3)
+        degen = np.where(di > -1, dg[np.clip(di, 0, max(dg.shape[0] - 1, 0)), 2] if dg.shape[0] else -1, -1)
+    r = ct['rough']
+    eng.set_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'], degen)
+    mo, no, oo = eng.reflect(g['facets'], g['in_modes'][:, 0] * J + g['in_modes'][:, 1], g['col_pos'], g['n_in'],
+                             g['omega_in'], g['r_spec'], np.nan_to_num(g['r_deg']), np.nan_to_num(g['r_diff']))
+    assert np.array_equal(mo, g['out_modes'][:, 0] * J + g['out_modes'][:, 1])
+    assert rel_err(oo, g['omega_out']) < 1e-14
+    assert rel_err(no, g['n_out']) < 1e-12
+
+
+@pytest.mark.parametrize('variant', ['lin', 'near', 'fixed', 'tref'])
+def test_frozen_step_vs_reference(variant):
+    """One full timestep on a frozen reference state (no emission): the engine must reproduce the reference's
+    drift -> boundary_scattering -> refresh_temperatures -> lifetime_scattering -> heat flux."""
+    from nanokappa_amd.engine import Engine
+    gm = sub(golden('mesh'), 'box200ttp')
+    gs = sub(golden('step'), variant)
+    ph = golden_phonon()
+    J = ph.number_of_branches
+    M = ph.number_of_qpoints * J
+    interp = {'lin': 1, 'near': 0, 'fixed': 1, 'tref': 1}[variant]
+    eng = Engine(0, 1)
+    eng.set_material(ph.tables())
+    eng.set_mesh(gm)
+    eng.set_subvolumes(gm['subvol_center'], gm['subvol_volume'], 0, int(gm['slice_axis']), interp, gs['pre_subvol_temperature'])
+    eng.set_reservoirs(gm['res_facets'], gs['res_facet_temperature'], np.zeros((2, M)), np.zeros((2, M)))
+    eng.set_params(dt=1.0, norm_fixed=(variant == 'fixed'), particle_density=float(gs['particle_density']),
+                   T_ref=(300.0 if variant == 'tref' else None), flux_every=1, contains_every=0)
+    eng.upload(gs['pre_positions'], gs['pre_modes'][:, 0] * J + gs['pre_modes'][:, 1], gs['pre_occupation'],
+               gs['pre_n_timesteps'], gs['pre_collision_facets'])
+    t = eng.step(1)
+    assert np.array_equal(t['N_leaving'][0], gs['mid_N_leaving'])
+    assert rel_err(t['res_energy'][0], gs['mid_res_energy_balance']) < 1e-10
+    assert np.allclose(t['res_flux'][0], gs['mid_res_heat_flux'], rtol=1e-10, atol=1e-12)
+    assert np.array_equal(t['N_sv'][0], gs['post_subvol_N_p'])
+    assert rel_err(t['E_sv'][0], gs['post_subvol_energy']) < 1e-12
+    assert np.allclose(t['T_sv'][0], gs['post_subvol_temperature'], rtol=0, atol=1e-7)
+    # heat flux: Population.calculate_heat_flux scalings (Population.py:738-747)
+    if variant == 'fixed':
+        norm = ph.number_of_active_modes / (float(gs['particle_density']) * gm['subvol_volume'])
+    else:
+        norm = ph.number_of_active_modes / t['N_sv'][0]
+    flux = t['flux_raw'][0] * norm[:, None] / (ph.number_of_qpoints * ph.volume_unitcell) * ph.eVpsa2_in_Wm2
+    assert np.allclose(flux, gs['heat_flux'], rtol=1e-8, atol=1e-3)
+    p = eng.download()          # flushes the deferred relaxation = lifetime_scattering
+    n = gs['mid_positions'].shape[0]
+    assert p['mode'].shape[0] == n
+    assert np.array_equal(p['mode'], gs['mid_modes'][:, 0] * J + gs['mid_modes'][:, 1])
+    assert np.array_equal(p['facet'], gs['mid_collision_facets'])
+    assert np.allclose(p['positions'], gs['mid_positions'], rtol=1e-12, atol=1e-9)
+    assert np.allclose(p['n_timesteps'], gs['mid_n_timesteps'], rtol=1e-9, atol=1e-9)
+    assert rel_err(p['occupation'], gs['post_occupation']) < 1e-9
+
+
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
+def test_multistep_vs_oracle(case):
+    """Same seed, same counter-based RNG: engine and oracle must make the same decisions; compare the
+    per-step tallies and the final particle set (matched by particle id)."""
+    ct = case_tables(case)
+    pos, mode, occ, counter = random_population(ct, 30000, seed=5)
+    nsteps = 25
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=42)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=42)
+    t = eng.step(nsteps)
+    for s in range(nsteps):
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.array_equal(t['N_leaving'][s], sim.N_leaving[:2]), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+        assert rel_err(t['E_sv'][s], sim.E_sv) < 1e-11
+    p = eng.download()
+    n = sim.P.N
+    assert p['pid'].shape[0] == n
+    o1 = np.argsort(p['pid'])
+    o2 = np.argsort(sim.P.pid[:n])
+    assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
+    assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
+    assert np.array_equal(p['facet'][o1], sim.P.facet[:n][o2])
+    assert np.allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=1e-8)
+    assert np.allclose(p['n_timesteps'][o1], sim.P.n_ts[:n][o2], rtol=1e-8, atol=1e-8)
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+    # accumulated reservoir tallies
+    assert rel_err(t['res_energy'].sum(axis=0), sim.res_energy[:2]) < 1e-8

@@ -143,3 +143,118 @@ def test_frozen_step(variant):
     assert rel_err(sim.P.occ[:n], gs['post_occupation']) < 1e-9
     L.nko_heat_flux(r(sim.mat), r(sim.sv), r(sim.p), r(sim.P.s), P(sim.N_sv, O.c_lp), P(sim.flux))
     assert np.allclose(sim.flux, gs['heat_flux'], rtol=1e-8, atol=1e-3)
+
+
+def rough_from_setup(model, J):
+    gs = sub(golden('setup'), model)
+    gm = sub(golden('mesh'), 'box200')
+    sm = gs['spec_map']
+    flat = np.where(sm[..., 0] >= 0, sm[..., 0] * J + sm[..., 1], -1)
+    degen = None
+    if model == 'k':
+        di = gs['degen_index'].astype(int)
+        dg = gs['degeneracies'].astype(int).reshape(-1, 3)
+        degen = np.where(di > -1, dg[np.clip(di, 0, max(dg.shape[0] - 1, 0)), 2] if dg.shape[0] else -1, -1)
+    return O.make_rough(gm['rough_facets'], gs['specularity'], gs['true_specular'], flat,
+                        gs['creation_roulette'], degen), gm, gs
+
+
+@pytest.mark.parametrize('model', ['velocity', 'k'])
+def test_reflect(model):
+    """select_reflected_modes / pick_diffuse_modes with the uniforms the reference drew."""
+    ph = golden_phonon()
+    J = ph.number_of_branches
+    rough, gm, _ = rough_from_setup(model, J)
+    g = sub(golden('reflect'), model)
+    mat = O.make_material(ph.tables())
+    mesh = O.make_mesh(gm)
+    sv = O.make_subvols(gm['subvol_center'], gm['subvol_volume'], 0, int(gm['slice_axis']), 1)
+    n = g['facets'].shape[0]
+    mode_in = np.ascontiguousarray(g['in_modes'][:, 0] * J + g['in_modes'][:, 1], dtype=np.int32)
+    fac = np.ascontiguousarray(g['facets'], dtype=np.int32)
+    r_deg = np.nan_to_num(g['r_deg'], nan=0.0)
+    r_diff = np.nan_to_num(g['r_diff'], nan=0.0)
+    mo = np.zeros(n, dtype=np.int32); no = np.zeros(n); oo = np.zeros(n)
+    T_sv = np.ascontiguousarray(g['subvol_temperature'])
+    O.lib().nko_reflect(C.byref(mat), C.byref(mesh), C.byref(sv), C.byref(rough), P(T_sv), C.c_int64(n),
+                        P(fac, c_ip), P(mode_in, c_ip), P(np.ascontiguousarray(g['col_pos'])),
+                        P(np.ascontiguousarray(g['n_in'])), P(np.ascontiguousarray(g['omega_in'])),
+                        P(np.ascontiguousarray(g['r_spec'])), P(np.ascontiguousarray(r_deg)),
+                        P(np.ascontiguousarray(r_diff)), P(mo, c_ip), P(no), P(oo))
+    assert np.array_equal(mo, g['out_modes'][:, 0] * J + g['out_modes'][:, 1])
+    assert rel_err(oo, g['omega_out']) < 1e-14
+    assert rel_err(no, g['n_out']) < 1e-12
+
+
+@pytest.mark.parametrize('scale', ['lo', 'hi'])
+def test_emission(scale):
+    """fill_reservoirs('constant') + add_reservoir_particles.  Deterministic parts (counters, which modes
+    enter and how many, the level-1 entry time, the map (x0, v, dt_in) -> particle) must equal the
+    reference; the uniformly drawn parts are checked as distributions."""
+    g = sub(golden('emission'), scale)
+    gm = sub(golden('mesh'), 'box200ttp')
+    ph = golden_phonon()
+    J = ph.number_of_branches
+    M = ph.number_of_qpoints * J
+    mat = O.make_material(ph.tables())
+    mesh = O.make_mesh(gm)
+    res = O.make_reservoirs(gm['res_facets'], [302.0, 298.0], g['enter_prob'], g['counter_pre'].copy())
+    cap = g['res_modes'].shape[0] + 64
+    O.attach_emission_taps(res, cap)
+    par = O.make_params(seed=99)
+    store = O.ParticleStore(cap)
+    n = O.lib().nko_emit(C.byref(mat), C.byref(mesh), C.byref(res), C.byref(par), C.c_int64(5), C.c_int32(0),
+                         C.c_int32(1), C.byref(store.s))
+    assert n == g['res_modes'].shape[0]
+    assert np.allclose(res.counter_array.reshape(g['counter_post'].shape), g['counter_post'], rtol=0, atol=1e-15)
+    # same multiset of (reservoir, mode)
+    ref_r = np.searchsorted(gm['res_facets'], g['res_facet_id'])
+    ref_key = np.sort(ref_r * M + g['res_modes'][:, 0] * J + g['res_modes'][:, 1])
+    my_key = np.sort(res.tap_res[:n].astype(np.int64) * M + store.mode[:n])
+    assert np.array_equal(ref_key, my_key)
+    # level-1 entry times: the reference lists, per reservoir, levels c_max..1; the level-1 block is last
+    dt_ref = {}
+    for r in range(2):
+        sel = np.nonzero(ref_r == r)[0]
+        c = np.floor(g['enter_prob'][r]) + (g['counter_pre'][r] + g['enter_prob'][r] - np.floor(g['enter_prob'][r]) >= 1)
+        n1 = int((c >= 1).sum())
+        blk = sel[-n1:]
+        for i in blk:
+            dt_ref[(r, int(g['res_modes'][i, 0] * J + g['res_modes'][i, 1]))] = g['res_dt_in'][i]
+    lvl1 = np.nonzero(res.tap_level[:n] == 1)[0]
+    assert len(lvl1) == len(dt_ref)
+    mine = np.array([res.tap_dt_in[i] for i in lvl1])
+    theirs = np.array([dt_ref[(int(res.tap_res[i]), int(store.mode[i]))] for i in lvl1])
+    assert np.allclose(mine, theirs, rtol=1e-12, atol=1e-13)
+    # random levels: same law (dt_in = dt*(1-(level-1+u)/p)), compare moments with the reference's draws
+    hi = res.tap_level[:n] > 1
+    if hi.any():
+        p = g['enter_prob'].reshape(2, -1)[res.tap_res[:n][hi], store.mode[:n][hi]]
+        u = (1.0 - res.tap_dt_in[:n][hi]) * p - (res.tap_level[:n][hi] - 1)
+        assert u.min() >= 0 and u.max() < 1
+        assert abs(u.mean() - 0.5) < 4 * (1 / 12 / u.size) ** 0.5
+        assert abs(res.tap_dt_in[:n].mean() - g['res_dt_in'].mean()) < 0.02
+    # positions: on the facet, uniform (compare first two moments with the reference's sample)
+    for r, facet in enumerate(gm['res_facets']):
+        x0 = res.tap_x0[:n][res.tap_res[:n] == r]
+        xr = g['res_positions'][ref_r == r]
+        assert np.allclose(x0[:, 0], gm['facet_centroid'][facet, 0], atol=1e-9)
+        assert x0[:, 1:].min() >= 0 and x0[:, 1:].max() <= 200
+        se = 200 / 12 ** 0.5 / x0.shape[0] ** 0.5
+        assert np.all(np.abs(x0[:, 1:].mean(axis=0) - 100) < 5 * se)
+        assert np.all(np.abs(x0[:, 1:].std(axis=0) - xr[:, 1:].std(axis=0)) < 10 * se)
+    # deterministic map (x0, v, dt_in) -> particle state, against the oracle's own primitives and the
+    # reference's add_reservoir_particles outputs
+    vg = ph.group_vel.reshape(-1, 3)
+    v = vg[store.mode[:n]]
+    assert np.allclose(store.pos[:n], res.tap_x0[:n] + v * res.tap_dt_in[:n, None], rtol=1e-13, atol=1e-11)
+    vr = vg[g['res_modes'][:, 0] * J + g['res_modes'][:, 1]]
+    xr = np.ascontiguousarray(g['res_positions']); vr = np.ascontiguousarray(vr)
+    m = xr.shape[0]
+    xc = np.zeros((m, 3)); tc = np.zeros(m); fc = np.zeros(m, dtype=np.int32)
+    O.lib().nko_find_boundary(C.byref(mesh), C.c_int64(m), P(xr), P(vr), P(xc), P(tc), P(fc, c_ip))
+    assert np.array_equal(fc, g['new_collision_facets'])
+    assert np.allclose(tc / 1.0 - g['res_dt_in'] / 1.0, g['new_n_timesteps'], rtol=1e-12, atol=1e-12)
+    assert np.allclose(xr + vr * g['res_dt_in'][:, None], g['new_positions'], rtol=1e-13, atol=1e-11)
+    occ = ph.calculate_occupation(np.array([302.0, 298.0])[res.tap_res[:n]], ph.omega.ravel()[store.mode[:n]])
+    assert rel_err(store.occ[:n], occ) < 1e-13

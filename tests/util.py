@@ -50,3 +50,81 @@ def rel_err(a, b):
         e = np.abs(a - b) / scale
     e = np.where((a == b) | (np.isnan(a) & np.isnan(b)), 0.0, e)
     return float(np.nanmax(e)) if e.size else 0.0
+
+
+# ---------------------------------------------------------------------------------------------------
+# A complete small simulation case assembled from the reference's own tables (goldens), usable to
+# configure BOTH the oracle and the HIP engine identically.
+def case_tables(case='ttrrp', model='velocity'):
+    """case: 'ttp' (box 200^3, T T P) or 'ttrrp' (T T R R P, eta = 5 angstrom)."""
+    ph = golden_phonon()
+    J = ph.number_of_branches
+    gm = sub(golden('mesh'), 'box200' if case == 'ttrrp' else 'box200ttp')
+    gs = sub(golden('setup'), model)
+    M = ph.number_of_qpoints * J
+    out = dict(ph=ph, J=J, M=M, mesh=gm, tables=ph.tables(),
+               centers=gm['subvol_center'], volumes=gm['subvol_volume'], axis=int(gm['slice_axis']),
+               res_facets=gm['res_facets'], res_T=np.array([302.0, 298.0]),
+               enter_prob=gs['enter_prob'].reshape(2, M), particle_density=float(gs['particle_density']))
+    if case == 'ttrrp':
+        sm = gs['spec_map']
+        out['rough'] = dict(facets=gm['rough_facets'], specularity=gs['specularity'].reshape(-1, M),
+                            true_spec=gs['true_specular'].reshape(-1, M),
+                            spec_map=np.where(sm[..., 0] >= 0, sm[..., 0] * J + sm[..., 1], -1).reshape(-1, M),
+                            roulette=gs['creation_roulette'].reshape(-1, M))
+    else:
+        out['rough'] = None
+    return out
+
+
+def random_population(ct, n, seed, T0=298.0):
+    """Uniform positions in the box, uniformly random active modes, n = BE(T0) (Population.py:127-144, :280)."""
+    rng = np.random.default_rng(seed)
+    ph = ct['ph']
+    b = ct['mesh']['bounds']
+    pos = b[0] + rng.random((n, 3)) * (b[1] - b[0])
+    active = np.nonzero(~ph.inactive_modes_mask.ravel())[0]
+    mode = active[rng.integers(0, active.shape[0], n)].astype(np.int32)
+    occ = ph.calculate_occupation(T0, ph.omega.ravel()[mode])
+    counter = rng.random(ct['enter_prob'].shape)
+    return pos, mode, occ, counter
+
+
+def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=298.0, emit_scale=1.0):
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
+    import nk_oracle as O
+    mat = O.make_material(ct['tables'])
+    mesh = O.make_mesh(ct['mesh'])
+    sv = O.make_subvols(ct['centers'], ct['volumes'], 0, ct['axis'], interp)
+    res = O.make_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'] * emit_scale, counter.copy())
+    if ct['rough'] is not None:
+        r = ct['rough']
+        rough = O.make_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'])
+    else:
+        z = np.zeros(0)
+        rough = O.make_rough(np.zeros(0, dtype=np.int32), z, np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32), z)
+    par = O.make_params(dt=1.0, particle_density=ct['particle_density'], seed=seed)
+    n = pos.shape[0]
+    store = O.ParticleStore(cap or (2 * n + 4096))
+    store.load(pos, mode, occ)
+    sim = O.OracleSim(mat, mesh, sv, res, rough, par, store, np.full(ct['centers'].shape[0], T0))
+    sim.init_boundaries()
+    return sim
+
+
+def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scale=1.0, flux_every=10,
+                contains_every=100, device=0):
+    from nanokappa_amd.engine import Engine
+    eng = Engine(device, seed)
+    eng.set_material(ct['tables'])
+    eng.set_mesh(ct['mesh'])
+    eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], interp, np.full(ct['centers'].shape[0], T0))
+    eng.set_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'] * emit_scale, counter)
+    if ct['rough'] is not None:
+        r = ct['rough']
+        eng.set_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'])
+    eng.set_params(dt=1.0, particle_density=ct['particle_density'], flux_every=flux_every, contains_every=contains_every)
+    eng.upload(pos, mode, occ)
+    eng.init_boundaries()
+    return eng
