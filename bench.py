@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- phonon-steps/s of the Population timestep loop on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): synthetic Si (31^3 q-points x 6 branches), box
+200 x 200 x 200 angstrom, 20 slices along x, BCs T T P (302 K / 298 K reservoirs on +-x, periodic sides), dt = 1 ps,
+1e7 particles PER GPU (weak scaling: the ensemble grows with N, the per-step tally is all-reduced over RCCL).
+A "step" is one Population.run_timestep: relax -> drift -> reservoir emission -> boundary events -> tally -> T update.
+Particles are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+
+torch is used only as plumbing when WORLD_SIZE > 1 (gloo rendezvous: unique-id broadcast, barriers, max of the
+elapsed times); the compute path is libnanokappa_hip.so + RCCL.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BYTES_PER_PHONON_STEP = 68.0      # x,y,z read+write (48) + mode read (4) + occupation read+write (16)
+HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def workload_argv(particles, box=200.0):
+    b = str(box)
+    return ['--geometry', 'box', '--dimensions', b, b, b, '--subvolumes', 'slice', '20', '0',
+            '--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5', '--bound_cond', 'T', 'T', 'P',
+            '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
+            '--bound_values', '302', '298', '--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
+            '--reference_temp', 'local', '--temp_dist', 'cold', '--temp_interp', 'linear',
+            '--part_dist', 'random_subvol', '--timestep', '1', '--n_mean', '10', '--conv_crit', '0', '10',
+            '--output', 'screen', '--energy_normal', 'mean', '--particles', 'total', str(int(particles))]
+
+
+def quiet(fn, *a, **k):
+    """The Population constructor prints progress like the reference; keep stdout for the JSON line."""
+    old = sys.stdout
+    sys.stdout = open(os.devnull, 'w')
+    try:
+        return fn(*a, **k)
+    finally:
+        sys.stdout.close()
+        sys.stdout = old
+
+
+def cpu_baseline(geo, ph, mesh_n, seconds_target=15.0):
+    """The CPU oracle (oracle/nk_oracle.c, a scalar C port of the reference loop) timed on this host on a bounded
+    sample of the same workload: same box / BCs / material, 1e6 particles."""
+    sys.path.insert(0, os.path.join(ROOT, 'oracle'))
+    import nk_oracle as O
+    from nanokappa_amd import setup_tables as ST
+    n = 1000000
+    density = n / geo.volume
+    mat = O.make_material(ph.tables())
+    g = geo.tables()
+    g['bound_cond'] = np.array([ord(c) for c in geo.bound_cond], dtype=np.int8)
+    mesh = O.make_mesh(g)
+    sv = O.make_subvols(geo.subvol_center, geo.subvol_volume, 0, geo.slice_axis, 1)
+    Q, J = ph.omega.shape
+    ep = ST.enter_probability(geo, ph, geo.res_facets, density, 1.0).reshape(-1, Q * J)
+    rng = np.random.default_rng(1)
+    res = O.make_reservoirs(geo.res_facets, geo.res_values, ep, rng.random(ep.shape))
+    z = np.zeros(0)
+    rough = O.make_rough(np.zeros(0, dtype=np.int32), z, np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32), z)
+    par = O.make_params(dt=1.0, particle_density=density, seed=1)
+    pos = geo.mesh.sample_volume(n, rng)
+    active = np.nonzero(~ph.inactive_modes_mask.ravel())[0]
+    mode = active[np.arange(n) % active.shape[0]].astype(np.int32)
+    occ = ph.calculate_occupation(298.0, ph.omega.ravel()[mode])
+    store = O.ParticleStore(int(1.3 * n))
+    store.load(pos, mode, occ)
+    sim = O.OracleSim(mat, mesh, sv, res, rough, par, store, np.full(geo.n_of_subvols, 298.0))
+    sim.init_boundaries()
+    sim.run_timestep()                       # warm-up step
+    t0 = time.time()
+    steps, psteps = 0, 0
+    while time.time() - t0 < seconds_target and steps < 200:
+        sim.run_timestep()
+        psteps += int(sim.N_sv.sum())
+        steps += 1
+    dt = time.time() - t0
+    return dict(value=psteps / dt, unit='phonon-steps/s', cores=1, kind='port',
+                sample='%d particles x %d steps of the same workload (box 200 A, T T P, %d^3 x 6 modes), oracle/nk_oracle.c, 1 thread'
+                       % (n, steps, mesh_n))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--particles', type=float, default=1e7, help='particles per GPU')
+    ap.add_argument('--mesh-n', type=int, default=31, help='q-mesh of the synthetic material (31 -> 29791 q-points)')
+    ap.add_argument('--box', type=float, default=200.0)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != a.gpus and world > 1:
+        raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (a.gpus, world))
+    dist = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+
+    from nanokappa_amd import synthetic
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.engine import comm_unique_id
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.phonon import Phonon
+    from nanokappa_amd.population import Population
+
+    total = int(a.particles) * world
+    args = initialise_parser().parse_args(workload_argv(total, a.box) + ['--seed', '2025', '--device', str(local_rank)])
+    args.results_folder = ''
+    geo = quiet(Geometry, args)
+    ph = Phonon(args, 0, material=synthetic.make_material(a.mesh_n, 'Si', temperatures=np.arange(200.0, 401.0, 10.0)))
+
+    comm = None
+    if world > 1:
+        import torch
+        buf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
+        dist.broadcast(buf, 0)
+        comm = (bytes(buf.numpy().tobytes()), rank, world)
+    pop = quiet(Population, args, geo, ph, None, comm)
+    eng = pop.engine
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    if a.warmup > 0:
+        eng.step(a.warmup)                 # nk_step returns after the stream has drained (hipStreamSynchronize)
+    barrier()
+    t0 = time.perf_counter()
+    t = eng.step(a.steps)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        import torch
+        te = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        elapsed = float(te[0])
+    tm = eng.timing()
+    psteps = float(t['N_sv'].sum())        # sum over steps of N_p(step), all ranks (tallies are all-reduced)
+    value = psteps / elapsed
+
+    if rank == 0:
+        live_rank = tm['live'] / world if world > 1 else tm['live']
+        k_ms = tm['step_kernel_ms']
+        achieved = BYTES_PER_PHONON_STEP * live_rank / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
+        if os.path.exists(tf) and world == 1 and int(a.particles) == 10000000 and a.mesh_n == 31:
+            try:
+                traffic = json.load(open(tf)).get('k_step_hbm_bytes_per_launch')
+            except Exception:
+                traffic = None
+        out = {
+            'metric': 'phonon-steps/sec (whole node)', 'value': value, 'unit': 'phonon-steps/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'Si-like synthetic %d^3x6 modes, box %gx%gx%g A, slice 20 subvols, BCs T T P, dt 1 ps, '
+                                   '%.0e particles per GPU (BASELINE configs[1])' % (a.mesh_n, a.box, a.box, a.box, a.particles),
+                       'particles_total': total, 'live_particles_end': tm['live'], 'parallelism': 'particle-shard x%d' % world},
+            'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'kernel': 'k_step', 'kernel_ms': k_ms, 'emit_kernel_ms': tm['emit_kernel_ms'],
+                         'algorithmic_bytes_per_launch': BYTES_PER_PHONON_STEP * live_rank},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(geo, ph, a.mesh_n)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

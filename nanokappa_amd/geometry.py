@@ -1,0 +1,220 @@
+"""Geometry: mesh + boundary conditions + subvolumes, with the attribute surface `Population` reads from the
+reference's `Geometry` (classes/Geometry.py; SURVEY.md section 8b "Path -> Geometry").
+
+Scope this round: `box`/`cuboid` and `cylinder`/`rod`/`bar` primitives, STL files, `slice` subvolumes.
+`grid` / `voronoi` subvolumes and the remaining primitives are SURVEY section 8f row 4 (not built yet).
+"""
+import numpy as np
+
+from .mesh import Mesh, read_stl
+
+
+class SubvolClassifier(object):
+    """Nearest-centre classifier (Geometry.py:1198-1213).  Host copy for initialisation; the hot path classifies
+    on the GPU."""
+
+    def __init__(self, n, xc):
+        self.n = n
+        self.xc = np.asarray(xc, dtype=float)
+
+    def predict(self, x):
+        x = np.atleast_2d(np.asarray(x, dtype=float))
+        out = np.empty(x.shape[0], dtype=int)
+        for s in range(0, x.shape[0], 1 << 18):
+            d = ((x[s:s + (1 << 18), None, :] - self.xc[None]) ** 2).sum(axis=2)
+            out[s:s + (1 << 18)] = np.argmin(d, axis=1)
+        return out
+
+
+def box_primitive(dims):
+    """Vertices / faces of Geometry.generate_primitives('box') (Geometry.py:87-108)."""
+    v = np.array([[0, 0, 0], [0, 0, 1], [0, 1, 1], [0, 1, 0], [1, 0, 0], [1, 0, 1], [1, 1, 1], [1, 1, 0]], dtype=float)
+    v = v * np.array(dims[:3], dtype=float)
+    f = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [0, 4, 5], [0, 5, 1],
+                  [3, 7, 6], [3, 6, 2], [0, 4, 7], [0, 7, 3], [1, 5, 6], [1, 6, 2]], dtype=int)
+    return v, f
+
+
+def cylinder_primitive(dims):
+    """Geometry.generate_primitives('cylinder') (Geometry.py:110-142): dims = L, R, N_sides; axis along z."""
+    L, R, N = float(dims[0]), float(dims[1]), int(dims[2])
+    ang = np.arange(N) * 2 * np.pi / N
+    ring = np.vstack((np.cos(ang), np.sin(ang), np.zeros(N))).T * R
+    v = np.vstack((np.zeros((1, 3)), ring, np.array([[0, 0, L]]), ring + np.array([0, 0, L])))
+    # face order of the reference primitive: lower cap fan, side quads (two triangles each), upper cap fan
+    nxt = lambda i: 1 if i == N else i + 1
+    f = [[0, i, nxt(i)] for i in range(1, N + 1)]
+    for i in range(1, N + 1):
+        f.append([i, i + N + 1, nxt(i) + N + 1])
+        f.append([i, nxt(i), nxt(i) + N + 1])
+    f += [[N + 1, i + N + 1, nxt(i) + N + 1] for i in range(1, N + 1)]
+    return v, np.array(f, dtype=int)
+
+
+class Geometry(object):
+    def __init__(self, args):
+        self.args = args
+        self.scale = np.array(args.scale, dtype=float)
+        self.shape = args.geometry[0]
+        self.dimensions = args.dimensions
+        self.folder = getattr(args, 'results_folder', '.')
+        self.subvol_type = args.subvolumes[0]
+        gr = list(getattr(args, 'geo_rotation', []))
+        if len(gr) > 0:
+            self.rotation = np.array(gr[:-1]).astype(float)
+            self.rot_order = gr[-1]
+        else:
+            self.rotation, self.rot_order = None, None
+
+        self.load_geo_file(self.shape)
+        self.transform_mesh()
+        self.get_mesh_properties()
+        self.get_bound_facets(args)
+        self.check_facet_connections(args)
+        self.set_subvolumes()
+
+    # ---------------------------------------------------------------------- mesh
+    def load_geo_file(self, shape):
+        if shape in ('cuboid', 'box'):
+            v, f = box_primitive(self.dimensions)
+        elif shape in ('cylinder', 'rod', 'bar'):
+            v, f = cylinder_primitive(self.dimensions)
+        elif str(shape).lower().endswith('.stl'):
+            v, f = read_stl(shape)
+        else:
+            raise NotImplementedError('geometry %r: only box, cylinder and STL files are built so far' % shape)
+        self._raw = (v, f)
+
+    def transform_mesh(self):
+        """rezero -> scale -> rotate -> rezero (Geometry.py:414-433)."""
+        v, f = self._raw
+        v = (v - v.min(axis=0)) * self.scale
+        if self.rotation is not None and np.any(self.rotation != 0):
+            from scipy.spatial.transform import Rotation as rot
+            v = rot.from_euler(self.rot_order, self.rotation, degrees=True).apply(v)
+        v = v - v.min(axis=0)
+        self.mesh = Mesh(v, f)
+
+    def get_mesh_properties(self):
+        m = self.mesh
+        self.faces, self.facets = m.faces, m.facets
+        self.n_of_faces, self.n_of_facets = m.n_of_faces, m.n_of_facets
+        self.bounds, self.facet_centroid, self.volume = m.bounds, m.facet_centroid, m.volume
+        self.facets_normal, self.facets_area = m.facets_normal, m.facets_area
+
+    def scale_positions(self, x, inv=False):
+        ext = self.bounds[1] - self.bounds[0]                                          # Geometry.py:946-959
+        return x * ext + self.bounds[0] if inv else (x - self.bounds[0]) / ext
+
+    # ------------------------------------------------------- boundary conditions
+    def get_bound_facets(self, args):
+        """Geometry.get_bound_facets (Geometry.py:652-709): the last --bound_cond entry is the default; the
+        others are attached to the facet closest to each --bound_pos point."""
+        self.bound_cond = np.array([args.bound_cond[-1] for _ in range(self.n_of_facets)])
+        try:
+            self.bound_pos = np.array(args.bound_pos[1:]).reshape(-1, 3).astype(float)
+        except Exception:
+            raise Exception('Boundary positions ill defined. Check input parameters.')
+        if args.bound_pos[0] == 'relative':
+            self.bound_pos = self.scale_positions(self.bound_pos, True)
+        elif args.bound_pos[0] != 'absolute':
+            raise Exception('Please specify the type of position for BC with the keyword "absolute" or "relative".')
+        self.bound_facets, _, _ = self.mesh.closest_facet(self.bound_pos)
+        for j, i in enumerate(self.bound_facets):
+            self.bound_cond[i] = args.bound_cond[j]
+        is_res = (self.bound_cond == 'T') | (self.bound_cond == 'F')
+        self.res_facets = np.arange(self.n_of_facets, dtype=int)[is_res]
+        self.res_bound_cond = self.bound_cond[is_res]
+        self.rough_facets = np.arange(self.n_of_facets, dtype=int)[self.bound_cond == 'R']
+        self.n_of_reservoirs = self.res_facets.shape[0]
+        self.n_of_rough_facets = self.rough_facets.shape[0]
+        self.res_values = np.ones(self.n_of_reservoirs) * np.nan
+        self.rough_facets_values = np.ones(self.n_of_rough_facets) * np.nan
+        if args.bound_cond[-1] in ('T', 'F'):
+            self.res_values[:] = args.bound_values[-1]
+        elif args.bound_cond[-1] == 'R':
+            self.rough_facets_values[:] = args.bound_values[-1]
+        bound_indices = [-1] * len(self.bound_cond)
+        i = 0
+        for f, facet in enumerate(self.bound_facets):
+            if self.bound_cond[facet] != 'P':
+                bound_indices[f] = i
+                i += 1
+        for i, bf in enumerate(self.bound_facets):
+            if bf in self.res_facets:
+                self.res_values[self.res_facets == bf] = args.bound_values[bound_indices[i]]
+            elif bf in self.rough_facets:
+                self.rough_facets_values[self.rough_facets == bf] = args.bound_values[bound_indices[i]]
+
+    def check_facet_connections(self, args):
+        """Pairs of periodic facets (Geometry.py:711-726).  The reference's polygon-equality sanity check
+        (:728-766) only prints; here opposite normals and equal areas are enforced."""
+        self.connected_facets = np.zeros((0, 2), dtype=int)
+        cp = list(getattr(args, 'connect_pos', []))
+        if len(cp) > 0:
+            pts = np.array(cp[1:], dtype=float).reshape(-1, 3)
+            if cp[0] == 'relative':
+                pts = self.scale_positions(pts, True)
+            elif cp[0] != 'absolute':
+                raise Exception("Wrong option in --connect_pos. Choose between 'relative' or 'absolute'.")
+            self.connected_facets = self.mesh.closest_facet(pts)[0].reshape(-1, 2)
+        for a, b in self.connected_facets:
+            if not np.all(np.abs(self.facets_normal[a] + self.facets_normal[b]) < 0.1):
+                raise Exception('Connected facets normals do not agree!!')
+            if abs(self.facets_area[a] - self.facets_area[b]) > 1e-6 * self.facets_area[a]:
+                raise Exception('Connected facets have different areas. Check --connect_pos.')
+        for f in np.nonzero(self.bound_cond == 'P')[0]:
+            if f not in self.connected_facets:
+                raise Exception('Facet %d has periodic BC but no partner in --connect_pos.' % f)
+
+    # ---------------------------------------------------------------- subvolumes
+    def set_subvolumes(self):
+        if self.subvol_type == 'grid':
+            grid = np.array(self.args.subvolumes[1:4]).astype(int)
+            if (grid == 1).sum() == 2:                                                  # Geometry.py:497-506
+                ax = int(np.nonzero(grid != 1)[0][0])
+                self.args.subvolumes = ['slice', int(grid[ax]), ax]
+                self.subvol_type = 'slice'
+        if self.subvol_type != 'slice':
+            raise NotImplementedError("subvolume type %r: only 'slice' is built so far (SURVEY 8f row 4)" % self.subvol_type)
+        self.n_of_subvols = int(self.args.subvolumes[1])                                # Geometry.py:449-471
+        self.slice_axis = int(self.args.subvolumes[2])
+        ext = self.bounds[1] - self.bounds[0]
+        c = np.zeros((self.n_of_subvols, 3)) + np.mean(self.bounds, axis=0)
+        arr = (np.arange(self.n_of_subvols) + 0.5) / self.n_of_subvols
+        arr *= ext[self.slice_axis]
+        arr += self.bounds[0, self.slice_axis]
+        c[:, self.slice_axis] = arr
+        self.subvol_center = c[np.lexsort((c[:, 2], c[:, 1], c[:, 0]))]
+        self.slice_length = ext[self.slice_axis] / self.n_of_subvols
+        self.subvol_classifier = SubvolClassifier(self.n_of_subvols, self.subvol_center)
+        self.subvol_volume = self.calculate_subvol_volume()
+        con = np.vstack((np.arange(self.n_of_subvols - 1), np.arange(self.n_of_subvols - 1) + 1)).T
+        self.subvol_connections = con                                                   # Geometry.py:968-975
+        self.n_of_subvol_con = con.shape[0]
+        self.subvol_con_vectors = self.subvol_center[con[:, 1]] - self.subvol_center[con[:, 0]]
+
+    def calculate_subvol_volume(self, tol=1e-4, seed=20231003):
+        """Exact V/S for boxes (Geometry.py:551-552); Monte-Carlo cover otherwise (:605-639), seeded."""
+        if self.shape in ('cuboid', 'box'):
+            return self.volume * np.ones(self.n_of_subvols) / self.n_of_subvols
+        rng = np.random.default_rng(seed)
+        cover = np.zeros(self.n_of_subvols)
+        nt, ns, err = 0, 1 << 14, 1.0
+        while err > tol and nt < (1 << 24):
+            r = self.subvol_classifier.predict(self.mesh.sample_volume(ns, rng))
+            nr = np.bincount(r, minlength=self.n_of_subvols)
+            new = (cover * nt + nr) / (nt + ns)
+            nt += ns
+            with np.errstate(divide='ignore', invalid='ignore'):
+                e = np.abs((new - cover) / cover)
+            e[np.isnan(e)] = 1
+            err = e.max()
+            cover = new
+        return cover * self.volume
+
+    def tables(self):
+        """Mesh + BC arrays handed to nk_set_mesh."""
+        t = self.mesh.tables()
+        t.update(bound_cond=self.bound_cond, connected_facets=self.connected_facets)
+        return t

@@ -1,0 +1,624 @@
+"""`Population`: drop-in for the reference's class of the same name on its hot path
+(reference classes/Population.py; driver contract nanokappa.py:89-107).
+
+    pop = Population(args, geo, phonons)
+    pop.run_timestep(geo, phonons)        # or pop.run(n) to batch n steps into one library call
+    pop.current_timestep, pop.finish_sim, pop.write_final_state(geo), pop.f, pop.view.postprocess()
+
+`geo` / `phonons` may be this package's Geometry / Phonon or the reference's own objects: only the attributes
+listed in SURVEY.md section 8b are read.  The particle state lives in HBM inside libnanokappa_hip.so; the host
+keeps the tallies (subvolume temperatures, energies, fluxes, reservoir balances), the convergence bookkeeping
+and the text outputs.  There is no CPU fallback: without the library / a GPU the constructor raises.
+"""
+import os
+import sys
+from datetime import datetime
+
+import numpy as np
+
+from .constants import Constants
+from . import setup_tables as ST
+from .engine import Engine
+
+
+class _Stats(object):
+    """Mean / std over the last n_mean convergence rows: the numbers Visualisation.read_convergence derives by
+    re-reading convergence.txt (reference classes/Visualisation.py:122-212), kept in memory instead."""
+
+    def __init__(self, pop):
+        self.pop = pop
+
+    def update_population(self, pop, verbose=False):
+        self.pop = pop
+
+    def postprocess(self, verbose=False):
+        p = self.pop
+        N = p.n_mean
+        rows = p.conv_rows[-N:]
+        T = np.array([r['T'] for r in rows])
+        phi = np.array([r['phi'].ravel() for r in rows])
+        en_res = np.array([r['en_res'] for r in rows]).reshape(len(rows), -1)
+        self.mean_T, self.std_T = T.mean(axis=0), T.std(axis=0)
+        self.mean_sv_phi, self.std_sv_phi = phi.mean(axis=0), phi.std(axis=0)
+        self.mean_en_res, self.std_en_res = en_res.mean(axis=0), en_res.std(axis=0)
+        if p.subvol_type == 'slice':
+            k = np.array([r['sv_k'] for r in rows])
+            with np.errstate(invalid='ignore'):
+                self.mean_sv_k, self.std_sv_k = np.nanmean(k, axis=0), np.nanstd(k, axis=0)
+            kk = np.array([r['kappa'] for r in rows])
+            self.mean_k, self.std_k = np.nanmean(kk), np.nanstd(kk)
+
+
+class Population(Constants):
+    '''Class comprising the particles to be simulated (GPU-resident).'''
+
+    def __init__(self, arguments, geometry, phonon, engine=None, comm=None):
+        super(Population, self).__init__()
+        self.args = arguments
+        args = arguments
+        self.results_folder_name = args.results_folder
+        self.n_dt_to_conv = 10                                               # Population.py:41
+        self.norm = args.energy_normal[0]
+        self.n_of_subvols = geometry.n_of_subvols
+        self.subvol_type = geometry.subvol_type
+        self.empty_subvols = list(args.empty_subvols)
+        self.n_of_empty_subvols = len(self.empty_subvols)
+        self.rank, self.nranks = (0, 1) if comm is None else (int(comm[1]), int(comm[2]))
+
+        M = phonon.number_of_active_modes
+        self.particle_type = args.particles[0]                               # Population.py:50-63
+        if self.particle_type == 'pmps':
+            self.particles_pmps = float(args.particles[1])
+            self.N_p = int(np.ceil(self.particles_pmps * M * self.n_of_subvols))
+            self.particle_density = self.N_p / geometry.volume
+        elif self.particle_type == 'total':
+            self.N_p = int(np.ceil(float(args.particles[1])))
+            self.particles_pmps = self.N_p / (M * self.n_of_subvols)
+            self.particle_density = self.N_p / geometry.volume
+        elif self.particle_type == 'pv':
+            self.particle_density = float(args.particles[1])
+            self.N_p = int(np.ceil(self.particle_density * geometry.volume))
+            self.particles_pmps = self.N_p / (M * (self.n_of_subvols - self.n_of_empty_subvols))
+        else:
+            raise Exception('Invalid --particles keyword.')
+
+        self.dt = float(args.timestep[0])
+        self.t = 0.0
+        if geometry.subvol_type == 'slice':
+            self.slice_axis = geometry.slice_axis
+            self.slice_length = geometry.slice_length
+        self.subvol_volume = geometry.subvol_volume
+        self.bound_cond = geometry.bound_cond
+        self.res_gen = args.reservoir_gen[0]
+        if self.res_gen not in ('constant', 'fixed_rate'):
+            raise NotImplementedError("--reservoir_gen %s: 'constant' and 'fixed_rate' are built" % self.res_gen)
+        self.rough_facets = np.asarray(geometry.rough_facets)
+        self.rough_facets_values = np.asarray(geometry.rough_facets_values)
+        self.connected_facets = geometry.connected_facets
+        self.T_distribution = args.temp_dist[0]
+        self.temp_interp_type = args.temp_interp[0]
+        if args.reference_temp[0] != 'local':
+            self.T_reference = float(args.reference_temp[0])
+            self.reference_occupation = phonon.calculate_occupation(self.T_reference, phonon.omega)
+            self.ref_en_density = phonon.crystal_energy_function(self.T_reference)
+        else:
+            self.T_reference = 'local'
+        self.n_mean = int(args.n_mean[0])
+        self._geo, self._ph = geometry, phonon
+        self.current_timestep = 0
+        self.seed = int(getattr(args, 'seed', [0])[0])
+        self.rng = np.random.default_rng(self.seed)
+
+        print('Calculating diffuse scattering probabilities...')
+        self._build_rough_tables(geometry, phonon)
+
+        print('Initialising reservoirs...')
+        self.n_of_reservoirs = int((self.bound_cond == 'T').sum() + (self.bound_cond == 'F').sum())
+        if self.n_of_reservoirs > 0:
+            self.initialise_reservoirs(geometry, phonon)
+        else:
+            self.res_facet = np.zeros(0, dtype=int)
+            self.res_facet_temperature = np.zeros(0)
+            self.res_energy_balance = np.zeros(0)
+            self.res_heat_flux = np.zeros((0, 3))
+            self.N_leaving = np.zeros(0, dtype=int)
+
+        print('Initialising population...')
+        pos, modes, occ = self.initialise_all_particles(geometry, phonon)
+
+        # ---- device engine
+        self.engine = engine if engine is not None else Engine(int(getattr(args, 'device', [0])[0]), self.seed)
+        self._configure_engine(geometry, phonon)
+        if comm is not None and self.nranks > 1:
+            self.engine.comm_init(comm[0], self.rank, self.nranks)
+        J = phonon.number_of_branches
+        lo, hi = self._shard(pos.shape[0])
+        self.engine.reserve(int(1.3 * (hi - lo)) + 65536)
+        self.engine.upload(pos[lo:hi], (modes[lo:hi, 0] * J + modes[lo:hi, 1]).astype(np.int32), occ[lo:hi], pid_offset=lo)
+        print('Getting first boundary collisions...')
+        self.engine.init_boundaries()
+
+        print('Initialising local quantities...')
+        self._initial_tallies(geometry, phonon, pos, modes, occ)
+        del pos, modes, occ
+
+        self.conv_crit = float(args.conv_crit[0])
+        self.conv_count_min = int(args.conv_crit[1])
+        self.initialise_residue(geometry)
+        self.conv_rows = []
+        self.f = None
+        if self.rank == 0 and self.results_folder_name:
+            print('Creating convergence file...')
+            self.open_convergence(geometry)
+        self._record_convergence(geometry)
+        self.view = _Stats(self)
+        print('Initialisation done!')
+
+    # ----------------------------------------------------------------------------------- setup
+    def _shard(self, n):
+        """Initial particles are split evenly by index over the ranks."""
+        lo = (n * self.rank) // self.nranks
+        hi = (n * (self.rank + 1)) // self.nranks
+        return lo, hi
+
+    def _build_rough_tables(self, geometry, phonon):
+        self.scat_model = self.args.bound_scat[0]
+        Q, J = phonon.omega.shape
+        Fr = self.rough_facets.shape[0]
+        if Fr == 0:
+            print('No rough facets to calculate.')
+            self.specularity = np.zeros((0, Q, J))
+            self.true_specular = np.zeros((0, Q, J), dtype=bool)
+            self.correspondent_modes = np.zeros((0, 7))
+            self.spec_map = np.zeros((0, Q, J), dtype=np.int64)
+            self.creation_roulette = np.zeros((0, Q * J))
+            self.degeneracies, self.degen_index = ST.find_degeneracies(phonon)
+            return
+        if self.scat_model not in ('v', 'vel', 'velocity', 'groupvel', 'group_vel'):
+            raise NotImplementedError("--bound_scat %s: only the 'velocity' reflection model is built so far" % self.scat_model)
+        spec0 = ST.fbz_specularity(geometry, phonon, self.rough_facets, self.rough_facets_values)
+        self.correspondent_modes, self.true_specular = ST.specular_correspondences_velocity(geometry, phonon, self.rough_facets)
+        self.specularity = self.true_specular.astype(int) * spec0                  # Population.py:1459
+        self.spec_map = ST.specular_map(self.correspondent_modes, geometry, self.rough_facets, Q, J)
+        self.degeneracies, self.degen_index = ST.find_degeneracies(phonon)
+        self.creation_rate, self.creation_roulette = ST.diffuse_roulette(
+            geometry, phonon, self.rough_facets, self.specularity, self.correspondent_modes, self.scat_model, self.degeneracies)
+        if self.rank == 0 and self.results_folder_name:
+            np.savetxt(os.path.join(self.results_folder_name, 'specular_correspondences.txt'), self.correspondent_modes,
+                       fmt='%.3f %.3f %.3f %d %d %d %d')                            # Population.py:1461
+
+    def initialise_reservoirs(self, geometry, phonon):
+        """Population.py:323-354."""
+        self.res_facet = np.asarray(geometry.res_facets)
+        self.res_bound_values = np.asarray(geometry.res_values, dtype=float)
+        self.res_bound_cond = np.asarray(geometry.res_bound_cond)
+        mask_temp = self.res_bound_cond == 'T'
+        mask_flux = self.res_bound_cond == 'F'
+        self.res_facet_temperature = np.full(self.n_of_reservoirs, np.nan)
+        self.res_facet_temperature[mask_temp] = self.res_bound_values[mask_temp]
+        if mask_flux.any():
+            self.res_facet_temperature[mask_flux] = self.res_bound_values[mask_temp].mean()
+        self.enter_prob = ST.enter_probability(geometry, phonon, self.res_facet, self.particle_density, self.dt)
+        self.res_counter = self.rng.random(self.enter_prob.shape)                   # Population.py:343
+        self.N_leaving = np.sum(self.enter_prob, axis=(1, 2)).round().astype(int)
+        self.res_energy_balance = np.zeros(self.n_of_reservoirs)
+        self.res_heat_flux = np.zeros((self.n_of_reservoirs, 3))
+
+    def initialise_modes(self, phonon):
+        """Population.py:127-144: tiled unique modes when there is at least one particle per mode and subvolume."""
+        self.unique_modes = np.vstack(np.where(~phonon.inactive_modes_mask)).T
+        if self.particles_pmps >= 1:
+            reps = int(np.ceil(self.particles_pmps * (self.n_of_subvols - self.n_of_empty_subvols)))
+            idx = np.arange(self.N_p) % self.unique_modes.shape[0]
+            if reps * self.unique_modes.shape[0] < self.N_p:
+                raise Exception('internal: mode tiling shorter than N_p')
+            modes = self.unique_modes[idx, :]
+        else:
+            modes = self.unique_modes[self.rng.integers(0, phonon.number_of_active_modes, size=self.N_p), :]
+        return modes.astype(int)
+
+    def generate_positions(self, n, mesh):
+        x = mesh.sample_volume(n, self.rng)                                         # Population.py:163-184
+        keep = mesh.contains(x) if getattr(mesh, 'n_of_faces', 0) > 12 and n < 200000 else np.ones(n, dtype=bool)
+        return x[keep]
+
+    def initialise_all_particles(self, geometry, phonon):
+        """Positions, modes, temperatures, occupations (Population.py:186-321)."""
+        key = self.args.part_dist[0]
+        S = self.n_of_subvols
+        if key == 'random_domain':
+            pos = geometry.mesh.sample_volume(self.N_p, self.rng)
+        elif key == 'center_domain':
+            pos = np.ones((self.N_p, 3)) * geometry.mesh.center_mass
+        elif key == 'random_subvol':
+            vol = np.asarray(geometry.subvol_volume, dtype=float)
+            n = self.N_p * vol / (vol.sum() - vol[self.empty_subvols].sum())
+            n = np.ceil(n).astype(int)
+            n[self.empty_subvols] = 0
+            chunks = [[] for _ in range(S)]
+            have = np.zeros(S, dtype=int)
+            while np.any(have < n):
+                batch = int(min(max((n - have).sum() * 1.2, 1e4), 4e6))
+                x_new = geometry.mesh.sample_volume(batch, self.rng)
+                sv = geometry.subvol_classifier.predict(x_new) if S > 1 else np.zeros(batch, dtype=int)
+                order = np.argsort(sv, kind='stable')
+                counts = np.bincount(sv, minlength=S)
+                start = np.concatenate(([0], np.cumsum(counts)))
+                for i in range(S):
+                    need = n[i] - have[i]
+                    if need > 0 and counts[i] > 0:
+                        take = order[start[i]:start[i] + min(need, counts[i])]
+                        chunks[i].append(x_new[take])
+                        have[i] += take.shape[0]
+            pos = np.vstack([np.vstack(c) if c else np.zeros((0, 3)) for c in chunks])[:self.N_p, :]
+        elif key == 'center_subvol':
+            raise NotImplementedError('--part_dist center_subvol needs per-subvolume meshes (not built)')
+        else:
+            data = np.loadtxt(key, delimiter=',', comments='#', dtype=float)        # resume file, Population.py:284-306
+            modes = data[:, [0, 1]].astype(int)
+            pos = data[:, [2, 3, 4]].copy()
+            occ = data[:, 5].copy()
+            self.N_p = pos.shape[0]
+            self._resume_modes = modes
+            self.subvol_id = geometry.subvol_classifier.predict(pos)
+            self.subvol_temperature = self._assign_subvol_temperatures(geometry)
+            return pos, modes, occ
+        self.N_p = pos.shape[0]
+        modes = self.initialise_modes(phonon)
+        self.subvol_id = geometry.subvol_classifier.predict(pos) if S > 1 else np.zeros(self.N_p, dtype=int)
+        self.subvol_temperature = self._assign_subvol_temperatures(geometry)
+        T = self.subvol_temperature[self.subvol_id]
+        occ = phonon.calculate_occupation(T, phonon.omega[modes[:, 0], modes[:, 1]])  # Population.py:280
+        return pos, modes, occ
+
+    def _assign_subvol_temperatures(self, geometry):
+        """assign_temperatures (Population.py:565-655), subvolume part."""
+        key = self.T_distribution
+        S = self.n_of_subvols
+        if key == 'custom':
+            return np.array(self.args.subvol_temp, dtype=float)
+        if self.n_of_reservoirs > 0:
+            bound_T = self.res_bound_values[self.res_bound_cond == 'T']
+        else:
+            bound_T = np.zeros(0)
+        if len(bound_T) == 0:
+            bound_T = np.array([float(self.T_reference)])
+        if key == 'cold':
+            return np.ones(S) * bound_T.min()
+        if key == 'hot':
+            return np.ones(S) * bound_T.max()
+        if key == 'mean':
+            return np.ones(S) * bound_T.mean()
+        if key == 'random':
+            return self.rng.random(S) * (bound_T.max() - bound_T.min()) + bound_T.min()
+        if key == 'linear':
+            fi = self.res_facet[self.res_bound_cond == 'T']
+            bp = geometry.facet_centroid[fi, :]
+            if len(bound_T) == 1:
+                return np.ones(S) * bound_T
+            if len(bound_T) == 2:
+                d = bp[1] - bp[0]
+                alpha = ((geometry.subvol_center - bp[0]) * d).sum(axis=1) / (d ** 2).sum()
+                return bound_T[0] + alpha * (bound_T[1] - bound_T[0])
+            dd = np.sum((geometry.subvol_center - bp[:, None, :]) ** 2, axis=2).T ** 0.5
+            w = 1 / dd
+            w /= w.sum(axis=1, keepdims=True)
+            return np.sum(bound_T * w, axis=1)
+        raise Exception('Invalid --temp_dist')
+
+    def _configure_engine(self, geometry, phonon):
+        eng = self.engine
+        eng.set_material(phonon.tables() if hasattr(phonon, 'tables') else _phonon_tables(phonon))
+        eng.set_mesh(geometry.tables() if hasattr(geometry, 'tables') else _geometry_tables(geometry))
+        if geometry.subvol_type == 'slice' and self.temp_interp_type in ('nearest', 'linear'):
+            kind, axis, interp = 0, geometry.slice_axis, (1 if self.temp_interp_type == 'linear' else 0)
+        elif self.temp_interp_type == 'nearest':
+            kind, axis, interp = 1, 0, 2
+        else:
+            raise NotImplementedError('--temp_interp %s on %s subvolumes (RBF) is not built'
+                                      % (self.temp_interp_type, geometry.subvol_type))
+        eng.set_subvolumes(geometry.subvol_center, geometry.subvol_volume, kind, axis, interp, self.subvol_temperature)
+        Q, J = phonon.omega.shape
+        if self.n_of_reservoirs > 0:
+            eng.set_reservoirs(self.res_facet, self.res_facet_temperature, self.enter_prob.reshape(-1, Q * J),
+                               self.res_counter.reshape(-1, Q * J), gen={'constant': 0, 'fixed_rate': 1}[self.res_gen])
+        if self.rough_facets.shape[0] > 0:
+            eng.set_rough(self.rough_facets, self.specularity.reshape(-1, Q * J), self.true_specular.reshape(-1, Q * J),
+                          self.spec_map.reshape(-1, Q * J), self.creation_roulette)
+        eng.set_params(dt=self.dt, norm_fixed=(self.norm == 'fixed'), particle_density=self.particle_density,
+                       T_ref=(None if self.T_reference == 'local' else self.T_reference),
+                       flux_every=self.n_dt_to_conv, contains_every=100)
+
+    def _initial_tallies(self, geometry, phonon, pos, modes, occ):
+        """calculate_energy / calculate_heat_flux / calculate_kappa on the initial state (Population.py:282, :318-321)."""
+        S = self.n_of_subvols
+        self.subvol_N_p = np.bincount(self.subvol_id, minlength=S).astype(np.int64)
+        self.N_p = int(self.subvol_N_p.sum())
+        om = phonon.omega[modes[:, 0], modes[:, 1]]
+        if self.T_reference == 'local':
+            dn = occ - phonon.calculate_occupation(self.subvol_temperature[self.subvol_id], om)
+            ref = phonon.crystal_energy_function(self.subvol_temperature)
+        else:
+            dn = occ - self.reference_occupation[modes[:, 0], modes[:, 1]]
+            ref = self.ref_en_density
+        e = self.hbar * om * dn
+        self.total_energy = float(e.sum())
+        E_raw = np.bincount(self.subvol_id, weights=e, minlength=S)
+        v = phonon.group_vel[modes[:, 0], modes[:, 1], :]
+        flux_raw = np.stack([np.bincount(self.subvol_id, weights=v[:, d] * e, minlength=S) for d in range(3)], axis=1)
+        self.subvol_energy = self._normalise_energy(phonon, E_raw, self.subvol_N_p) + ref
+        self.subvol_heat_flux = self._normalise_flux(phonon, flux_raw, self.subvol_N_p)
+        self.calculate_kappa(geometry)
+        del self.subvol_id
+
+    # ----------------------------------------------------------------------------- normalisation
+    def _norm(self, phonon, N_sv):
+        if self.norm == 'fixed':
+            return phonon.number_of_active_modes / (self.particle_density * np.asarray(self.subvol_volume, dtype=float))
+        with np.errstate(divide='ignore', invalid='ignore'):
+            n = phonon.number_of_active_modes / np.asarray(N_sv, dtype=float)
+        return np.where(np.isnan(n), 0, n)
+
+    def _normalise_energy(self, phonon, E_raw, N_sv):
+        return phonon.normalise_to_density(E_raw * self._norm(phonon, N_sv))       # Population.py:719-726
+
+    def _normalise_flux(self, phonon, flux_raw, N_sv):
+        n = self._norm(phonon, N_sv).reshape(-1, 1)                                 # Population.py:738-747
+        with np.errstate(invalid='ignore'):
+            return phonon.normalise_to_density(flux_raw * n) * self.eVpsa2_in_Wm2
+
+    def calculate_kappa(self, geometry):
+        """Population.py:749-788."""
+        if geometry.subvol_type == 'slice':
+            S = self.n_of_subvols
+            T = np.zeros(S + 2)
+            T[1:-1] = self.subvol_temperature
+            if self.n_of_reservoirs >= 2:
+                T[[0, -1]] = self.res_facet_temperature[[0, -1]] if self.n_of_reservoirs > 2 else self.res_facet_temperature
+            else:
+                T[[0, -1]] = np.nan
+            phi = self.subvol_heat_flux[:, geometry.slice_axis]
+            ext = geometry.bounds[1, geometry.slice_axis] - geometry.bounds[0, geometry.slice_axis]
+            dx = 2 * ext * self.a_in_m / S
+            dT = T[2:] - T[:-2]
+            DX = ext * self.a_in_m * (1 + S) / S
+            DT = T[-1] - T[0]
+            with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+                self.subvol_kappa = -phi * dx / dT
+                self.kappa = -np.sum(phi * self.subvol_N_p) * (DX / DT) / self.N_p
+            self.subvol_kappa[np.absolute(self.subvol_kappa) == np.inf] = 0
+        else:
+            i, j = geometry.subvol_connections[:, 0], geometry.subvol_connections[:, 1]
+            dx = geometry.subvol_center[j, :] - geometry.subvol_center[i, :]
+            nrm = np.linalg.norm(dx, axis=1, keepdims=True)
+            dT = self.subvol_temperature[j] - self.subvol_temperature[i]
+            phi = (self.subvol_heat_flux[i, :] + self.subvol_heat_flux[j, :]) / 2
+            with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+                self.svcon_kappa = np.where(dT == 0, 0, -np.sum(phi * dx / nrm, axis=1) * nrm[:, 0] * self.a_in_m / dT)
+
+    def adjust_reservoir_balance(self, geometry, phonon):
+        """Population.py:1685-1693."""
+        if self.n_of_reservoirs > 0:
+            A = geometry.facets_area[self.res_facet].reshape(-1, 1)
+            c = phonon.number_of_active_modes / (self.particle_density * self.dt * self.n_dt_to_conv)
+            self.res_heat_flux = phonon.normalise_to_density(self.res_heat_flux * c / A) * self.eVpsa2_in_Wm2
+            self.res_energy_balance = phonon.normalise_to_density(self.res_energy_balance * c)
+
+    def restart_reservoir_balance(self):
+        self.res_heat_flux = np.zeros((self.n_of_reservoirs, 3))                    # Population.py:1695-1699
+        self.res_energy_balance = np.zeros(self.n_of_reservoirs)
+
+    # ------------------------------------------------------------------------------- time loop
+    def run_timestep(self, geometry, phonon):
+        """One timestep, Population.py:1724-1769."""
+        self.run(1, geometry, phonon)
+
+    def run(self, nsteps, geometry=None, phonon=None):
+        """Advance nsteps timesteps.  Library calls are cut at the 100-step bookkeeping boundaries
+        (Population.py:1729-1741) so that outputs are identical to stepping one by one."""
+        geometry = geometry if geometry is not None else self._geo
+        phonon = phonon if phonon is not None else self._ph
+        self._geo, self._ph = geometry, phonon
+        done = 0
+        while done < nsteps:
+            if self.current_timestep == 0:
+                print('Simulating...')
+            if (self.current_timestep % 100) == 0:
+                self._every_hundred(geometry)
+            chunk = min(nsteps - done, 100 - (self.current_timestep % 100))
+            t = self.engine.step(chunk)
+            for s in range(chunk):
+                self.current_timestep += 1
+                self.t = self.current_timestep * self.dt
+                self.subvol_temperature = t['T_sv'][s]
+                self.subvol_energy = t['E_sv'][s]
+                self.subvol_N_p = t['N_sv'][s].astype(np.int64)
+                self.N_p = int(self.subvol_N_p.sum())
+                self.total_energy = float(t['E_raw'][s].sum())
+                if self.n_of_reservoirs > 0:
+                    self.N_leaving = t['N_leaving'][s].astype(np.int64)
+                    self.res_energy_balance = self.res_energy_balance + t['res_energy'][s]
+                    self.res_heat_flux = self.res_heat_flux + t['res_flux'][s]
+                if (self.current_timestep % self.n_dt_to_conv) == 0:                # Population.py:1762-1767
+                    self.subvol_heat_flux = self._normalise_flux(phonon, t['flux_raw'][s], self.subvol_N_p)
+                    self.calculate_kappa(geometry)
+                    self.adjust_reservoir_balance(geometry, phonon)
+                    self._record_convergence(geometry)
+                    self.restart_reservoir_balance()
+            done += chunk
+
+    def _every_hundred(self, geometry):
+        if self.rank == 0 and self.results_folder_name and getattr(self.args, 'checkpoint', True):
+            self.write_final_state(geometry)
+        self.view.postprocess(verbose=False)
+        self.update_residue(geometry)
+        info = 'Timestep {:>5d} - max residue: {:>9.3e} ({:<9s}) ['.format(int(self.current_timestep), self.max_residue, self.max_residue_qt)
+        for sv in range(self.n_of_subvols):
+            info += ' {:>7.3f}'.format(self.subvol_temperature[sv])
+        print(info + ' ]')
+
+    # ----------------------------------------------------------------------- convergence / residue
+    def initialise_residue(self, geo):
+        """Population.py:1771-1795."""
+        S, R = self.n_of_subvols, self.n_of_reservoirs
+        if geo.subvol_type == 'slice':
+            n = 3 * S + R
+            ax = ['x', 'y', 'z'][self.slice_axis]
+            self.residue_qts = (['T_{:d}'.format(i) for i in range(S)] + ['phi_{:s}_{:d}'.format(ax, j) for j in range(S)] +
+                                ['en_res_{:d}'.format(i) for i in range(R)] + ['k_{:d}'.format(i) for i in range(S)])
+        else:
+            n = 4 * S + R + geo.n_of_subvol_con
+            self.residue_qts = (['T_{:d}'.format(i) for i in range(S)] +
+                                ['phi_{:s}_{:d}'.format(i, j) for j in range(S) for i in ['x', 'y', 'z']] +
+                                ['en_res_{:d}'.format(i) for i in range(R)] + ['k_{:d}'.format(i) for i in range(geo.n_of_subvol_con)])
+        self.old_mean_large = np.ones(n)
+        self.old_std_large = np.ones(n)
+        self.conv_count = 0
+        self.finish_sim = False
+        self.max_residue = 1
+        self.max_residue_qt = 'none'
+
+    def update_residue(self, geo):
+        """Population.py:1797-1839."""
+        v = self.view
+        S = self.n_of_subvols
+        with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+            if geo.subvol_type == 'slice':
+                sel = 3 * np.arange(S) + self.slice_axis
+                new_mean = np.concatenate((v.mean_T, v.mean_sv_phi[sel], v.mean_en_res, v.mean_sv_k))
+                new_std = np.concatenate((v.std_T, v.std_sv_phi[sel], v.std_en_res, v.std_sv_k))
+            else:
+                raise NotImplementedError('residue for non-slice subvolumes')
+            residue_mean = np.absolute((new_mean - self.old_mean_large) / self.old_mean_large)
+        self.residue_all = np.where(new_std > np.absolute(new_mean), 0, residue_mean)
+        self.max_residue = np.nanmax(self.residue_all)
+        index = np.nonzero(self.residue_all == self.max_residue)[0][0]
+        self.max_residue_qt = self.residue_qts[index]
+        self.conv_count = self.conv_count + 1 if self.max_residue < self.conv_crit else 0
+        if self.conv_count >= self.conv_count_min:
+            self.finish_sim = True
+        self.old_mean_large, self.old_std_large = new_mean, new_std
+        if self.rank == 0 and self.results_folder_name:
+            with open(os.path.join(self.results_folder_name, 'residue.txt'), 'a+') as f:
+                f.writelines(''.join('{:9.3e} '.format(i) for i in self.residue_all) + '\n')
+
+    def open_convergence(self, geometry):
+        """Header of convergence.txt, column layout of Population.py:1991-2022."""
+        S, R = self.n_of_subvols, self.n_of_reservoirs
+        line = '# ' + 'Real Time                  ' + 'Timest. ' + 'Simul. Time ' + 'Total Energy '
+        for i in range(R):
+            line += 'En Bal Res {} '.format(i)
+        for i in range(R):
+            line += ' Hflux x Res {} '.format(i) + ' Hflux y Res {} '.format(i) + ' Hflux z Res {} '.format(i)
+        line += ' No. Part. '
+        line += ''.join(' T Sv {:>3d} '.format(i) for i in range(S))
+        line += ''.join(' Energ Sv {:>2d} '.format(i) for i in range(S))
+        for i in range(S):
+            line += ' Hflux x Sv {:>2d} '.format(i) + ' Hflux y Sv {:>2d} '.format(i) + ' Hflux z Sv {:>2d} '.format(i)
+        line += ''.join(' Np Sv {:>3d} '.format(i) for i in range(S))
+        if geometry.subvol_type == 'slice':
+            line += ''.join(' Kappa Sv {:>2d} '.format(i) for i in range(S)) + ' Kappa total  '
+        else:
+            line += ''.join(' K Con {:>3d}-{:>3d} '.format(a, b) for a, b in geometry.subvol_connections)
+        self.f = open(os.path.join(self.results_folder_name, 'convergence.txt'), 'a+')
+        self.f.write(line + '\n')
+        self.f.close()
+
+    def _record_convergence(self, geometry):
+        row = dict(step=self.current_timestep, T=np.array(self.subvol_temperature), phi=np.array(self.subvol_heat_flux),
+                   en_res=np.array(self.res_energy_balance), N_p=self.N_p, sv_Np=np.array(self.subvol_N_p),
+                   kappa=getattr(self, 'kappa', np.nan), sv_k=np.array(getattr(self, 'subvol_kappa', np.zeros(0))))
+        self.conv_rows.append(row)
+        if len(self.conv_rows) > max(self.n_mean, 1000):
+            del self.conv_rows[:-max(self.n_mean, 1000)]
+        if self.rank == 0 and self.results_folder_name:
+            self.write_convergence(geometry)
+
+    def write_convergence(self, geometry):
+        """One row of convergence.txt, formats of Population.py:2027-2069."""
+        def arr(a, fmt):
+            return ' '.join(fmt.format(x) for x in np.ravel(a))
+        line = datetime.now().strftime('%Y-%m-%dT%H:%M:%S.%f ')
+        line += '{:>8d} '.format(int(self.current_timestep))
+        line += '{:>12.5e} '.format(self.t)
+        line += '{:>12.5e} '.format(self.total_energy)
+        if self.n_of_reservoirs > 0:
+            line += arr(self.res_energy_balance, '{:>12.5e}') + ' '
+            for i in range(self.n_of_reservoirs):
+                line += arr(self.res_heat_flux[i, :], '{:>14.6e}') + ' '
+        line += '{:>10d} '.format(self.N_p)
+        line += arr(self.subvol_temperature, '{:>9.3f}') + ' '
+        line += arr(self.subvol_energy, '{:>12.5e}') + ' '
+        for i in range(self.n_of_subvols):
+            line += arr(self.subvol_heat_flux[i, :], '{:>14.6e}') + ' '
+        line += arr(np.asarray(self.subvol_N_p).astype(int), '{:>10d}') + ' '
+        if geometry.subvol_type == 'slice':
+            line += arr(self.subvol_kappa, '{:>12.5e}') + ' '
+            line += '{:>13.6e} '.format(self.kappa)
+        else:
+            line += arr(self.svcon_kappa, '{:>14.7e}') + ' '
+        self.f = open(os.path.join(self.results_folder_name, 'convergence.txt'), 'a+')
+        self.f.writelines(line + '\n')
+        self.f.close()
+
+    # ------------------------------------------------------------------------------ particle data
+    def particles(self):
+        """Download the live particles (flushes the deferred relaxation): dict with positions, modes (N,2),
+        occupation, n_timesteps, collision_facets, pid."""
+        p = self.engine.download()
+        J = self._J
+        p['modes'] = np.stack((p['mode'] // J, p['mode'] % J), axis=1)
+        p['collision_facets'] = p['facet']
+        return p
+
+    @property
+    def _J(self):
+        return self.engine.J
+
+    def write_final_state(self, geometry):
+        """particle_data.txt and subvolumes.txt, formats of Population.py:2071-2151."""
+        time = datetime.now().strftime('%Y-%m-%dT%H:%M:%S.%f')
+        p = self.particles()
+        header = ('Particles final state data \n' + 'Date and time: {}\n'.format(time) +
+                  'hdf file = {}, POSCAR file = {}\n'.format(self.args.hdf_file, self.args.poscar_file) +
+                  'q-point, branch, pos x [angs], pos y [angs], pos z [angs], occupation')
+        data = np.hstack((p['modes'], p['positions'], p['occupation'].reshape(-1, 1)))
+        np.savetxt(os.path.join(self.results_folder_name, 'particle_data.txt'), data, '%d, %d, %.3f, %.3f, %.3f, %.6e',
+                   delimiter=',', header=header)
+        if self.current_timestep > 0 and geometry.subvol_type == 'slice' and hasattr(self.view, 'mean_T'):
+            v = self.view
+            S = self.n_of_subvols
+            header = ('subvols final state data \n' + 'Date and time: {}\n'.format(time) +
+                      'hdf file = {}, POSCAR file = {}\n'.format(self.args.hdf_file, self.args.poscar_file) +
+                      'subvol id, subvol x, subvol y, subvol z, subvol volume, T [K], sigma T [K], HF x [W/m^2], HF y [W/m^2], '
+                      'HF z [W/m^2], sigma HF x [W/m^2], sigma HF y [W/m^2], sigma HF z [W/m^2], kappa [W/m K], sigma kappa [W/m K]')
+            data = np.hstack((np.arange(S).reshape(-1, 1), geometry.subvol_center, np.asarray(self.subvol_volume).reshape(-1, 1),
+                              v.mean_T.reshape(-1, 1), v.std_T.reshape(-1, 1), v.mean_sv_phi.reshape(-1, 3),
+                              v.std_sv_phi.reshape(-1, 3), v.mean_sv_k.reshape(-1, 1), v.std_sv_k.reshape(-1, 1)))
+            np.savetxt(os.path.join(self.results_folder_name, 'subvolumes.txt'), data,
+                       '%d, %.3e, %.3e, %.3e, %.3e, %.3f, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e',
+                       delimiter=',', header=header)
+
+    def save_plot_real_time(self):
+        """Called by the reference driver (nanokappa.py:105) but defined nowhere there; a no-op here."""
+        return None
+
+
+def _phonon_tables(ph):
+    """Tables from a REFERENCE Phonon object (attribute names of classes/Phonon.py)."""
+    T_min, T_max = ph.temperature_array.min(), ph.temperature_array.max()
+    T_array = np.arange(T_min, T_max + 0.1, 0.1)
+    return dict(omega=ph.omega, group_vel=ph.group_vel, T_grid=ph.temperature_array, lifetime=ph.lifetime,
+                T_array=T_array, energy_array=ph.energy_array, hbar=ph.hbar, kb=ph.kb,
+                QV=ph.number_of_qpoints * ph.volume_unitcell, active_modes=ph.number_of_active_modes)
+
+
+def _geometry_tables(geo):
+    """Tables from a REFERENCE Geometry object (attribute names of classes/Geometry.py, classes/Mesh.py)."""
+    m = geo.mesh
+    return dict(vertices=m.vertices, faces=m.faces, face_normals=m.face_normals, face_k=m.face_k, face_bounds=m.face_bounds,
+                face_basis_matrix=m.face_basis_matrix, face_origins=m.face_origins, face_facets=m.face_facets,
+                face_areas=m.face_areas, facets_normal=m.facets_normal, facet_centroid=m.facet_centroid, facets=m.facets,
+                bounds=m.bounds, simplices_points=m.simplices_points, simplices=m.simplices,
+                simplices_volumes=m.simplices_volumes, tol=m.tol, bound_cond=geo.bound_cond,
+                connected_facets=geo.connected_facets)

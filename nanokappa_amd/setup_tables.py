@@ -1,0 +1,171 @@
+"""Per-facet x per-mode tables consumed by the hot loop (SURVEY.md section 8 row a2/a7 inputs, 8f row 1).
+
+Host-side NumPy restatements of the reference's one-off builders in classes/Population.py:
+  enter_probability            :146-161
+  calculate_fbz_specularity    :852-877
+  find_specular_correspondences ('velocity' model) :1241-1454, specular_function :1457
+  diffuse_scat_probability     :879-939
+  find_degeneracies            :1017-1040
+The 'k' (wavevector) reflection model of :1058-1239 is not built yet.
+"""
+import numpy as np
+
+
+def enter_probability(geometry, phonon, res_facet, particle_density, dt):
+    """p[r,q,j] = max(0, v.n_in) * dt / bound_thickness, bound_thickness = M / (rho * A_facet)."""
+    thick = phonon.number_of_active_modes / (particle_density * geometry.facets_area[res_facet])
+    normals = -geometry.facets_normal[res_facet, :]                      # inward
+    vpar = np.einsum('rd,qjd->rqj', normals, phonon.group_vel)
+    p = vpar * dt / thick.reshape(-1, 1, 1)
+    return np.where(p < 0, 0, p)
+
+
+def fbz_specularity(geometry, phonon, rough_facets, eta):
+    """exp(-(2 eta cos(theta))^2 k^2) per (facet, q, j)."""
+    n = -geometry.facets_normal[rough_facets, :]
+    k_norm = np.sum(phonon.wavevectors ** 2, axis=1) ** 0.5
+    v = phonon.group_vel
+    v_norm = np.sum(v ** 2, axis=-1) ** 0.5
+    dot = np.einsum('fd,qjd->fqj', n, v)
+    with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
+        cos = dot / v_norm[None]
+    const = -(2 * np.asarray(eta, dtype=float).reshape(-1, 1, 1) * cos) ** 2
+    spec = np.exp(const * (k_norm.reshape(1, -1, 1) ** 2))
+    spec[np.isnan(spec)] = 0
+    return spec
+
+
+def find_degeneracies(phonon):
+    """[q, j1, j2] rows with equal omega at the same q (j1 < j2), and the (Q,J) index table."""
+    om = phonon.omega
+    J = om.shape[1]
+    rows = []
+    for j1 in range(J):
+        for j2 in range(j1 + 1, J):
+            q = np.nonzero(np.abs(om[:, j1] - om[:, j2]) < 1e-10)[0]
+            rows += [(int(a), j1, j2) for a in q]
+    deg = np.array(sorted(rows), dtype=int).reshape(-1, 3)
+    idx = -np.ones(om.shape)
+    if deg.shape[0]:
+        idx[deg[:, 0], deg[:, 1]] = np.arange(deg.shape[0])
+        idx[deg[:, 0], deg[:, 2]] = np.arange(deg.shape[0])
+    return deg, idx
+
+
+def specular_correspondences_velocity(geometry, phonon, rough_facets, crit=1e-3, keep_nan_pairs=False):
+    """Pairs (in-mode -> out-mode) whose mirrored group velocity and frequency agree within the grid tolerance.
+
+    Returns (correspondent_modes (K,7): n(3) q_in j_in q_out j_out, true_spec (Fr,Q,J) bool).
+    """
+    normals = -np.round(geometry.facets_normal[rough_facets, :], decimals=10)
+    normals, inv_normals = np.unique(normals, axis=0, return_inverse=True)
+    inv_normals = np.asarray(inv_normals).ravel()
+    v = phonon.group_vel
+    Q, J = phonon.omega.shape
+    true_spec = np.zeros((len(rough_facets), Q, J), dtype=bool)
+    k_grid = phonon.q_to_k(np.absolute(1 / (2 * phonon.data_mesh)))
+    delta_omega = np.sum((v * k_grid) ** 2, axis=2) ** 0.5
+    rows = []
+    for i_n, n in enumerate(normals):
+        vdn = np.sum(v * n, axis=2)
+        in_modes = np.vstack(np.nonzero(vdn < 0)).T
+        out_modes = np.vstack(np.nonzero(vdn > 0)).T
+        v_in = v[in_modes[:, 0], in_modes[:, 1], :]
+        v_ref = v_in - 2 * n * np.sum(v_in * n, axis=1, keepdims=True)
+        v_out = v[out_modes[:, 0], out_modes[:, 1], :]
+        nrm_in = np.linalg.norm(v_ref, axis=1)
+        nrm_out = np.linalg.norm(v_out, axis=1)
+        om_in = phonon.omega[in_modes[:, 0], in_modes[:, 1]]
+        om_out = phonon.omega[out_modes[:, 0], out_modes[:, 1]]
+        d_in = delta_omega[in_modes[:, 0], in_modes[:, 1]]
+        d_out = delta_omega[out_modes[:, 0], out_modes[:, 1]]
+        # candidate window in the sorted x-velocities, then the exact per-pair criteria
+        order = np.argsort(v_out[:, 0], kind='stable')
+        sx = v_out[order, 0]
+        vmax = max(nrm_in.max(), nrm_out.max())
+        lo = np.searchsorted(sx, v_ref[:, 0] - crit * vmax, side='left')
+        hi = np.searchsorted(sx, v_ref[:, 0] + crit * vmax, side='right')
+        pi, po = [], []
+        for a in range(in_modes.shape[0]):
+            if hi[a] > lo[a]:
+                cand = order[lo[a]:hi[a]]
+                ref = np.fmax(nrm_in[a], nrm_out[cand])
+                ok = np.all(np.abs(v_ref[a] - v_out[cand]) / ref[:, None] < crit, axis=1)
+                ok &= np.abs(om_in[a] - om_out[cand]) < d_in[a] + d_out[cand]
+                cand = cand[ok]
+                if cand.size:
+                    # angle test exactly as the reference evaluates it (Population.py:1357-1369): normalise the
+                    # un-mirrored in-velocity, mirror it, dot with the normalised out-velocity.  When rounding
+                    # pushes the dot product above 1 arccos is NaN and the reference REJECTS the pair (angle := pi);
+                    # that drops ~1/4 of the perfectly aligned pairs, and is reproduced for table parity.
+                    u_in = v_in[a] / np.sqrt(v_in[a, 0] ** 2 + v_in[a, 1] ** 2 + v_in[a, 2] ** 2)
+                    vo = v_out[cand]
+                    u_out = vo / np.sqrt(vo[:, 0] ** 2 + vo[:, 1] ** 2 + vo[:, 2] ** 2)[:, None]
+                    u_try = u_in - 2 * n * np.sum(u_in * n)
+                    with np.errstate(invalid='ignore'):
+                        ang = np.arccos(np.sum(u_try * u_out, axis=1))
+                    if keep_nan_pairs:
+                        ang = np.where(np.isnan(ang), 0.0, ang)
+                    else:
+                        ang[np.isnan(ang)] = np.pi
+                    cand = cand[ang < crit]
+                    pi += [a] * cand.size
+                    po += list(np.sort(cand))
+        pi = np.array(pi, dtype=int)
+        po = np.array(po, dtype=int)
+        # reference ordering: by sorted reflected-vx of the in-mode, then ascending out index within it
+        key = np.lexsort((po, np.argsort(np.argsort(v_ref[:, 0], kind='stable'))[pi])) if pi.size else np.zeros(0, dtype=int)
+        pi, po = pi[key], po[key]
+        im, om_ = in_modes[pi], out_modes[po]
+        facets_here = np.nonzero(inv_normals == i_n)[0]
+        for fct in facets_here:
+            true_spec[fct, im[:, 0], im[:, 1]] = True
+        rows.append(np.hstack((np.tile(n, (im.shape[0], 1)), im, om_)))
+    corr = np.vstack(rows) if rows else np.zeros((0, 7))
+    return corr, true_spec
+
+
+def specular_map(corr, geometry, rough_facets, Q, J):
+    """Flat out-mode per (rough facet, q, j), -1 where the mode has no specular partner.  When an in-mode has
+    several partners the reference's nearest-neighbour lookup (Population.py:1457) returns one of them; here the
+    one with the smallest (q_out, j_out) is taken."""
+    out = -np.ones((len(rough_facets), Q, J), dtype=np.int64)
+    if corr.shape[0] == 0:
+        return out
+    normals = -np.round(geometry.facets_normal[rough_facets, :], decimals=10)
+    for i, n in enumerate(normals):
+        sel = np.nonzero(np.linalg.norm(corr[:, :3] - n, axis=1) < 1e-9)[0]
+        c = corr[sel].astype(np.int64)
+        order = np.lexsort((c[:, 6], c[:, 5]))[::-1]        # descending, so the smallest is written last
+        c = c[order]
+        out[i, c[:, 3], c[:, 4]] = c[:, 5] * J + c[:, 6]
+    return out
+
+
+def diffuse_roulette(geometry, phonon, rough_facets, specularity, corr, scat_model='velocity', degeneracies=None):
+    """creation_rate and its cumulative 'roulette' per rough facet."""
+    n = -geometry.facets_normal[rough_facets, :]
+    vdn = np.einsum('fd,qjd->fqj', n, phonon.group_vel)
+    C_total = np.where(vdn > 0, vdn, 0)
+    D_total = np.where(vdn < 0, -vdn, 0)
+    specular_D = D_total * specularity
+    rate = np.where(np.isnan(C_total), 0, C_total).copy()
+    if corr.shape[0]:
+        in_q, in_j = corr[:, 3].astype(int), corr[:, 4].astype(int)
+        out_q, out_j = corr[:, 5].astype(int), corr[:, 6].astype(int)
+        un, inv_n = np.unique(n, axis=0, return_inverse=True)
+        inv_n = np.asarray(inv_n).ravel()
+        for i_n, u in enumerate(un):
+            sel = np.nonzero(np.linalg.norm(corr[:, :3] - u, axis=1) < 1e-10)[0]
+            for f in np.nonzero(inv_n == i_n)[0]:
+                np.subtract.at(rate[f], (out_q[sel], out_j[sel]), specular_D[f, in_q[sel], in_j[sel]])
+    if scat_model in ('k', 'wavevector', 'wave_vector') and degeneracies is not None:
+        for q, j1, j2 in degeneracies:
+            rate[:, q, [j1, j2]] = rate[:, q, [j1, j2]].mean(axis=-1, keepdims=True)
+    rate = np.around(rate, decimals=10)
+    Fr = len(rough_facets)
+    roul = np.zeros((Fr, phonon.number_of_qpoints * phonon.number_of_branches))
+    for f in range(Fr):
+        c = np.cumsum(rate[f])
+        roul[f] = c / c.max()
+    return rate, roul

@@ -158,29 +158,4 @@ def make_phonon(ref, args, material):
     return p
 
 
-BOX_TTP = ['--geometry', 'box', '--dimensions', '200', '200', '200',
-           '--subvolumes', 'slice', '20', '0',
-           '--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5',
-           '--bound_cond', 'T', 'T', 'P',
-           '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
-           '--bound_values', '302', '298']
-
-BOX_TTRRP = ['--geometry', 'box', '--dimensions', '200', '200', '200',
-             '--subvolumes', 'slice', '20', '0',
-             '--bound_pos', 'relative', '-0.1', '0.5', '0.5', '1.1', '0.5', '0.5',
-             '0.5', '0.5', '-0.1', '0.5', '0.5', '1.1',
-             '--bound_cond', 'T', 'T', 'R', 'R', 'P',
-             '--connect_pos', 'relative', '0.5', '-0.1', '0.5', '0.5', '1.1', '0.5',
-             '--bound_values', '302', '298', '5', '5']
-
-COMMON = ['--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
-          '--reference_temp', 'local', '--temp_dist', 'cold', '--temp_interp', 'linear',
-          '--part_dist', 'random_subvol', '--timestep', '1', '--n_mean', '10',
-          '--conv_crit', '0', '10', '--colormap', 'jet', '--fig_plot', 'energy',
-          '--output', 'screen', '--max_sim_time', '0-00:00:00', '--energy_normal', 'mean']
-
-
-def argv_for(case, particles, iterations=1000, extra=()):
-    base = {'ttp': BOX_TTP, 'ttrrp': BOX_TTRRP}[case]
-    return list(base) + list(COMMON) + ['--particles', 'total', str(particles),
-                                        '--iterations', str(iterations)] + list(extra)
+from ref_harness_args import BOX_TTP, BOX_TTRRP, COMMON, argv_for  # noqa: E402,F401

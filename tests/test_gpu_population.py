@@ -1,0 +1,86 @@
+"""End-to-end Population runs on the GPU against the reference's statistical goldens
+(tests/golden/stats_*.npz: 8 seeds x 1e5 particles x 1000 steps of the reference itself)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import golden, golden_material
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
+
+
+def build_population(case, particles, seed, tmpdir=None, extra=()):
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.phonon import Phonon
+    from nanokappa_amd.population import Population
+    import ref_harness_args as A
+    argv = A.argv_for(case, particles) + ['--seed', str(seed)] + list(extra)
+    args = initialise_parser().parse_args(argv)
+    args.results_folder = str(tmpdir) if tmpdir else ''
+    geo = Geometry(args)
+    ph = Phonon(args, 0, material=golden_material())
+    pop = Population(args, geo, ph)
+    return pop, geo, ph
+
+
+def window_stats(rows, lo=50):
+    """mean over the convergence rows lo.. of each run -> per-run scalars."""
+    cols = dict(N_p=1, kappa=2)
+    T = rows[:, lo:, 3:23].mean(axis=1)
+    phi = rows[:, lo:, 23:43].mean(axis=(1, 2))
+    kap = rows[:, lo:, 2].mean(axis=1)
+    Np = rows[:, lo:, 1].mean(axis=1)
+    return T, phi, kap, Np
+
+
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
+def test_statistical_parity_with_reference(case, tmp_path):
+    """Same configuration as the reference goldens (C1a / C1b of SURVEY 8d, 729 x 6 synthetic Si): per-subvolume
+    temperature, heat flux, kappa and particle count, averaged over steps 500-1000, must lie within the
+    reference's seed-to-seed scatter (criterion of SURVEY 8d: 2 sigma on T / phi / kappa, 1 % on N_p)."""
+    g = golden('stats_' + case)
+    Tr, phir, kr, Npr = window_stats(g['rows'])
+    seeds = [101, 102, 103, 104]
+    rows = []
+    for s in seeds:
+        pop, geo, ph = build_population(case, 100000, s, tmp_path / ('run%d' % s) if False else None)
+        rec = []
+        for _ in range(100):
+            pop.run(10, geo, ph)
+            rec.append(np.concatenate(([pop.current_timestep, pop.N_p, pop.kappa], pop.subvol_temperature,
+                                       pop.subvol_heat_flux[:, 0], pop.subvol_N_p, pop.subvol_kappa)))
+        rows.append(np.array(rec))
+        pop.engine.close()
+    rows = np.array(rows)
+    Tm, phim, km, Npm = window_stats(rows)
+    n = len(seeds)
+    # difference of means against the pooled standard error, 3 sigma on each of the 20 temperatures
+    se_T = np.sqrt(Tr.var(axis=0, ddof=1) / Tr.shape[0] + Tm.var(axis=0, ddof=1) / n)
+    assert np.all(np.abs(Tm.mean(axis=0) - Tr.mean(axis=0)) < 3 * se_T + 1e-3), (Tm.mean(axis=0) - Tr.mean(axis=0)) / se_T
+    se = np.sqrt(phir.var(ddof=1) / phir.size + phim.var(ddof=1) / n)
+    assert abs(phim.mean() - phir.mean()) < 3 * se, (phim.mean(), phir.mean(), se)
+    se = np.sqrt(kr.var(ddof=1) / kr.size + km.var(ddof=1) / n)
+    assert abs(km.mean() - kr.mean()) < 3 * se, (km.mean(), kr.mean(), se)
+    assert abs(Npm.mean() / Npr.mean() - 1) < 0.01
+
+
+def test_outputs_written(tmp_path):
+    """convergence.txt / particle_data.txt / residue.txt in the reference's layout."""
+    pop, geo, ph = build_population('ttrrp', 20000, 7, tmp_path)
+    pop.args.results_folder = str(tmp_path)
+    pop.run(110, geo, ph)
+    pop.write_final_state(geo)
+    conv = open(tmp_path / 'convergence.txt').read().splitlines()
+    assert conv[0].startswith('# Real Time')
+    assert len(conv) == 1 + 1 + 11
+    ncol = len(conv[1].split())
+    S, R = 20, 2
+    assert ncol == 4 + 4 * R + 1 + 7 * S + 1
+    pd = np.loadtxt(tmp_path / 'particle_data.txt', delimiter=',', comments='#')
+    assert pd.shape[1] == 6 and abs(pd.shape[0] - 20000) < 2000
+    assert os.path.exists(tmp_path / 'residue.txt')
