@@ -137,8 +137,9 @@ typedef struct {
 
 /* Kernel timing of the last nk_step call, from HIP events on the library's stream. */
 typedef struct {
-    double step_kernel_ms;   /* mean duration of the fused advect-scatter-tally kernel */
-    double emit_kernel_ms;   /* mean duration of the reservoir emission kernel */
+    double step_kernel_ms;   /* mean duration of k_step: relax + drift + tally over every live slot */
+    double emit_kernel_ms;   /* mean duration of reservoir emission (k_emit_count + k_spawn) */
+    double events_kernel_ms; /* mean duration of k_events: boundary events of the queued particles */
     double total_ms;         /* wall time of the whole call on the stream */
     int64_t slots;           /* particle slots swept by the last step kernel */
     int64_t live;            /* live particles after the call (this rank) */

@@ -1,19 +1,24 @@
 // nk_device.h -- device-side data model and per-particle physics of the MI355X engine.
 //
-// One particle = one lane.  Particle state is SoA in HBM (x, y, z, occupation, time-to-boundary as
-// doubles; mode and next facet as int32; a 64-bit particle id that keys the counter-based RNG).
-// Small read-only tables (faces, facets, slice centres, subvolume temperatures) and the tally bins
-// live in LDS; per-mode tables are gathered from L2 / Infinity Cache.
+// One particle = one lane.  Particle state is SoA in HBM (x, y, z, occupation, time-to-boundary as doubles; mode and
+// next facet as int32; a 64-bit particle id that keys the counter-based RNG).  Small read-only tables (planes, faces,
+// facets, slice centres, subvolume temperatures) and the tally bins live in LDS; per-mode records (64 B: omega, group
+// velocity and the four lifetime rows around the live temperature range) are gathered from L2 / Infinity Cache.
 //
 // Reference semantics cited as file:line under the reference checkout (classes/Population.py etc.).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#define NK_WG 256          // threads per workgroup (4 waves of 64)
-#define NK_NREP 8          // LDS replicas of the tally bins (lane & 7) to thin same-address atomics
-#define NK_FACE_DOUBLES 20 // doubles per face record
-#define NK_LDS_FACES 256   // meshes up to this many faces keep their face table in LDS
+#define NK_WG 256            // threads per workgroup (4 waves of 64)
+#define NK_NREP 8            // LDS replicas of the tally bins (lane & 7) to thin same-address atomics
+#define NK_PLANE_DOUBLES 5   // nx ny nz k {face_begin, face_end}
+#define NK_FACE_DOUBLES 16   // lo(3) hi(3) o(3) iu(3) iw(3) {orig_face, facet}
+#define NK_LDS_FACES 256     // meshes up to this many faces keep their plane/face tables in LDS
+#define NK_TAU_ROWS 4        // lifetime rows packed into each mode record
+#define NK_EVQ_SHARDS 256    // the event queue is split into shards, each with its own counter (one hot counter
+                             // saturates at ~90 atomics/us: 156k wave-level pushes per step would cost 1.8 ms)
+#define NK_EVQ_PAD 32        // ints between shard counters (128 B: one L2 line each)
 
 // RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")
 #define NK_TAG_REFLECT 0x00000u
@@ -31,12 +36,18 @@ struct NkFacet {          // 80 bytes
     int32_t pad[4];
 };
 
+struct __attribute__((aligned(64))) NkMode {   // one gather per particle
+    double omega, vx, vy, vz;
+    double tau[NK_TAU_ROWS];                   // lifetime at T_grid[tau_row0 .. tau_row0+3]
+};
+
 // Everything a kernel needs, passed by value (pointers are device pointers).
 struct NkDev {
     // ---- material
     int32_t Q, J, NT, M;              // M = Q*J
-    const double4 *modetab;           // [M] {omega, vx, vy, vz}
-    const double *tau;                // [NT*M]
+    const NkMode *modetab;            // [M]
+    int32_t tau_row0;                 // first T_grid row held in NkMode::tau
+    const double *tau;                // [NT*M] full table (fallback outside the packed window)
     const double *Tgrid;              // [NT]
     int32_t nE;
     const double *Tarr, *Earr;        // [nE]
@@ -44,13 +55,13 @@ struct NkDev {
     double hbar, kb, QV;
     double active_modes;
     // ---- mesh
-    int32_t F, Fc;
-    const double *faces;              // [F*NK_FACE_DOUBLES]
-    const int32_t *face_facet;        // [F]
+    int32_t F, Fc, NP;                // faces, facets, distinct planes
+    const double *planes;             // [NP*NK_PLANE_DOUBLES]
+    const double *faces;              // [F*NK_FACE_DOUBLES], grouped by plane
     const NkFacet *facets;            // [Fc]
     double tol;
     double bbox[6];
-    const double *face_verts;         // [F*9]
+    const double *face_verts;         // [F*9] original face order
     const int32_t *facet_face_off;    // [Fc+1]
     const int32_t *facet_face_idx;
     const double *facet_face_cdf;     // per facet, cumulative area fraction of its faces (same CSR)
@@ -69,6 +80,9 @@ struct NkDev {
     const double *res_T;              // [R]
     const double *enter_prob;         // [R*M]
     double *res_counter;              // [R*M]
+    double *res_cval;                 // [R*M] counter / dice value used by the level-1 entry time
+    uint64_t *spawn_list;             // [spawn_cap] (rm << 12 | level) of every particle entering this step
+    int64_t spawn_cap;
     // ---- rough facets
     int32_t Fr;
     const double *specularity;        // [Fr*M]
@@ -87,15 +101,27 @@ struct NkDev {
     double *x, *y, *z, *occ, *nts;
     int32_t *mode, *facet;
     uint64_t *pid;
-    // ---- bookkeeping in device memory
+    // ---- bookkeeping words in device memory
     int64_t *n_slots;                 // high-water slot count
-    int32_t *free_list;               // [cap] stack of dead slots
-    int32_t *free_top;                // entries on the stack
-    int32_t *alloc_count;             // slots requested by the emission kernel this step
+    int32_t *free_ring;               // [cap] FIFO of dead slots: pushes at tail (k_events), pops at head (k_spawn)
+    unsigned long long *fl_head, *fl_tail;
+    int64_t *fl_avail;                // tail - head snapshot taken by k_update = slots the next emission may reuse
+    int32_t *evq;                     // [NK_EVQ_SHARDS][evq_seg] slots whose particle meets a boundary this step
+    int32_t *evq_count;               // [NK_EVQ_SHARDS*NK_EVQ_PAD] entries per shard
+    int64_t evq_seg;                  // capacity of one shard
+    int32_t *alloc_count;             // particles entering this step (this rank)
     int32_t *overflow;                // set when a particle had to be dropped for lack of capacity
     double *partials;                 // [rows][NB] per-workgroup tally rows
     int32_t NB;                       // bins per row = 5*S + 5*R + 1
 };
+
+// Append slot `i` to the event queue shard of this workgroup.
+__device__ __forceinline__ void nk_evq_push(const NkDev &d, int64_t i) {
+    const int q = blockIdx.x & (NK_EVQ_SHARDS - 1);
+    const int k = atomicAdd(d.evq_count + q * NK_EVQ_PAD, 1);
+    if (k < d.evq_seg) d.evq[(int64_t)q * d.evq_seg + k] = (int32_t)i;
+    else *d.overflow = 1;
+}
 
 // ------------------------------------------------------------------------------------------------ RNG
 // Philox4x32-10, counter = {pid_lo, pid_hi, step, tag}, key = seed.  Stateless: nothing is stored per particle.
@@ -159,20 +185,28 @@ __device__ __forceinline__ double nk_E_of_T(const NkDev &d, double T) {
     return nk_interp_lin(d.Tarr, d.Earr, d.nE, T);
 }
 // lifetime_function = RegularGridInterpolator((T,q,j), tau) at integer (q,j): linear in tau along T (Phonon.py:336).
-// Out-of-table T gives NaN (the reference raises ValueError there).
-__device__ __forceinline__ double nk_lifetime(const NkDev &d, double T, int mode) {
+// Out-of-table T gives NaN (the reference raises ValueError there).  `rec` is the particle's mode record; its four
+// packed rows serve the live temperature range, anything else falls back to the full table.
+__device__ __forceinline__ double nk_lifetime(const NkDev &d, const NkMode &rec, double T, int mode) {
     const int NT = d.NT;
     const double *g = d.Tgrid;
     if (!(T >= g[0]) || !(T <= g[NT - 1])) return __builtin_nan("");
-    // uniform-grid guess, then the exact searchsorted fix-up
-    int i = (int)((T - g[0]) / (g[1] - g[0]));
+    int i = (int)((T - g[0]) / (g[1] - g[0]));       // uniform-grid guess, then the exact searchsorted fix-up
     i = i < 0 ? 0 : (i > NT - 1 ? NT - 1 : i);
-    while (i < NT && g[i] < T) ++i;          // i = number of grid points < T  (searchsorted left)
+    while (i < NT && g[i] < T) ++i;                  // i = number of grid points < T  (searchsorted left)
     while (i > 0 && g[i - 1] >= T) --i;
     i -= 1;
     i = i < 0 ? 0 : (i > NT - 2 ? NT - 2 : i);
-    double y = (T - g[i]) / (g[i + 1] - g[i]);
-    double t0 = d.tau[(int64_t)i * d.M + mode], t1 = d.tau[(int64_t)(i + 1) * d.M + mode];
+    const double y = (T - g[i]) / (g[i + 1] - g[i]);
+    const int k = i - d.tau_row0;
+    double t0, t1;
+    if (k >= 0 && k < NK_TAU_ROWS - 1) {
+        t0 = k == 0 ? rec.tau[0] : (k == 1 ? rec.tau[1] : rec.tau[2]);
+        t1 = k == 0 ? rec.tau[1] : (k == 1 ? rec.tau[2] : rec.tau[3]);
+    } else {
+        t0 = d.tau[(int64_t)i * d.M + mode];
+        t1 = d.tau[(int64_t)(i + 1) * d.M + mode];
+    }
     return t0 * (1.0 - y) + t1 * y;
 }
 
@@ -224,33 +258,40 @@ __device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen,
 }
 
 // -------------------------------------------------------------------------------------- ray casting
-// Mesh.find_boundary, Mesh.py:806-856: nearest valid triangle hit; first index wins ties; miss -> inf, -1.
-// Face record: n(3) k lo(3) hi(3) o(3) iu(3) iw(3) pad -> 20 doubles; iu/iw are the first two rows of the inverse of
-// face_basis_matrix, so (u, w) = rows . (c - o) is the solve() of Mesh.py:840.
-__device__ __forceinline__ void nk_find_boundary(const double *faces, const int32_t *face_facet, int F, double tol,
-                                                 double x, double y, double z, double vx, double vy, double vz,
-                                                 double &tc, int &fc) {
+// Mesh.find_boundary, Mesh.py:806-856: nearest valid triangle hit; the lowest face index wins ties; miss -> inf, -1.
+// Coplanar triangles share one plane record, so t = -(x.n + k)/(v.n) (Mesh.py:818) is evaluated once per distinct
+// plane and only when x.n + k and v.n have opposite signs (t >= tol > 0 is impossible otherwise, Mesh.py:820); the
+// per-triangle AABB (:828-829) and barycentric tests (:837-843) then run on that plane's faces.  Face record rows
+// iu/iw are the first two rows of the inverse of face_basis_matrix: (u, w) = rows . (c - o) is the solve() of :840.
+__device__ __forceinline__ void nk_find_boundary(const double *planes, const double *faces, int NP, double tol, double x,
+                                                 double y, double z, double vx, double vy, double vz, double &tc, int &fc) {
     double tbest = __builtin_inf();
-    int fbest = -1;
-    for (int f = 0; f < F; ++f) {
-        const double *p = faces + f * NK_FACE_DOUBLES;
-        double num = x * p[0] + y * p[1] + z * p[2] + p[3];
-        double den = vx * p[0] + vy * p[1] + vz * p[2];
-        double t = -num / den;
-        if (!(t >= tol) || isinf(t)) continue;
-        double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
-        if (!(cx >= p[4] - tol) || !(cy >= p[5] - tol) || !(cz >= p[6] - tol) || !(cx <= p[7] + tol) ||
-            !(cy <= p[8] + tol) || !(cz <= p[9] + tol))
-            continue;
-        double bx = cx - p[10], by = cy - p[11], bz = cz - p[12];
-        double u = p[13] * bx + p[14] * by + p[15] * bz;
-        double w = p[16] * bx + p[17] * by + p[18] * bz;
-        double q = 1.0 - (u + w);
-        if (!(u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && q >= -tol && q <= 1.0 + tol)) continue;
-        if (t < tbest) { tbest = t; fbest = f; }
+    int fbest = 0x7fffffff, facet = -1;
+    for (int pl = 0; pl < NP; ++pl) {
+        const double *p = planes + pl * NK_PLANE_DOUBLES;
+        const double num = x * p[0] + y * p[1] + z * p[2] + p[3];
+        const double den = vx * p[0] + vy * p[1] + vz * p[2];
+        if (!((num < 0.0 && den > 0.0) || (num > 0.0 && den < 0.0))) continue;
+        const double t = -num / den;
+        if (!(t >= tol) || isinf(t) || t > tbest) continue;
+        const double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
+        const int2 rng = *reinterpret_cast<const int2 *>(p + 4);
+        for (int f = rng.x; f < rng.y; ++f) {
+            const double *q = faces + f * NK_FACE_DOUBLES;
+            if (!(cx >= q[0] - tol) || !(cy >= q[1] - tol) || !(cz >= q[2] - tol) || !(cx <= q[3] + tol) ||
+                !(cy <= q[4] + tol) || !(cz <= q[5] + tol))
+                continue;
+            const double bx = cx - q[6], by = cy - q[7], bz = cz - q[8];
+            const double u = q[9] * bx + q[10] * by + q[11] * bz;
+            const double w = q[12] * bx + q[13] * by + q[14] * bz;
+            const double r = 1.0 - (u + w);
+            if (!(u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol)) continue;
+            const int2 id = *reinterpret_cast<const int2 *>(q + 15);
+            if (t < tbest || id.x < fbest) { tbest = t; fbest = id.x; facet = id.y; }
+        }
     }
     tc = tbest;
-    fc = fbest < 0 ? -1 : face_facet[fbest];
+    fc = facet;
 }
 
 // ---------------------------------------------------------------------------------- rough reflection
@@ -273,7 +314,7 @@ __device__ __forceinline__ void nk_reflect(const NkDev &d, const double *cen, co
         int flat = nk_ss_left(roul, d.M, r);
         if (flat > d.M - 1) flat = d.M - 1;
         mode_out = flat;
-        omega_out = d.modetab[flat].x;
+        omega_out = d.modetab[flat].omega;
         double T = nk_interp_T(d, cen, Tsv, cx, cy, cz, -1);
         n_out = nk_occupation(d, T, omega_out);
     }
@@ -287,15 +328,15 @@ struct NkBins {
     unsigned int *N, *nleave, *misc;
 };
 
-// One particle's life inside a timestep after the free drift: Population.boundary_scattering (Population.py:1546-1683)
-// restated per particle.  On entry (x,y,z) is the end-of-step position of the free drift and nts < 0.
 struct NkParticle {
     double x, y, z, occ, nts, omega, vx, vy, vz;
     int mode, facet;
     bool alive;
 };
 
-__device__ __forceinline__ void nk_events(const NkDev &d, const double *faces, const int32_t *face_facet,
+// One particle's boundary events inside a timestep: Population.boundary_scattering (Population.py:1546-1683) restated
+// per particle.  On entry (x,y,z) is the end-of-step position of the free drift and nts < 0.
+__device__ __forceinline__ void nk_events(const NkDev &d, const double *planes, const double *faces,
                                           const NkFacet *facets, const double *cen, const double *Tsv, NkBins &b,
                                           NkParticle &p, uint64_t pid, uint32_t step) {
     const double dt = d.dt;
@@ -338,11 +379,11 @@ __device__ __forceinline__ void nk_events(const NkDev &d, const double *faces, c
                 int mo; double no, oo;
                 nk_reflect(d, cen, Tsv, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, r0, r1, r1, mo, no, oo);
                 p.mode = mo; p.occ = no; p.omega = oo;
-                double4 rec = d.modetab[mo];
-                p.vx = rec.y; p.vy = rec.z; p.vz = rec.w;
+                const NkMode *rec = d.modetab + mo;
+                p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
             }
             double tc; int fcn;
-            nk_find_boundary(faces, face_facet, d.F, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
+            nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
             p.nts = tc / dt;
             p.facet = fcn;
             if (++ev > 4096u) cts = 1.0;                     // the reference would spin
@@ -355,17 +396,18 @@ __device__ __forceinline__ void nk_events(const NkDev &d, const double *faces, c
 }
 
 // Population.calculate_energy's per-particle part (Population.py:704-717) + the heat-flux sum (:734-736).
-__device__ __forceinline__ void nk_tally_one(const NkDev &d, const double *cen, const double *Tsv, NkBins &b,
-                                         const NkParticle &p, bool do_flux, int rep) {
-    int s = nk_classify(d, cen, p.x, p.y, p.z);
+__device__ __forceinline__ void nk_tally_one(const NkDev &d, const double *cen, const double *Tsv, NkBins &b, double x,
+                                             double y, double z, double occ, double omega, double vx, double vy, double vz,
+                                             bool do_flux, int rep) {
+    int s = nk_classify(d, cen, x, y, z);
     double Tr = d.T_ref_local ? Tsv[s] : d.T_ref;
-    double e = d.hbar * p.omega * (p.occ - nk_occupation(d, Tr, p.omega));
+    double e = d.hbar * omega * (occ - nk_occupation(d, Tr, omega));
     atomicAdd(&b.E[rep * d.S + s], e);
     atomicAdd(&b.N[rep * d.S + s], 1u);
     if (do_flux) {
         double *fl = b.flux + (rep * d.S + s) * 3;
-        atomicAdd(fl + 0, p.vx * e);
-        atomicAdd(fl + 1, p.vy * e);
-        atomicAdd(fl + 2, p.vz * e);
+        atomicAdd(fl + 0, vx * e);
+        atomicAdd(fl + 1, vy * e);
+        atomicAdd(fl + 2, vz * e);
     }
 }

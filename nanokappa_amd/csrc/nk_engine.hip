@@ -1,422 +1,20 @@
-// nk_engine.hip -- kernels and C ABI of libnanokappa_hip.so (gfx950 / MI355X only).
-//
-// Stream order of one timestep (reference Population.run_timestep, Population.py:1724-1769):
-//   [k_relax + k_contains every `contains_every` steps]          contains_check        :1712-1722
-//   k_step    relax(previous step) -> drift -> boundary events -> energy/flux tally
-//                                                                 lifetime_scattering  :1701-1710 (deferred, see below)
-//                                                                 drift                :790-795
-//                                                                 boundary_scattering  :1546-1683
-//                                                                 calculate_energy     :704-717
-//   k_emit    reservoir emission + the same event loop + tally    fill_reservoirs      :356-523, add_reservoir_particles :525-552
-//   k_reduce  deterministic column sums of the per-workgroup tally rows
-//   (RCCL all-reduce of the tally vector when nranks > 1)
-//   k_update  normalisation, E -> T, bookkeeping, history row     calculate_energy     :719-728, refresh_temperatures :692
-//
-// Deferred relaxation: the reference relaxes occupations at the END of step k with the temperatures of step k.
-// Those temperatures need the global tally of step k, so the relaxation is carried into the BEGINNING of the step
-// kernel of step k+1 (same particle positions, same T_sv): one streaming pass per step instead of two.  A pending
-// relaxation is flushed by k_relax before anything observes the particles (download, contains_check).
+// nk_engine.hip -- host side (C ABI, include/nanokappa_hip.h) of libnanokappa_hip.so; kernels in nk_kernels.h.
+// gfx950 / MI355X only.  HIP runtime + (lazily, multi-GPU only) RCCL; no PyTorch, no CPU fallback.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
 #include <rccl/rccl.h>
 
 #include "../../include/nanokappa_hip.h"
-#include "nk_device.h"
+#include "nk_kernels.h"
 
-// =================================================================================== LDS carve-up
-struct NkLds {
-    double *Tsv, *cen;
-    NkBins bins;
-    const double *faces;
-    const int32_t *face_facet;
-    const NkFacet *facets;
-};
-
-__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int Fc) {
-    int Fl = F <= NK_LDS_FACES ? F : 0;
-    int Fcl = Fc <= NK_LDS_FACES ? Fc : 0;
-    size_t nd = (size_t)S + 3 * S + NK_NREP * S + NK_NREP * 3 * S + 4 * R + (size_t)Fl * NK_FACE_DOUBLES;
-    size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) + (size_t)Fl * 4 + (size_t)(NK_NREP * S + R + 1) * 4;
-    return (bytes + 15) & ~(size_t)15;
-}
-
-// Cooperative fill of the read-only tables and zeroing of the bins; ends with a barrier.
-__device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem, NkLds &L) {
-    const int S = d.S, R = d.R;
-    const int Fl = d.F <= NK_LDS_FACES ? d.F : 0;
-    const int Fcl = d.Fc <= NK_LDS_FACES ? d.Fc : 0;
-    double *p = (double *)smem;
-    L.Tsv = p; p += S;
-    L.cen = p; p += 3 * S;
-    L.bins.E = p; p += NK_NREP * S;
-    L.bins.flux = p; p += NK_NREP * 3 * S;
-    L.bins.resb = p; p += 4 * R;
-    double *faces = p; p += (size_t)Fl * NK_FACE_DOUBLES;
-    NkFacet *facets = (NkFacet *)p;
-    int32_t *ff = (int32_t *)(facets + Fcl);
-    unsigned int *u = (unsigned int *)(ff + Fl);
-    L.bins.N = u; u += NK_NREP * S;
-    L.bins.nleave = u; u += R;
-    L.bins.misc = u;
-    const int t = threadIdx.x;
-    for (int i = t; i < S; i += NK_WG) L.Tsv[i] = d.T_sv[i];
-    for (int i = t; i < 3 * S; i += NK_WG) L.cen[i] = d.centers[i];
-    for (int i = t; i < NK_NREP * S; i += NK_WG) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
-    for (int i = t; i < NK_NREP * 3 * S; i += NK_WG) L.bins.flux[i] = 0.0;
-    for (int i = t; i < 4 * R; i += NK_WG) L.bins.resb[i] = 0.0;
-    for (int i = t; i < R; i += NK_WG) L.bins.nleave[i] = 0u;
-    if (t == 0) L.bins.misc[0] = 0u;
-    for (int i = t; i < Fl * NK_FACE_DOUBLES; i += NK_WG) faces[i] = d.faces[i];
-    for (int i = t; i < Fl; i += NK_WG) ff[i] = d.face_facet[i];
-    {
-        const int nw = Fcl * (int)(sizeof(NkFacet) / 4);
-        const int32_t *src = (const int32_t *)d.facets;
-        int32_t *dst = (int32_t *)facets;
-        for (int i = t; i < nw; i += NK_WG) dst[i] = src[i];
-    }
-    L.faces = Fl ? faces : d.faces;
-    L.face_facet = Fl ? ff : d.face_facet;
-    L.facets = Fcl ? facets : d.facets;
-    __syncthreads();
-}
-
-// Row layout: E[S] N[S] flux[3S] nleave[R] resE[R] resF[3R] emitted[1]
-__device__ __forceinline__ void nk_lds_flush(const NkDev &d, const NkLds &L, int64_t row) {
-    __syncthreads();
-    const int S = d.S, R = d.R;
-    double *out = d.partials + row * d.NB;
-    for (int b = threadIdx.x; b < d.NB; b += NK_WG) {
-        double v = 0.0;
-        if (b < S) { for (int r = 0; r < NK_NREP; ++r) v += L.bins.E[r * S + b]; }
-        else if (b < 2 * S) { unsigned int c = 0; for (int r = 0; r < NK_NREP; ++r) c += L.bins.N[r * S + (b - S)]; v = (double)c; }
-        else if (b < 5 * S) { int k = b - 2 * S; for (int r = 0; r < NK_NREP; ++r) v += L.bins.flux[r * 3 * S + k]; }
-        else if (b < 5 * S + R) v = (double)L.bins.nleave[b - 5 * S];
-        else if (b < 5 * S + 2 * R) v = L.bins.resb[4 * (b - 5 * S - R)];
-        else if (b < 5 * S + 5 * R) { int k = b - 5 * S - 2 * R; v = L.bins.resb[4 * (k / 3) + 1 + (k % 3)]; }
-        else v = (double)L.bins.misc[0];
-        out[b] = v;
-    }
-}
-
-// ========================================================================================= kernels
-// Deferred lifetime_scattering (Population.py:1701-1710) for one particle.
-__device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, double x, double y, double z, double occ,
-                                           double omega, int mode) {
-    double T = nk_interp_T(d, L.cen, L.Tsv, x, y, z, -1);
-    double tau = nk_lifetime(d, T, mode);
-    double n0 = nk_occupation(d, T, omega);
-    return (tau > 0.0) ? n0 + (occ - n0) * exp(-d.dt / tau) : n0;
-}
-
-__global__ __launch_bounds__(NK_WG) void k_step(NkDev d, uint32_t step, int do_relax, int do_flux) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    NkLds L;
-    nk_lds_setup(d, smem, L);
-    const int64_t n = *d.n_slots;
-    const int rep = threadIdx.x & (NK_NREP - 1);
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode0 = d.mode[i];
-        if (mode0 < 0) continue;                                  // dead slot (absorbed, not yet reused)
-        NkParticle p;
-        p.x = d.x[i]; p.y = d.y[i]; p.z = d.z[i]; p.occ = d.occ[i]; p.nts = d.nts[i];
-        p.mode = mode0; p.facet = d.facet[i]; p.alive = true;
-        const double4 rec = d.modetab[mode0];
-        p.omega = rec.x; p.vx = rec.y; p.vy = rec.z; p.vz = rec.w;
-        if (do_relax) p.occ = nk_relax(d, L, p.x, p.y, p.z, p.occ, p.omega, p.mode);
-        p.x += p.vx * d.dt; p.y += p.vy * d.dt; p.z += p.vz * d.dt;                 // drift, Population.py:793
-        p.nts -= 1.0;                                                               // :795
-        const bool had_event = p.nts < 0.0;
-        if (had_event) nk_events(d, L.faces, L.face_facet, L.facets, L.cen, L.Tsv, L.bins, p, d.pid[i], step);
-        if (p.alive) {
-            nk_tally_one(d, L.cen, L.Tsv, L.bins, p, do_flux != 0, rep);
-            d.x[i] = p.x; d.y[i] = p.y; d.z[i] = p.z; d.nts[i] = p.nts;
-            if (do_relax || had_event) d.occ[i] = p.occ;
-            if (had_event) { d.mode[i] = p.mode; d.facet[i] = p.facet; }
-        } else {
-            d.mode[i] = -1;
-            int k = atomicAdd(d.free_top, 1);
-            d.free_list[k] = (int32_t)i;
-        }
-    }
-    nk_lds_flush(d, L, blockIdx.x);
-}
-
-// Reservoir emission: one lane per (reservoir, mode) table entry.
-// fill_reservoirs 'constant' (Population.py:358-406) / 'fixed_rate' (:408-455), Mesh.sample_surface (Mesh.py:923-951),
-// add_reservoir_particles (Population.py:525-552), then the shared event loop and tally.
-__global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step, int do_flux, int row0) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    NkLds L;
-    nk_lds_setup(d, smem, L);
-    const int64_t RM = (int64_t)d.R * d.M;
-    const int64_t rm = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
-    const int rep = threadIdx.x & (NK_NREP - 1);
-    const int lane = threadIdx.x & 63;
-    const int ft0 = *d.free_top;
-    const int64_t ns0 = *d.n_slots;
-    int c = 0, c_mine = 0;
-    double prob = 0.0, cnt = 0.0;
-    if (rm < RM) {
-        prob = d.enter_prob[rm];
-        double fixed = floor(prob);
-        int mask;
-        if (d.res_gen == 0) {
-            double cv = d.res_counter[rm] + (prob - fixed);
-            mask = cv >= 1.0;
-            cv -= (double)mask;
-            d.res_counter[rm] = cv;
-            cnt = cv;
-        } else {
-            double d0, d1;
-            nk_uniform2_dev(d.seed, (uint64_t)rm | 0xFFFFFFFF00000000ull, step, NK_TAG_DICE, d0, d1);
-            mask = d0 <= (prob - fixed);
-            cnt = d0;
-        }
-        c = (int)fixed + mask;
-        if (d.nranks == 1) c_mine = c;
-        else for (int level = c; level >= 1; --level) c_mine += (((rm + level + (int64_t)step) % d.nranks) == d.rank);
-    }
-    // wave-aggregated slot allocation: inclusive scan over the 64 lanes, one atomic per wave
-    int incl = c_mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    int total = __shfl(incl, 63, 64);
-    int base = 0;
-    if (lane == 63 && total > 0) base = atomicAdd(d.alloc_count, total);
-    base = __shfl(base, 63, 64);
-    int g = base + incl - c_mine;
-    if (c_mine > 0) {
-        atomicAdd(&L.bins.misc[0], (unsigned int)c_mine);
-        const int r = (int)(rm / d.M), m = (int)(rm - (int64_t)r * d.M);
-        const int facet = d.res_facet[r];
-        const int f0 = d.facet_face_off[facet], nf = d.facet_face_off[facet + 1] - f0;
-        const double4 rec = d.modetab[m];
-        const double Tres = d.res_T[r];
-        const double occ0 = nk_occupation(d, Tres, rec.x);                       // Population.py:506
-        for (int level = c; level >= 1; --level) {
-            if (d.nranks > 1 && (((rm + level + (int64_t)step) % d.nranks) != d.rank)) continue;
-            const int gi = g++;
-            int64_t slot = gi < ft0 ? (int64_t)d.free_list[ft0 - 1 - gi] : ns0 + (gi - ft0);
-            if (slot >= d.cap) { *d.overflow = 1; continue; }
-            const uint64_t pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level;
-            double uf, us, ur, ut;
-            nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
-            nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
-            const double dt_in = (level == 1) ? d.dt * (1.0 - (cnt / prob))              // :391 / :440
-                                              : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);  // :394
-            int a = nk_ss_right(d.facet_face_cdf + f0, nf, uf);                          // np.random.choice, Mesh.py:937
-            a = a > nf - 1 ? nf - 1 : a;
-            const double *vx = d.face_verts + 9 * (int64_t)d.facet_face_idx[f0 + a];
-            const double sq = sqrt(us);
-            const double a0 = 1.0 - sq, a1 = (1.0 - ur) * sq, a2 = ur * sq;              // Mesh.py:945-947
-            NkParticle p;
-            const double x0 = a0 * vx[0] + a1 * vx[3] + a2 * vx[6];
-            const double y0 = a0 * vx[1] + a1 * vx[4] + a2 * vx[7];
-            const double z0 = a0 * vx[2] + a1 * vx[5] + a2 * vx[8];
-            p.omega = rec.x; p.vx = rec.y; p.vy = rec.z; p.vz = rec.w;
-            p.mode = m; p.occ = occ0; p.alive = true;
-            double tc; int fcn;
-            nk_find_boundary(L.faces, L.face_facet, d.F, d.tol, x0, y0, z0, p.vx, p.vy, p.vz, tc, fcn);
-            p.nts = tc / d.dt - dt_in / d.dt;                                            // :535
-            p.x = x0 + p.vx * dt_in; p.y = y0 + p.vy * dt_in; p.z = z0 + p.vz * dt_in;   // :536
-            p.facet = fcn;
-            if (p.nts < 0.0) nk_events(d, L.faces, L.face_facet, L.facets, L.cen, L.Tsv, L.bins, p, pid, step);
-            if (p.alive) {
-                nk_tally_one(d, L.cen, L.Tsv, L.bins, p, do_flux != 0, rep);
-                d.x[slot] = p.x; d.y[slot] = p.y; d.z[slot] = p.z; d.occ[slot] = p.occ; d.nts[slot] = p.nts;
-                d.mode[slot] = p.mode; d.facet[slot] = p.facet; d.pid[slot] = pid;
-            } else {
-                // absorbed inside its entry step: the slot is already allocated, so park it at the tail of free_list;
-                // k_update moves parked slots onto the free stack (the stack itself is being popped by this kernel)
-                d.mode[slot] = -1;
-                d.pid[slot] = pid;
-                int q = atomicAdd(d.alloc_count + 1, 1);
-                d.free_list[d.cap - 1 - q] = (int32_t)slot;
-            }
-        }
-    }
-    nk_lds_flush(d, L, row0 + blockIdx.x);
-}
-
-// Column sums of the tally rows, fixed order -> bitwise reproducible for a given grid.
-__global__ __launch_bounds__(NK_WG) void k_reduce(const double *partials, int rows, int NB, double *acc) {
-    __shared__ double sh[NK_WG];
-    const int b = blockIdx.x;
-    double v = 0.0;
-    for (int r = threadIdx.x; r < rows; r += NK_WG) v += partials[(int64_t)r * NB + b];
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int o = NK_WG / 2; o > 0; o >>= 1) {
-        if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) acc[b] = sh[0];
-}
-
-// Normalise, invert E(T), publish the new subvolume temperatures, bookkeeping, history row.
-// calculate_energy (Population.py:719-728) + refresh_temperatures (:692).
-// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, n_slots, free_top, overflow
-__global__ void k_update(NkDev d, const double *acc, double *hist_row, int do_flux) {
-    const int t = threadIdx.x;
-    const int S = d.S, NB = d.NB;
-    double Tnew = 0.0;
-    if (t < S) {
-        double Eraw = acc[t], Ns = acc[S + t];
-        double norm;
-        if (d.norm_fixed) norm = d.active_modes / (d.particle_density * d.sv_volume[t]);
-        else { norm = d.active_modes / Ns; if (isnan(norm)) norm = 0.0; }
-        double E = Eraw * norm / d.QV;
-        double ref = nk_E_of_T(d, d.T_ref_local ? d.T_sv[t] : d.T_ref);
-        E += ref;
-        Tnew = nk_T_of_E(d, E);
-        hist_row[NB + t] = Tnew;
-        hist_row[NB + S + t] = E;
-    }
-    for (int b = t; b < NB; b += blockDim.x) hist_row[b] = acc[b];
-    __syncthreads();
-    if (t < S) d.T_sv[t] = Tnew;
-    if (t == 0) {
-        int ft = *d.free_top, em = *d.alloc_count, dead = d.alloc_count[1];
-        int64_t ns = *d.n_slots;
-        if (em >= ft) { ns += em - ft; ft = 0; } else ft -= em;
-        if (ns > d.cap) ns = d.cap;
-        // slots that died inside the emission kernel were parked at the tail of free_list; move them onto the stack
-        for (int q = 0; q < dead; ++q) d.free_list[ft++] = d.free_list[d.cap - 1 - q];
-        *d.free_top = ft; *d.n_slots = ns; d.alloc_count[0] = 0; d.alloc_count[1] = 0;
-        hist_row[NB + 2 * S + 0] = (double)do_flux;
-        hist_row[NB + 2 * S + 1] = (double)ns;
-        hist_row[NB + 2 * S + 2] = (double)ft;
-        hist_row[NB + 2 * S + 3] = (double)*d.overflow;
-    }
-}
-
-// Stand-alone lifetime_scattering (flushes the deferred relaxation).
-__global__ __launch_bounds__(NK_WG) void k_relax(NkDev d) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    NkLds L;
-    nk_lds_setup(d, smem, L);
-    const int64_t n = *d.n_slots;
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode = d.mode[i];
-        if (mode < 0) continue;
-        d.occ[i] = nk_relax(d, L, d.x[i], d.y[i], d.z[i], d.occ[i], d.modetab[mode].x, mode);
-    }
-}
-
-// timesteps_to_boundary for every particle (Population.py:310-314)
-__global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    NkLds L;
-    nk_lds_setup(d, smem, L);
-    const int64_t n = *d.n_slots;
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode = d.mode[i];
-        if (mode < 0) continue;
-        const double4 rec = d.modetab[mode];
-        double tc; int fc;
-        nk_find_boundary(L.faces, L.face_facet, d.F, d.tol, d.x[i], d.y[i], d.z[i], rec.y, rec.z, rec.w, tc, fc);
-        d.nts[i] = tc / d.dt;
-        d.facet[i] = fc;
-    }
-}
-
-// contains_check (Population.py:1712-1722) + Mesh.sample_volume (Mesh.py:890-904)
-__global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    NkLds L;
-    nk_lds_setup(d, smem, L);
-    const int64_t n = *d.n_slots;
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode = d.mode[i];
-        if (mode < 0) continue;
-        double x = d.x[i], y = d.y[i], z = d.z[i];
-        bool out = x < d.bbox[0] - 1e-10 || y < d.bbox[1] - 1e-10 || z < d.bbox[2] - 1e-10 || x > d.bbox[3] + 1e-10 ||
-                   y > d.bbox[4] + 1e-10 || z > d.bbox[5] + 1e-10;
-        if (!out) continue;
-        const uint64_t pid = d.pid[i];
-        double u[6];
-        nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 0, u[0], u[1]);
-        nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 1, u[2], u[3]);
-        nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 2, u[4], u[5]);
-        int s = nk_ss_right(d.simplex_cdf, d.nS, u[0]);
-        s = s > d.nS - 1 ? d.nS - 1 : s;
-        double a[4], asum = 0.0;
-        for (int k = 0; k < 4; ++k) { a[k] = -log(u[1 + k]); asum += a[k]; }
-        const double *sp = d.simplex_pts + 12 * (int64_t)s;
-        x = y = z = 0.0;
-        for (int k = 0; k < 4; ++k) { double w = a[k] / asum; x += w * sp[3 * k]; y += w * sp[3 * k + 1]; z += w * sp[3 * k + 2]; }
-        const double4 rec = d.modetab[mode];
-        double tc; int fc;
-        nk_find_boundary(L.faces, L.face_facet, d.F, d.tol, x, y, z, rec.y, rec.z, rec.w, tc, fc);
-        d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = tc / d.dt; d.facet[i] = fc;
-    }
-}
-
-// {omega, vx, vy, vz} records for one-gather-per-particle access
-__global__ void k_build_modetab(const double *omega, const double *vg, int M, double4 *out) {
-    int m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < M) out[m] = make_double4(omega[m], vg[3 * m], vg[3 * m + 1], vg[3 * m + 2]);
-}
-
-// ---- parity taps: the reference's primitives evaluated on the device
-__global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n, const double *x, const double *v,
-                                                             double *xc, double *tc, int32_t *fc) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    NkLds L;
-    nk_lds_setup(d, smem, L);
-    int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
-    if (i >= n) return;
-    double t; int f;
-    nk_find_boundary(L.faces, L.face_facet, d.F, d.tol, x[3 * i], x[3 * i + 1], x[3 * i + 2], v[3 * i], v[3 * i + 1],
-                     v[3 * i + 2], t, f);
-    tc[i] = t; fc[i] = f;
-    for (int k = 0; k < 3; ++k) xc[3 * i + k] = x[3 * i + k] + t * v[3 * i + k];
-}
-__global__ __launch_bounds__(NK_WG) void k_tap_classify(NkDev d, int64_t n, const double *x, int32_t *id) {
-    int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
-    if (i < n) id[i] = nk_classify(d, d.centers, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
-}
-__global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, int what, int64_t n, const double *a, const int32_t *mode,
-                                                    double *out) {
-    int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
-    if (i >= n) return;
-    switch (what) {
-        case 0: out[i] = nk_occupation(d, a[i], d.modetab[mode[i]].x); break;
-        case 1: out[i] = nk_lifetime(d, a[i], mode[i]); break;
-        case 2: out[i] = nk_T_of_E(d, a[i]); break;
-        case 3: out[i] = nk_E_of_T(d, a[i]); break;
-        default: out[i] = nk_interp_T(d, d.centers, d.T_sv, a[3 * i], a[3 * i + 1], a[3 * i + 2], -1); break;
-    }
-}
-__global__ __launch_bounds__(NK_WG) void k_tap_reflect(NkDev d, int64_t n, const int32_t *facet, const int32_t *mode_in,
-                                                       const double *col, const double *n_in, const double *om_in,
-                                                       const double *r_spec, const double *r_deg, const double *r_diff,
-                                                       int32_t *mode_out, double *n_out, double *om_out) {
-    int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
-    if (i >= n) return;
-    int mo; double no, oo;
-    nk_reflect(d, d.centers, d.T_sv, d.facets[facet[i]].rough, mode_in[i], col[3 * i], col[3 * i + 1], col[3 * i + 2],
-               n_in[i], om_in[i], r_spec[i], r_deg ? r_deg[i] : 0.0, r_diff[i], mo, no, oo);
-    mode_out[i] = mo; n_out[i] = no; om_out[i] = oo;
-}
-__global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *out) {
-    double a, b;
-    nk_uniform2_dev(seed, pid, step, tag, a, b);
-    out[0] = a; out[1] = b;
-}
-
-// ============================================================================================ host
 struct NkRccl {      // symbols resolved lazily with dlopen: a single-GPU run never loads librccl
     void *lib = nullptr;
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
@@ -431,13 +29,13 @@ struct nk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    NkDev d;                       // device view (pointers into `allocs`)
+    NkDev d;                       // device view (pointers into `allocs` / `pallocs`)
     std::vector<void *> allocs;    // everything hipMalloc'ed except the particle arrays
     std::vector<void *> pallocs;   // particle arrays (re-allocated by nk_reserve)
     bool have_material = false, have_mesh = false, have_sv = false, have_params = false;
     int64_t step = 0;
     bool pending_relax = false;
-    int grid_step = 0, rows = 0;
+    int g_step = 0, g_spawn = 0, g_events = 0;   // grids of the three tallying kernels = rows of `partials`
     double *acc = nullptr;         // [NB]
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -447,6 +45,9 @@ struct nk_ctx {
     ncclComm_t comm = nullptr;
     int num_cu = 256;
     std::vector<NkFacet> host_facets;   // host mirror of d.facets (patched by nk_set_reservoirs / nk_set_rough)
+    const double *d_omega = nullptr, *d_vg = nullptr;   // kept to rebuild the packed mode records
+    std::vector<double> h_Tgrid;
+    double T_lo = 0.0, T_hi = 0.0;      // range of the subvolume temperatures last seen by the host
 };
 
 #define NK_HIP(call)                                                                                   \
@@ -475,6 +76,37 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 }
 #define NK_UP(src, n, dst)                                                                             \
     do { int rc_ = nk_upload(ctx, src, n, dst); if (rc_) return rc_; } while (0)
+
+static inline size_t nk_lds(const nk_ctx *ctx, bool geom) {
+    const NkDev &d = ctx->d;
+    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, geom);
+}
+static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
+
+// Choose the four lifetime rows packed into the mode records so that they bracket [T_lo, T_hi]; rebuild on change.
+static int nk_update_tau_window(nk_ctx *ctx, bool force) {
+    NkDev &d = ctx->d;
+    if (!ctx->have_material) return NK_OK;
+    const std::vector<double> &g = ctx->h_Tgrid;
+    int i = (int)(std::lower_bound(g.begin(), g.end(), ctx->T_lo) - g.begin()) - 1;   // bracket of T_lo
+    int row0 = i - 1;
+    if (row0 > d.NT - NK_TAU_ROWS) row0 = d.NT - NK_TAU_ROWS;
+    if (row0 < 0) row0 = 0;
+    const bool covered = d.tau_row0 >= 0 && ctx->T_lo >= g[d.tau_row0] &&
+                         ctx->T_hi <= g[std::min(d.tau_row0 + NK_TAU_ROWS - 1, d.NT - 1)];
+    if (!force && covered) return NK_OK;
+    k_build_modetab<<<(d.M + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_omega, ctx->d_vg, d.tau, d.M, d.NT, row0,
+                                                                  (NkMode *)d.modetab);
+    NK_HIP(hipGetLastError());
+    d.tau_row0 = row0;
+    return NK_OK;
+}
+
+static void nk_track_T(nk_ctx *ctx, const double *T, int S) {
+    double lo = T[0], hi = T[0];
+    for (int i = 1; i < S; ++i) { lo = std::min(lo, T[i]); hi = std::max(hi, T[i]); }
+    ctx->T_lo = lo; ctx->T_hi = hi;
+}
 
 extern "C" {
 
@@ -514,21 +146,28 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.seed = seed;
     ctx->d.rank = 0;
     ctx->d.nranks = 1;
+    ctx->d.tau_row0 = -1;
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
-    // bookkeeping words
-    {
-        int rc;
-        const int64_t *p64; const int32_t *p32;
-        if ((rc = nk_upload<int64_t>(ctx, nullptr, 1, &p64))) { g_create_error = ctx->err; delete ctx; return rc; }
-        ctx->d.n_slots = (int64_t *)p64;
-        if ((rc = nk_upload<int32_t>(ctx, nullptr, 1, &p32))) { g_create_error = ctx->err; delete ctx; return rc; }
-        ctx->d.free_top = (int32_t *)p32;
-        if ((rc = nk_upload<int32_t>(ctx, nullptr, 2, &p32))) { g_create_error = ctx->err; delete ctx; return rc; }
-        ctx->d.alloc_count = (int32_t *)p32;
-        if ((rc = nk_upload<int32_t>(ctx, nullptr, 1, &p32))) { g_create_error = ctx->err; delete ctx; return rc; }
-        ctx->d.overflow = (int32_t *)p32;
+    // bookkeeping words: n_slots, fl_head, fl_tail, fl_avail (64-bit); evq_count, alloc_count, overflow (32-bit)
+    const int64_t *p64 = nullptr;
+    const int32_t *p32 = nullptr;
+    int rc;
+    if ((rc = nk_upload<int64_t>(ctx, nullptr, 4, &p64)) ||
+        (rc = nk_upload<int32_t>(ctx, nullptr, NK_EVQ_SHARDS * NK_EVQ_PAD + 4, &p32))) {
+        g_create_error = ctx->err;
+        delete ctx;
+        return rc;
     }
+    int64_t *w = (int64_t *)p64;
+    ctx->d.n_slots = w;
+    ctx->d.fl_head = (unsigned long long *)(w + 1);
+    ctx->d.fl_tail = (unsigned long long *)(w + 2);
+    ctx->d.fl_avail = w + 3;
+    int32_t *v = (int32_t *)p32;
+    ctx->d.evq_count = v;
+    ctx->d.alloc_count = v + NK_EVQ_SHARDS * NK_EVQ_PAD;
+    ctx->d.overflow = v + NK_EVQ_SHARDS * NK_EVQ_PAD + 1;
     *out = ctx;
     return NK_OK;
 }
@@ -552,23 +191,23 @@ int nk_set_material(nk_ctx *ctx, const nk_material *m) {
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     d.Q = m->Q; d.J = m->J; d.NT = m->NT; d.M = m->Q * m->J;
-    const double *om, *vg;
-    NK_UP(m->omega, (size_t)d.M, &om);
-    NK_UP(m->group_vel, (size_t)d.M * 3, &vg);
-    const double4 *mt;
-    NK_UP((const double4 *)nullptr, (size_t)d.M, &mt);
-    k_build_modetab<<<(d.M + 255) / 256, 256, 0, ctx->stream>>>(om, vg, d.M, (double4 *)mt);
-    NK_HIP(hipGetLastError());
-    d.modetab = mt;
+    for (int i = 1; i < m->NT; ++i) NK_ARG(m->T_grid[i] > m->T_grid[i - 1], "nk_set_material: T_grid must ascend");
+    NK_UP(m->omega, (size_t)d.M, &ctx->d_omega);
+    NK_UP(m->group_vel, (size_t)d.M * 3, &ctx->d_vg);
+    NK_UP((const NkMode *)nullptr, (size_t)d.M, &d.modetab);
     NK_UP(m->lifetime, (size_t)d.NT * d.M, &d.tau);
     NK_UP(m->T_grid, (size_t)d.NT, &d.Tgrid);
+    ctx->h_Tgrid.assign(m->T_grid, m->T_grid + m->NT);
     d.nE = m->nE;
     NK_UP(m->T_array, (size_t)d.nE, &d.Tarr);
     NK_UP(m->energy_array, (size_t)d.nE, &d.Earr);
     d.Tfill_lo = m->T_fill_lo; d.Tfill_hi = m->T_fill_hi;
     d.hbar = m->hbar; d.kb = m->kb; d.QV = m->QV; d.active_modes = (double)m->active_modes;
-    NK_HIP(hipStreamSynchronize(ctx->stream));
     ctx->have_material = true;
+    ctx->T_lo = ctx->T_hi = m->T_grid[0];
+    int rc = nk_update_tau_window(ctx, true);
+    if (rc) return rc;
+    NK_HIP(hipStreamSynchronize(ctx->stream));
     return NK_OK;
 }
 
@@ -579,24 +218,46 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
     NkDev &d = ctx->d;
     d.F = m->F; d.Fc = m->Fc; d.tol = m->tol;
     for (int i = 0; i < 6; ++i) d.bbox[i] = m->bbox[i];
-    // face records: n k lo hi o iu iw pad
-    std::vector<double> rec((size_t)m->F * NK_FACE_DOUBLES, 0.0);
+    // distinct planes (bitwise-equal normal and k), in order of their first face; faces grouped by plane
+    std::vector<std::vector<int>> members;
     for (int f = 0; f < m->F; ++f) {
-        double *p = &rec[(size_t)f * NK_FACE_DOUBLES];
-        for (int k = 0; k < 3; ++k) {
-            p[k] = m->normals[3 * f + k]; p[4 + k] = m->bounds_lo[3 * f + k]; p[7 + k] = m->bounds_hi[3 * f + k];
-            p[10 + k] = m->origins[3 * f + k];
+        int found = -1;
+        for (size_t pl = 0; pl < members.size() && found < 0; ++pl) {
+            int g = members[pl][0];
+            if (m->normals[3 * g] == m->normals[3 * f] && m->normals[3 * g + 1] == m->normals[3 * f + 1] &&
+                m->normals[3 * g + 2] == m->normals[3 * f + 2] && m->k[g] == m->k[f])
+                found = (int)pl;
         }
-        p[3] = m->k[f];
-        const double *A = m->basis + 9 * f;      // A[d][b]: columns are (e1, e2, n)
-        double a00 = A[0], a01 = A[1], a02 = A[2], a10 = A[3], a11 = A[4], a12 = A[5], a20 = A[6], a21 = A[7], a22 = A[8];
-        double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
-        NK_ARG(det != 0.0 && isfinite(det), "nk_set_mesh: degenerate face");
-        p[13] = (a11 * a22 - a12 * a21) / det; p[14] = (a02 * a21 - a01 * a22) / det; p[15] = (a01 * a12 - a02 * a11) / det;
-        p[16] = (a12 * a20 - a10 * a22) / det; p[17] = (a00 * a22 - a02 * a20) / det; p[18] = (a02 * a10 - a00 * a12) / det;
+        if (found < 0) { members.push_back(std::vector<int>()); found = (int)members.size() - 1; }
+        members[found].push_back(f);
     }
-    NK_UP(rec.data(), rec.size(), &d.faces);
-    NK_UP(m->face_facet, (size_t)m->F, &d.face_facet);
+    d.NP = (int)members.size();
+    std::vector<double> planes((size_t)d.NP * NK_PLANE_DOUBLES, 0.0), faces((size_t)m->F * NK_FACE_DOUBLES, 0.0);
+    int pos = 0;
+    for (int pl = 0; pl < d.NP; ++pl) {
+        double *p = &planes[(size_t)pl * NK_PLANE_DOUBLES];
+        int g = members[pl][0];
+        p[0] = m->normals[3 * g]; p[1] = m->normals[3 * g + 1]; p[2] = m->normals[3 * g + 2]; p[3] = m->k[g];
+        int32_t rng[2] = {pos, pos + (int)members[pl].size()};
+        memcpy(p + 4, rng, 8);
+        for (int f : members[pl]) {
+            double *q = &faces[(size_t)pos * NK_FACE_DOUBLES];
+            for (int k = 0; k < 3; ++k) {
+                q[k] = m->bounds_lo[3 * f + k]; q[3 + k] = m->bounds_hi[3 * f + k]; q[6 + k] = m->origins[3 * f + k];
+            }
+            const double *A = m->basis + 9 * f;      // A[d][b]: columns are (e1, e2, n)
+            double a00 = A[0], a01 = A[1], a02 = A[2], a10 = A[3], a11 = A[4], a12 = A[5], a20 = A[6], a21 = A[7], a22 = A[8];
+            double det = a00 * (a11 * a22 - a12 * a21) - a01 * (a10 * a22 - a12 * a20) + a02 * (a10 * a21 - a11 * a20);
+            NK_ARG(det != 0.0 && isfinite(det), "nk_set_mesh: degenerate face");
+            q[9] = (a11 * a22 - a12 * a21) / det; q[10] = (a02 * a21 - a01 * a22) / det; q[11] = (a01 * a12 - a02 * a11) / det;
+            q[12] = (a12 * a20 - a10 * a22) / det; q[13] = (a00 * a22 - a02 * a20) / det; q[14] = (a02 * a10 - a00 * a12) / det;
+            int32_t id[2] = {f, m->face_facet[f]};
+            memcpy(q + 15, id, 8);
+            ++pos;
+        }
+    }
+    NK_UP(planes.data(), planes.size(), &d.planes);
+    NK_UP(faces.data(), faces.size(), &d.faces);
     NK_UP(m->vertices, (size_t)m->F * 9, &d.face_verts);
     NK_UP(m->facet_face_off, (size_t)m->Fc + 1, &d.facet_face_off);
     const int nidx = m->facet_face_off[m->Fc];
@@ -646,11 +307,11 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     d.NB = 5 * d.S + 5 * d.R + 1;
     if (ctx->acc) { hipFree(ctx->acc); ctx->acc = nullptr; }
     NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)d.NB * sizeof(double)));
-    ctx->grid_step = ctx->num_cu * 8;
-    int emit_blocks = (int)(((int64_t)d.R * d.M + NK_WG - 1) / NK_WG);
-    ctx->rows = ctx->grid_step + emit_blocks;
+    ctx->g_step = ctx->num_cu * 8;
+    ctx->g_spawn = ctx->num_cu * 4;
+    ctx->g_events = ((ctx->num_cu * 8 + NK_EVQ_SHARDS - 1) / NK_EVQ_SHARDS) * NK_EVQ_SHARDS;   // whole shards
     const double *p;
-    NK_UP((const double *)nullptr, (size_t)ctx->rows * d.NB, &p);
+    NK_UP((const double *)nullptr, (size_t)(ctx->g_step + ctx->g_spawn + ctx->g_events) * d.NB, &p);
     d.partials = (double *)p;
     return NK_OK;
 }
@@ -676,6 +337,9 @@ int nk_set_subvolumes(nk_ctx *ctx, const nk_subvols *s, const double *T_sv_init)
         d.sv_lo = c0 - 0.5 * Lx; d.sv_invL = 1.0 / Lx;
     } else { d.sv_lo = 0.0; d.sv_invL = 0.0; }
     ctx->have_sv = true;
+    nk_track_T(ctx, T_sv_init, s->S);
+    int rc = nk_update_tau_window(ctx, false);
+    if (rc) return rc;
     return nk_alloc_tally(ctx);
 }
 
@@ -694,10 +358,14 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
         const double *c;
         NK_UP(r->counter, (size_t)r->R * d.M, &c);
         d.res_counter = (double *)c;
-        NkFacet *hf = ctx->host_facets.data();
+        NK_UP((const double *)nullptr, (size_t)r->R * d.M, &c);
+        d.res_cval = (double *)c;
+        double pmax = 0.0;
+        for (size_t i = 0; i < (size_t)r->R * d.M; ++i) pmax = std::max(pmax, r->enter_prob[i]);
+        NK_ARG(pmax < 4094.0, "nk_set_reservoirs: more than 4094 particles of one mode per step (id layout)");
         for (int i = 0; i < r->R; ++i) {
             NK_ARG(r->facet[i] >= 0 && r->facet[i] < d.Fc, "nk_set_reservoirs: facet index");
-            hf[r->facet[i]].res = i;
+            ctx->host_facets[r->facet[i]].res = i;
         }
         int rc = nk_patch_facets(ctx);
         if (rc) return rc;
@@ -718,10 +386,9 @@ int nk_set_rough(nk_ctx *ctx, const nk_rough *r) {
         NK_UP(r->spec_map, n, &d.spec_map);
         NK_UP(r->roulette, n, &d.roulette);
         if (r->degen_j2) NK_UP(r->degen_j2, (size_t)d.M, &d.degen_j2); else d.degen_j2 = nullptr;
-        NkFacet *hf = ctx->host_facets.data();
         for (int i = 0; i < r->Fr; ++i) {
             NK_ARG(r->facet[i] >= 0 && r->facet[i] < d.Fc, "nk_set_rough: facet index");
-            hf[r->facet[i]].rough = i;
+            ctx->host_facets[r->facet[i]].rough = i;
         }
         return nk_patch_facets(ctx);
     }
@@ -744,13 +411,13 @@ static int nk_check_ready(nk_ctx *ctx) {
            "engine not configured: need material, mesh, subvolumes and params");
     NkDev &d = ctx->d;
     // every rough / reservoir facet must be backed by its table, otherwise a kernel would index garbage
-    const NkFacet *hf = ctx->host_facets.data();
     for (int f = 0; f < d.Fc; ++f) {
-        NK_ARG(hf[f].bc != 'R' || hf[f].rough >= 0, "a facet has BC 'R' but nk_set_rough did not cover it");
-        NK_ARG(!(hf[f].bc == 'T' || hf[f].bc == 'F') || hf[f].res >= 0, "a facet has BC 'T' but nk_set_reservoirs did not cover it");
+        const NkFacet &hf = ctx->host_facets[f];
+        NK_ARG(hf.bc != 'R' || hf.rough >= 0, "a facet has BC 'R' but nk_set_rough did not cover it");
+        NK_ARG(!(hf.bc == 'T' || hf.bc == 'F') || hf.res >= 0, "a facet has BC 'T' but nk_set_reservoirs did not cover it");
     }
     NK_ARG(d.cap > 0, "no particle storage: call nk_reserve / nk_upload_particles");
-    NK_ARG(nk_lds_bytes(d.S, d.R, d.F, d.Fc) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
+    NK_ARG(nk_lds(ctx, true) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
     return NK_OK;
 }
 
@@ -761,32 +428,38 @@ int nk_reserve(nk_ctx *ctx, int64_t capacity) {
     NkDev &d = ctx->d;
     if (capacity <= d.cap) return NK_OK;
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    int64_t ns = 0;
-    int32_t ft = 0;
-    if (d.cap > 0) {
-        NK_HIP(hipMemcpy(&ns, d.n_slots, 8, hipMemcpyDeviceToHost));
-        NK_HIP(hipMemcpy(&ft, d.free_top, 4, hipMemcpyDeviceToHost));
+    int64_t w[4] = {0, 0, 0, 0};                 // n_slots, head, tail, avail
+    if (d.cap > 0) NK_HIP(hipMemcpy(w, d.n_slots, 32, hipMemcpyDeviceToHost));
+    const int64_t ns = w[0];
+    std::vector<int32_t> ring;
+    if (d.cap > 0 && w[2] > w[1]) {              // linearise the free ring
+        std::vector<int32_t> old((size_t)d.cap);
+        NK_HIP(hipMemcpy(old.data(), d.free_ring, (size_t)d.cap * 4, hipMemcpyDeviceToHost));
+        for (int64_t k = w[1]; k < w[2]; ++k) ring.push_back(old[(size_t)(k % d.cap)]);
     }
     std::vector<void *> old = ctx->pallocs;
     ctx->pallocs.clear();
     NkDev nd = d;
     const double *pd; const int32_t *pi; const uint64_t *pu;
-#define NK_PALLOC(T, field, ptr)                                                                       \
+#define NK_PALLOC(T, field, ptr, copy)                                                                 \
     do { int rc_ = nk_upload<T>(ctx, nullptr, (size_t)capacity, &ptr, true); if (rc_) return rc_;      \
-         if (d.cap > 0 && ns > 0) NK_HIP(hipMemcpy((void *)ptr, d.field, (size_t)ns * sizeof(T), hipMemcpyDeviceToDevice)); \
+         if (copy && d.cap > 0 && ns > 0) NK_HIP(hipMemcpy((void *)ptr, d.field, (size_t)ns * sizeof(T), hipMemcpyDeviceToDevice)); \
          nd.field = (T *)ptr; } while (0)
-    NK_PALLOC(double, x, pd); NK_PALLOC(double, y, pd); NK_PALLOC(double, z, pd);
-    NK_PALLOC(double, occ, pd); NK_PALLOC(double, nts, pd);
-    NK_PALLOC(int32_t, mode, pi); NK_PALLOC(int32_t, facet, pi);
-    NK_PALLOC(uint64_t, pid, pu);
-    {
-        int rc_ = nk_upload<int32_t>(ctx, nullptr, (size_t)capacity, &pi, true);
-        if (rc_) return rc_;
-        if (d.cap > 0 && ft > 0) NK_HIP(hipMemcpy((void *)pi, d.free_list, (size_t)ft * 4, hipMemcpyDeviceToDevice));
-        nd.free_list = (int32_t *)pi;
-    }
+    NK_PALLOC(double, x, pd, true); NK_PALLOC(double, y, pd, true); NK_PALLOC(double, z, pd, true);
+    NK_PALLOC(double, occ, pd, true); NK_PALLOC(double, nts, pd, true);
+    NK_PALLOC(int32_t, mode, pi, true); NK_PALLOC(int32_t, facet, pi, true);
+    NK_PALLOC(uint64_t, pid, pu, true);
+    NK_PALLOC(int32_t, free_ring, pi, false);
+    NK_PALLOC(uint64_t, spawn_list, pu, false);
 #undef NK_PALLOC
     nd.cap = capacity;
+    nd.spawn_cap = capacity;
+    // event queue shards: a shard receives at most the particles swept / spawned by the workgroups of its residue
+    nd.evq_seg = (2 * capacity) / NK_EVQ_SHARDS + 4096;
+    { int rc_ = nk_upload<int32_t>(ctx, nullptr, (size_t)nd.evq_seg * NK_EVQ_SHARDS, &pi, true); if (rc_) return rc_; nd.evq = (int32_t *)pi; }
+    if (!ring.empty()) NK_HIP(hipMemcpy(nd.free_ring, ring.data(), ring.size() * 4, hipMemcpyHostToDevice));
+    w[1] = 0; w[2] = (int64_t)ring.size(); w[3] = std::min<int64_t>(w[3], (int64_t)ring.size());
+    NK_HIP(hipMemcpy(d.n_slots, w, 32, hipMemcpyHostToDevice));
     for (void *p : old) hipFree(p);
     d = nd;
     return NK_OK;
@@ -799,14 +472,14 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     NK_ARG(N == 0 || (x && y && z && mode && occ), "nk_upload_particles: x, y, z, mode, occ are required");
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
+    int64_t zero64[4] = {0, 0, 0, 0};
+    std::vector<int32_t> zero32(NK_EVQ_SHARDS * NK_EVQ_PAD + 4, 0);
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    NK_HIP(hipMemcpy(d.n_slots, zero64, 32, hipMemcpyHostToDevice));       // forget old contents
     if (N > d.cap) {
-        // forget old contents, then grow
-        int64_t zero = 0;
-        if (d.cap > 0) NK_HIP(hipMemcpy(d.n_slots, &zero, 8, hipMemcpyHostToDevice));
         int rc = nk_reserve(ctx, N + N / 2 + 4096);
         if (rc) return rc;
     }
-    NK_HIP(hipStreamSynchronize(ctx->stream));
     size_t n = (size_t)N;
     if (n) {
         NK_HIP(hipMemcpy(d.x, x, n * 8, hipMemcpyHostToDevice));
@@ -823,25 +496,19 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
             NK_HIP(hipMemcpy(d.pid, ids.data(), n * 8, hipMemcpyHostToDevice));
         }
     }
-    int32_t zero32[2] = {0, 0};
-    NK_HIP(hipMemcpy(d.n_slots, &N, 8, hipMemcpyHostToDevice));
-    NK_HIP(hipMemcpy(d.free_top, zero32, 4, hipMemcpyHostToDevice));
-    NK_HIP(hipMemcpy(d.alloc_count, zero32, 8, hipMemcpyHostToDevice));
-    NK_HIP(hipMemcpy(d.overflow, zero32, 4, hipMemcpyHostToDevice));
+    zero64[0] = N;
+    NK_HIP(hipMemcpy(d.n_slots, zero64, 32, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(d.evq_count, zero32.data(), zero32.size() * 4, hipMemcpyHostToDevice));
     ctx->pending_relax = false;
     return NK_OK;
 }
-
-static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
 
 int nk_init_boundaries(nk_ctx *ctx) {
     NK_ARG(ctx, "nk_init_boundaries: NULL context");
     int rc = nk_check_ready(ctx);
     if (rc) return rc;
     NK_HIP(hipSetDevice(ctx->device));
-    NkDev &d = ctx->d;
-    size_t lds = nk_lds_bytes(d.S, d.R, d.F, d.Fc);
-    k_init_boundaries<<<nk_sweep_grid(ctx), NK_WG, lds, ctx->stream>>>(d);
+    k_init_boundaries<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, true), ctx->stream>>>(ctx->d);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
     return NK_OK;
@@ -849,9 +516,7 @@ int nk_init_boundaries(nk_ctx *ctx) {
 
 static int nk_flush_relax(nk_ctx *ctx) {
     if (!ctx->pending_relax) return NK_OK;
-    NkDev &d = ctx->d;
-    size_t lds = nk_lds_bytes(d.S, d.R, d.F, d.Fc);
-    k_relax<<<nk_sweep_grid(ctx), NK_WG, lds, ctx->stream>>>(d);
+    k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(ctx->d);
     NK_HIP(hipGetLastError());
     ctx->pending_relax = false;
     return NK_OK;
@@ -862,6 +527,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     int rc = nk_check_ready(ctx);
     if (rc) return rc;
     NK_HIP(hipSetDevice(ctx->device));
+    if ((rc = nk_update_tau_window(ctx, false))) return rc;
     NkDev &d = ctx->d;
     const int S = d.S, R = d.R, NB = d.NB;
     const int HROW = NB + 2 * S + 4;
@@ -871,10 +537,12 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)nsteps * HROW * sizeof(double)));
         ctx->hist_cap = nsteps;
     }
-    const size_t lds = nk_lds_bytes(S, R, d.F, d.Fc);
-    const int emit_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
+    const size_t lds_s = nk_lds(ctx, false), lds_g = nk_lds(ctx, true);
+    const int count_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
+    const int rows_spawn = R > 0 ? ctx->g_spawn : 0;
+    const int rows = ctx->g_step + rows_spawn + ctx->g_events;
     const int nev = nsteps < 64 ? nsteps : 64;          // per-kernel timing on (up to) the first 64 steps
-    std::vector<hipEvent_t> ev((size_t)nev * 3);
+    std::vector<hipEvent_t> ev((size_t)nev * 4);
     for (auto &e : ev) NK_HIP(hipEventCreate(&e));
     hipEvent_t t0, t1;
     NK_HIP(hipEventCreate(&t0));
@@ -884,16 +552,21 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         const uint32_t step = (uint32_t)ctx->step;
         if (ctx->params.contains_every > 0 && (ctx->step % ctx->params.contains_every) == 0 && d.nS > 0) {
             if ((rc = nk_flush_relax(ctx))) return rc;
-            k_contains<<<nk_sweep_grid(ctx), NK_WG, lds, ctx->stream>>>(d, step);
+            k_contains<<<nk_sweep_grid(ctx), NK_WG, lds_g, ctx->stream>>>(d, step);
         }
         const int fe = ctx->params.flux_every;
         const int do_flux = (fe > 0 && ((ctx->step + 1) % fe) == 0) ? 1 : 0;
-        if (s < nev) NK_HIP(hipEventRecord(ev[3 * s], ctx->stream));
-        k_step<<<ctx->grid_step, NK_WG, lds, ctx->stream>>>(d, step, ctx->pending_relax ? 1 : 0, do_flux);
-        if (s < nev) NK_HIP(hipEventRecord(ev[3 * s + 1], ctx->stream));
-        if (R > 0) k_emit<<<emit_blocks, NK_WG, lds, ctx->stream>>>(d, step, do_flux, ctx->grid_step);
-        if (s < nev) NK_HIP(hipEventRecord(ev[3 * s + 2], ctx->stream));
-        k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d.partials, ctx->grid_step + (R > 0 ? emit_blocks : 0), NB, ctx->acc);
+        if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
+        k_step<<<ctx->g_step, NK_WG, lds_s, ctx->stream>>>(d, ctx->pending_relax ? 1 : 0, do_flux);
+        if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
+        if (R > 0) {
+            k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
+            k_spawn<<<ctx->g_spawn, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, ctx->g_step);
+        }
+        if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
+        k_events<<<ctx->g_events, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, ctx->g_step + rows_spawn);
+        if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
+        k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d.partials, rows, NB, ctx->acc);
         if (ctx->comm) {
             ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB, ncclDouble, ncclSum, ctx->comm, ctx->stream);
             if (nrc != ncclSuccess) { ctx->err = "ncclAllReduce failed"; return NK_ERR_COMM; }
@@ -906,16 +579,18 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0.f;
-    double sk = 0.0, ek = 0.0;
+    double sk = 0.0, ek = 0.0, vk = 0.0;
     for (int s = 0; s < nev; ++s) {
-        NK_HIP(hipEventElapsedTime(&ms, ev[3 * s], ev[3 * s + 1])); sk += ms;
-        NK_HIP(hipEventElapsedTime(&ms, ev[3 * s + 1], ev[3 * s + 2])); ek += ms;
+        NK_HIP(hipEventElapsedTime(&ms, ev[4 * s], ev[4 * s + 1])); sk += ms;
+        NK_HIP(hipEventElapsedTime(&ms, ev[4 * s + 1], ev[4 * s + 2])); ek += ms;
+        NK_HIP(hipEventElapsedTime(&ms, ev[4 * s + 2], ev[4 * s + 3])); vk += ms;
     }
     NK_HIP(hipEventElapsedTime(&ms, t0, t1));
     for (auto &e : ev) hipEventDestroy(e);
     hipEventDestroy(t0); hipEventDestroy(t1);
     ctx->timing.step_kernel_ms = sk / nev;
     ctx->timing.emit_kernel_ms = ek / nev;
+    ctx->timing.events_kernel_ms = vk / nev;
     ctx->timing.total_ms = ms;
     std::vector<double> h((size_t)nsteps * HROW);
     NK_HIP(hipMemcpy(h.data(), ctx->hist, h.size() * sizeof(double), hipMemcpyDeviceToHost));
@@ -938,6 +613,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         if (out->E_sv) memcpy(out->E_sv + (size_t)s * S, row + NB + S, S * 8);
     }
     const double *last = &h[(size_t)(nsteps - 1) * HROW];
+    nk_track_T(ctx, last + NB, S);
     ctx->timing.slots = (int64_t)last[NB + 2 * S + 1];
     double live = 0.0;
     for (int k = 0; k < S; ++k) live += last[S + k];
@@ -1007,6 +683,7 @@ int nk_set_subvol_temperature(nk_ctx *ctx, const double *T_sv) {
     NK_HIP(hipSetDevice(ctx->device));
     NK_HIP(hipStreamSynchronize(ctx->stream));
     NK_HIP(hipMemcpy(ctx->d.T_sv, T_sv, (size_t)ctx->d.S * 8, hipMemcpyHostToDevice));
+    nk_track_T(ctx, T_sv, ctx->d.S);
     return NK_OK;
 }
 int nk_get_step(nk_ctx *ctx, int64_t *step) {
@@ -1074,7 +751,7 @@ int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x, const double *v, d
     NK_DEV_IN(double, dx, x, n * 3); NK_DEV_IN(double, dv, v, n * 3);
     NK_DEV_IN(double, dxc, (double *)nullptr, n * 3); NK_DEV_IN(double, dtc, (double *)nullptr, n);
     NK_DEV_IN(int32_t, dfc, (int32_t *)nullptr, n);
-    k_tap_find_boundary<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, nk_lds_bytes(d.S, d.R, d.F, d.Fc), ctx->stream>>>(d, n, dx, dv, dxc, dtc, dfc);
+    k_tap_find_boundary<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, nk_lds(ctx, true), ctx->stream>>>(d, n, dx, dv, dxc, dtc, dfc);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
     NK_DEV_OUT(double, dxc, xc, n * 3); NK_DEV_OUT(double, dtc, tc, n); NK_DEV_OUT(int32_t, dfc, fc, n);
@@ -1111,9 +788,8 @@ int nk_reflect(nk_ctx *ctx, int64_t n, const int32_t *facet, const int32_t *mode
                const double *r_diff, int32_t *mode_out, double *n_out, double *omega_out) {
     NK_ARG(ctx && ctx->have_material && ctx->have_sv && ctx->have_mesh && ctx->d.Fr > 0 && n > 0, "nk_reflect: engine not configured");
     NK_ARG(facet && mode_in && col_pos && n_in && omega_in && r_spec && r_diff, "nk_reflect: NULL input");
-    const NkFacet *hf = ctx->host_facets.data();
     for (int64_t i = 0; i < n; ++i)
-        NK_ARG(facet[i] >= 0 && facet[i] < ctx->d.Fc && hf[facet[i]].rough >= 0, "nk_reflect: facet is not rough");
+        NK_ARG(facet[i] >= 0 && facet[i] < ctx->d.Fc && ctx->host_facets[facet[i]].rough >= 0, "nk_reflect: facet is not rough");
     NK_HIP(hipSetDevice(ctx->device));
     NK_DEV_IN(int32_t, df, facet, n); NK_DEV_IN(int32_t, dm, mode_in, n); NK_DEV_IN(double, dc, col_pos, n * 3);
     NK_DEV_IN(double, dn, n_in, n); NK_DEV_IN(double, dom, omega_in, n); NK_DEV_IN(double, drs, r_spec, n);

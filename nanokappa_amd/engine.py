@@ -66,7 +66,8 @@ class nk_tally(C.Structure):
 
 
 class nk_timing(C.Structure):
-    _fields_ = [('step_kernel_ms', C.c_double), ('emit_kernel_ms', C.c_double), ('total_ms', C.c_double),
+    _fields_ = [('step_kernel_ms', C.c_double), ('emit_kernel_ms', C.c_double), ('events_kernel_ms', C.c_double),
+                ('total_ms', C.c_double),
                 ('slots', C.c_int64), ('live', C.c_int64)]
 
 
@@ -326,7 +327,8 @@ class Engine(object):
     def timing(self):
         t = nk_timing()
         self._ck(self.L.nk_get_timing(self.h, C.byref(t)), 'nk_get_timing')
-        return dict(step_kernel_ms=t.step_kernel_ms, emit_kernel_ms=t.emit_kernel_ms, total_ms=t.total_ms,
+        return dict(step_kernel_ms=t.step_kernel_ms, emit_kernel_ms=t.emit_kernel_ms, events_kernel_ms=t.events_kernel_ms,
+                    total_ms=t.total_ms,
                     slots=int(t.slots), live=int(t.live))
 
     def comm_init(self, unique_id, rank, nranks):
