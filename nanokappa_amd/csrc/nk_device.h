@@ -47,6 +47,7 @@ struct NkDev {
     int32_t Q, J, NT, M;              // M = Q*J
     const NkMode *modetab;            // [M]
     int32_t tau_row0;                 // first T_grid row held in NkMode::tau
+    double tau_g[NK_TAU_ROWS];        // T_grid[tau_row0 .. tau_row0+3] by value (scalar registers, no loads)
     const double *tau;                // [NT*M] full table (fallback outside the packed window)
     const double *Tgrid;              // [NT]
     int32_t nE;
@@ -113,6 +114,7 @@ struct NkDev {
     int32_t *overflow;                // set when a particle had to be dropped for lack of capacity
     double *partials;                 // [rows][NB] per-workgroup tally rows
     int32_t NB;                       // bins per row = 5*S + 5*R + 1
+    int32_t dbg;                      // developer ablation mask (env NK_DEBUG; 0 in production): see k_step
 };
 
 // Append slot `i` to the event queue shard of this workgroup.
@@ -188,6 +190,17 @@ __device__ __forceinline__ double nk_E_of_T(const NkDev &d, double T) {
 // Out-of-table T gives NaN (the reference raises ValueError there).  `rec` is the particle's mode record; its four
 // packed rows serve the live temperature range, anything else falls back to the full table.
 __device__ __forceinline__ double nk_lifetime(const NkDev &d, const NkMode &rec, double T, int mode) {
+    // Fast path: T strictly inside the packed window (g0, g3].  searchsorted-left - 1 puts T in (g_k, g_k+1] at
+    // interval k, so two compares select it; grid values come from scalar registers, lifetimes from the mode record.
+    if (T > d.tau_g[0] && T <= d.tau_g[3]) {
+        const bool b1 = T > d.tau_g[1], b2 = T > d.tau_g[2];
+        const double glo = b2 ? d.tau_g[2] : (b1 ? d.tau_g[1] : d.tau_g[0]);
+        const double ghi = b2 ? d.tau_g[3] : (b1 ? d.tau_g[2] : d.tau_g[1]);
+        const double t0 = b2 ? rec.tau[2] : (b1 ? rec.tau[1] : rec.tau[0]);
+        const double t1 = b2 ? rec.tau[3] : (b1 ? rec.tau[2] : rec.tau[1]);
+        const double y = (T - glo) / (ghi - glo);
+        return t0 * (1.0 - y) + t1 * y;
+    }
     const int NT = d.NT;
     const double *g = d.Tgrid;
     if (!(T >= g[0]) || !(T <= g[NT - 1])) return __builtin_nan("");

@@ -99,6 +99,8 @@ static int nk_update_tau_window(nk_ctx *ctx, bool force) {
                                                                   (NkMode *)d.modetab);
     NK_HIP(hipGetLastError());
     d.tau_row0 = row0;
+    for (int k = 0; k < NK_TAU_ROWS; ++k) d.tau_g[k] = (row0 + k < d.NT) ? g[row0 + k] : INFINITY;
+    if (d.NT < NK_TAU_ROWS) d.tau_g[0] = INFINITY;     // no packed window: every lookup takes the full-table path
     return NK_OK;
 }
 
@@ -147,6 +149,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.rank = 0;
     ctx->d.nranks = 1;
     ctx->d.tau_row0 = -1;
+    { const char *dbg = getenv("NK_DEBUG"); ctx->d.dbg = dbg ? atoi(dbg) : 0; }
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
     // bookkeeping words: n_slots, fl_head, fl_tail, fl_avail (64-bit); evq_count, alloc_count, overflow (32-bit)

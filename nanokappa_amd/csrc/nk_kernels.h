@@ -122,19 +122,29 @@ __global__ __launch_bounds__(NK_WG) void k_step(NkDev d, int do_relax, int do_fl
     const int64_t n = *d.n_slots;
     const int rep = threadIdx.x & (NK_NREP - 1);
     const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode = d.mode[i];
+    // Software pipeline: the next slot's state is requested before this slot's arithmetic starts, so the HBM round
+    // trip of iteration k+1 overlaps the exp/divide chains of iteration k (the kernel is latency-bound: 86 % of wave
+    // cycles were s_waitcnt stalls without it).
+    int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
+    int modeN = -1;
+    double xN = 0, yN = 0, zN = 0, occN = 0, ntsN = 0;
+    if (i < n) { modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i]; }
+    for (; i < n; i += stride) {
+        const int mode = modeN;
+        double x = xN, y = yN, z = zN, occ = occN, nts = ntsN;
+        NkMode rec = d.modetab[(mode >= 0 && !(d.dbg & 4)) ? mode : 0];   // gather first, prefetch behind it (vmcnt is in-order)
+        if (d.dbg & 4) { rec.omega = 10.0 + (mode & 63); rec.vx = (mode & 7) - 3.5; rec.vy = ((mode >> 3) & 7) - 3.5; rec.vz = ((mode >> 6) & 7) - 3.5; }
+        const int64_t in = i + stride;
+        if (in < n) { modeN = d.mode[in]; xN = d.x[in]; yN = d.y[in]; zN = d.z[in]; occN = d.occ[in]; ntsN = d.nts[in]; }
         if (mode < 0) continue;                                   // dead slot (absorbed, not yet reused)
-        double x = d.x[i], y = d.y[i], z = d.z[i], occ = d.occ[i], nts = d.nts[i];
-        const NkMode rec = d.modetab[mode];
-        if (do_relax) occ = nk_relax(d, L, rec, x, y, z, occ, mode);
+        if (do_relax && !(d.dbg & 16)) occ = nk_relax(d, L, rec, x, y, z, occ, mode);
         x += rec.vx * d.dt; y += rec.vy * d.dt; z += rec.vz * d.dt;                 // drift, Population.py:793
         nts -= 1.0;                                                                 // :795
-        d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts;
+        if (!(d.dbg & 8)) { d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts; }
         if (do_relax) d.occ[i] = occ;
         if (nts < 0.0) {
-            nk_evq_push(d, i);                                    // boundary reached inside this step -> k_events
-        } else {
+            if (!(d.dbg & 2)) nk_evq_push(d, i);                  // boundary reached inside this step -> k_events
+        } else if (!(d.dbg & 1)) {
             nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, rec.omega, rec.vx, rec.vy, rec.vz, do_flux != 0, rep);
         }
     }
@@ -174,9 +184,20 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     const int total = __shfl(incl, 63, 64);
-    int base = 0;
-    if (lane == 63 && total > 0) base = atomicAdd(d.alloc_count, total);
-    base = __shfl(base, 63, 64);
+    // one global atomic per workgroup (a single hot counter serves only ~90 atomics/us)
+    __shared__ int wsum[NK_WG / 64];
+    __shared__ int bbase;
+    const int wave = threadIdx.x >> 6;
+    if (lane == 63) wsum[wave] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int t = 0;
+        for (int w = 0; w < NK_WG / 64; ++w) t += wsum[w];
+        bbase = t > 0 ? atomicAdd(d.alloc_count, t) : 0;
+    }
+    __syncthreads();
+    int base = bbase;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
     int64_t g = (int64_t)base + incl - c_mine;
     for (int level = c; level >= 1 && c_mine > 0; --level) {
         if (d.nranks > 1 && (((rm + level + (int64_t)step) % d.nranks) != d.rank)) continue;
