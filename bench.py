@@ -101,6 +101,8 @@ def main():
     ap.add_argument('--mesh-n', type=int, default=31, help='q-mesh of the synthetic material (31 -> 29791 q-points)')
     ap.add_argument('--box', type=float, default=200.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--calibrate', action='store_true',
+                    help='after the timed region run 3 known-traffic sweeps (k_cal_stream) for PMC calibration')
     a = ap.parse_args()
 
     rank = int(os.environ.get('RANK', '0'))
@@ -155,6 +157,10 @@ def main():
         dist.all_reduce(te, op=dist.ReduceOp.MAX)
         elapsed = float(te[0])
     tm = eng.timing()
+    if a.calibrate:
+        cal = eng.calibrate_stream(3)
+        if rank == 0:
+            sys.stderr.write('calibration: k_cal_stream reads %d B and writes %d B per launch\n' % cal)
     psteps = float(t['N_sv'].sum())        # sum over steps of N_p(step), all ranks (tallies are all-reduced)
     value = psteps / elapsed
 
@@ -179,6 +185,7 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
                          'kernel': 'k_step', 'kernel_ms': k_ms, 'emit_kernel_ms': tm['emit_kernel_ms'],
+                         'events_kernel_ms': tm['events_kernel_ms'],
                          'algorithmic_bytes_per_launch': BYTES_PER_PHONON_STEP * live_rank},
         }
         if world == 1 and not a.no_cpu_baseline:

@@ -193,6 +193,10 @@ int nk_reflect(nk_ctx *ctx, int64_t n, const int32_t *facet, const int32_t *mode
                const double *r_diff, int32_t *mode_out, double *n_out, double *omega_out); /* Population.py:941-1015 */
 int nk_uniform2(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *u0, double *u1);
 
+/* measurement helper: `launches` sweeps of the particle arrays with a known byte count per launch (returned), in
+ * the access shape of the step kernel, so that rocprofv3 FETCH_SIZE / WRITE_SIZE readings can be calibrated */
+int nk_calibrate_stream(nk_ctx *ctx, int32_t launches, int64_t *bytes_read, int64_t *bytes_written);
+
 #ifdef __cplusplus
 }
 #endif

@@ -808,6 +808,19 @@ int nk_reflect(nk_ctx *ctx, int64_t n, const int32_t *facet, const int32_t *mode
     if (drd) hipFree(drd);
     return NK_OK;
 }
+int nk_calibrate_stream(nk_ctx *ctx, int32_t launches, int64_t *bytes_read, int64_t *bytes_written) {
+    NK_ARG(ctx && launches > 0 && ctx->d.cap > 0, "nk_calibrate_stream: bad arguments");
+    NK_HIP(hipSetDevice(ctx->device));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t ns = 0;
+    NK_HIP(hipMemcpy(&ns, ctx->d.n_slots, 8, hipMemcpyDeviceToHost));
+    for (int k = 0; k < launches; ++k) k_cal_stream<<<ctx->g_step, NK_WG, 0, ctx->stream>>>(ctx->d);
+    NK_HIP(hipGetLastError());
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    if (bytes_read) *bytes_read = ns * 44;
+    if (bytes_written) *bytes_written = ns * 32;
+    return NK_OK;
+}
 int nk_uniform2(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *u0, double *u1) {
     if (!u0 || !u1) return NK_ERR_ARG;
     double *dout = nullptr, h[2];

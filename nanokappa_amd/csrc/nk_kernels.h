@@ -474,6 +474,19 @@ __global__ __launch_bounds__(NK_WG) void k_tap_reflect(NkDev d, int64_t n, const
                n_in[i], om_in[i], r_spec[i], r_deg ? r_deg[i] : 0.0, r_diff[i], mo, no, oo);
     mode_out[i] = mo; n_out[i] = no; om_out[i] = oo;
 }
+// Counter calibration: the same coalesced 8-byte-per-lane sweep as k_step with a KNOWN byte count
+// (44 B read + 32 B written per slot), so FETCH_SIZE / WRITE_SIZE readings of k_step can be scaled
+// (MI355X_MICROARCH.md: FETCH_SIZE is uncalibrated for accesses other than 16 B/lane).
+__global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
+    const int64_t n = *d.n_slots;
+    const int64_t stride = (int64_t)gridDim.x * NK_WG;
+    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
+        const int mode = d.mode[i];
+        double x = d.x[i], y = d.y[i], z = d.z[i], occ = d.occ[i], nts = d.nts[i];
+        if (mode == -123456789) { x += occ; }                     // keeps the occ load alive; never true
+        d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts;
+    }
+}
 __global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *out) {
     double a, b;
     nk_uniform2_dev(seed, pid, step, tag, a, b);

@@ -75,7 +75,7 @@ EXPORTS = ['nk_create', 'nk_destroy', 'nk_last_error', 'nk_set_material', 'nk_se
            'nk_set_reservoirs', 'nk_set_rough', 'nk_set_params', 'nk_reserve', 'nk_upload_particles',
            'nk_init_boundaries', 'nk_step', 'nk_download_particles', 'nk_get_subvol_temperature',
            'nk_set_subvol_temperature', 'nk_get_step', 'nk_get_timing', 'nk_comm_unique_id', 'nk_comm_init',
-           'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2']
+           'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2', 'nk_calibrate_stream']
 
 _lib = None
 
@@ -115,6 +115,7 @@ def load_library():
     L.nk_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int64, c_dp, c_ip, c_dp]
     L.nk_reflect.argtypes = [C.c_void_p, C.c_int64, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp]
     L.nk_uniform2.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, c_dp, c_dp]
+    L.nk_calibrate_stream.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
     _lib = L
     return L
 
@@ -330,6 +331,12 @@ class Engine(object):
         return dict(step_kernel_ms=t.step_kernel_ms, emit_kernel_ms=t.emit_kernel_ms, events_kernel_ms=t.events_kernel_ms,
                     total_ms=t.total_ms,
                     slots=int(t.slots), live=int(t.live))
+
+    def calibrate_stream(self, launches=3):
+        """Known-traffic sweeps for counter calibration; returns (bytes_read, bytes_written) per launch."""
+        r, w = C.c_int64(0), C.c_int64(0)
+        self._ck(self.L.nk_calibrate_stream(self.h, int(launches), C.byref(r), C.byref(w)), 'nk_calibrate_stream')
+        return int(r.value), int(w.value)
 
     def comm_init(self, unique_id, rank, nranks):
         buf = C.create_string_buffer(bytes(unique_id), 128)

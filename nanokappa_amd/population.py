@@ -19,6 +19,7 @@ import numpy as np
 from .constants import Constants
 from . import setup_tables as ST
 from .engine import Engine
+from .sharding import shard_range
 
 
 class _Stats(object):
@@ -124,6 +125,11 @@ class Population(Constants):
             self.N_leaving = np.zeros(0, dtype=int)
 
         print('Initialising population...')
+        # every rank creates only its own share of the ensemble; ids and tiled modes use global indices
+        self.N_total = self.N_p
+        self.pid_lo, hi = self._shard(self.N_total)
+        self.N_local = hi - self.pid_lo
+        self.prng = np.random.default_rng([self.seed, 7919, self.rank])
         pos, modes, occ = self.initialise_all_particles(geometry, phonon)
 
         # ---- device engine
@@ -132,9 +138,8 @@ class Population(Constants):
         if comm is not None and self.nranks > 1:
             self.engine.comm_init(comm[0], self.rank, self.nranks)
         J = phonon.number_of_branches
-        lo, hi = self._shard(pos.shape[0])
-        self.engine.reserve(int(1.3 * (hi - lo)) + 65536)
-        self.engine.upload(pos[lo:hi], (modes[lo:hi, 0] * J + modes[lo:hi, 1]).astype(np.int32), occ[lo:hi], pid_offset=lo)
+        self.engine.reserve(int(1.3 * pos.shape[0]) + 65536)
+        self.engine.upload(pos, (modes[:, 0] * J + modes[:, 1]).astype(np.int32), occ, pid_offset=self.pid_lo)
         print('Getting first boundary collisions...')
         self.engine.init_boundaries()
 
@@ -157,9 +162,7 @@ class Population(Constants):
     # ----------------------------------------------------------------------------------- setup
     def _shard(self, n):
         """Initial particles are split evenly by index over the ranks."""
-        lo = (n * self.rank) // self.nranks
-        hi = (n * (self.rank + 1)) // self.nranks
-        return lo, hi
+        return shard_range(n, self.rank, self.nranks)
 
     def _build_rough_tables(self, geometry, phonon):
         self.scat_model = self.args.bound_scat[0]
@@ -208,38 +211,31 @@ class Population(Constants):
         """Population.py:127-144: tiled unique modes when there is at least one particle per mode and subvolume."""
         self.unique_modes = np.vstack(np.where(~phonon.inactive_modes_mask)).T
         if self.particles_pmps >= 1:
-            reps = int(np.ceil(self.particles_pmps * (self.n_of_subvols - self.n_of_empty_subvols)))
-            idx = np.arange(self.N_p) % self.unique_modes.shape[0]
-            if reps * self.unique_modes.shape[0] < self.N_p:
-                raise Exception('internal: mode tiling shorter than N_p')
+            idx = (self.pid_lo + np.arange(self.N_local)) % self.unique_modes.shape[0]
             modes = self.unique_modes[idx, :]
         else:
-            modes = self.unique_modes[self.rng.integers(0, phonon.number_of_active_modes, size=self.N_p), :]
+            modes = self.unique_modes[self.prng.integers(0, phonon.number_of_active_modes, size=self.N_local), :]
         return modes.astype(int)
-
-    def generate_positions(self, n, mesh):
-        x = mesh.sample_volume(n, self.rng)                                         # Population.py:163-184
-        keep = mesh.contains(x) if getattr(mesh, 'n_of_faces', 0) > 12 and n < 200000 else np.ones(n, dtype=bool)
-        return x[keep]
 
     def initialise_all_particles(self, geometry, phonon):
         """Positions, modes, temperatures, occupations (Population.py:186-321)."""
         key = self.args.part_dist[0]
         S = self.n_of_subvols
+        NL = self.N_local
         if key == 'random_domain':
-            pos = geometry.mesh.sample_volume(self.N_p, self.rng)
+            pos = geometry.mesh.sample_volume(NL, self.prng)
         elif key == 'center_domain':
-            pos = np.ones((self.N_p, 3)) * geometry.mesh.center_mass
+            pos = np.ones((NL, 3)) * geometry.mesh.center_mass
         elif key == 'random_subvol':
             vol = np.asarray(geometry.subvol_volume, dtype=float)
-            n = self.N_p * vol / (vol.sum() - vol[self.empty_subvols].sum())
+            n = NL * vol / (vol.sum() - vol[self.empty_subvols].sum())
             n = np.ceil(n).astype(int)
             n[self.empty_subvols] = 0
             chunks = [[] for _ in range(S)]
             have = np.zeros(S, dtype=int)
             while np.any(have < n):
                 batch = int(min(max((n - have).sum() * 1.2, 1e4), 4e6))
-                x_new = geometry.mesh.sample_volume(batch, self.rng)
+                x_new = geometry.mesh.sample_volume(batch, self.prng)
                 sv = geometry.subvol_classifier.predict(x_new) if S > 1 else np.zeros(batch, dtype=int)
                 order = np.argsort(sv, kind='stable')
                 counts = np.bincount(sv, minlength=S)
@@ -250,7 +246,7 @@ class Population(Constants):
                         take = order[start[i]:start[i] + min(need, counts[i])]
                         chunks[i].append(x_new[take])
                         have[i] += take.shape[0]
-            pos = np.vstack([np.vstack(c) if c else np.zeros((0, 3)) for c in chunks])[:self.N_p, :]
+            pos = np.vstack([np.vstack(c) if c else np.zeros((0, 3)) for c in chunks])[:NL, :]
         elif key == 'center_subvol':
             raise NotImplementedError('--part_dist center_subvol needs per-subvolume meshes (not built)')
         else:
@@ -258,14 +254,14 @@ class Population(Constants):
             modes = data[:, [0, 1]].astype(int)
             pos = data[:, [2, 3, 4]].copy()
             occ = data[:, 5].copy()
-            self.N_p = pos.shape[0]
-            self._resume_modes = modes
+            lo, hi = self._shard(pos.shape[0])
+            self.N_total, self.pid_lo, self.N_local = pos.shape[0], lo, hi - lo
+            modes, pos, occ = modes[lo:hi], pos[lo:hi], occ[lo:hi]
             self.subvol_id = geometry.subvol_classifier.predict(pos)
             self.subvol_temperature = self._assign_subvol_temperatures(geometry)
             return pos, modes, occ
-        self.N_p = pos.shape[0]
         modes = self.initialise_modes(phonon)
-        self.subvol_id = geometry.subvol_classifier.predict(pos) if S > 1 else np.zeros(self.N_p, dtype=int)
+        self.subvol_id = geometry.subvol_classifier.predict(pos) if S > 1 else np.zeros(pos.shape[0], dtype=int)
         self.subvol_temperature = self._assign_subvol_temperatures(geometry)
         T = self.subvol_temperature[self.subvol_id]
         occ = phonon.calculate_occupation(T, phonon.omega[modes[:, 0], modes[:, 1]])  # Population.py:280
@@ -290,7 +286,7 @@ class Population(Constants):
         if key == 'mean':
             return np.ones(S) * bound_T.mean()
         if key == 'random':
-            return self.rng.random(S) * (bound_T.max() - bound_T.min()) + bound_T.min()
+            return self.rng.random(S) * (bound_T.max() - bound_T.min()) + bound_T.min()     # same stream on every rank
         if key == 'linear':
             fi = self.res_facet[self.res_bound_cond == 'T']
             bp = geometry.facet_centroid[fi, :]
@@ -332,7 +328,8 @@ class Population(Constants):
     def _initial_tallies(self, geometry, phonon, pos, modes, occ):
         """calculate_energy / calculate_heat_flux / calculate_kappa on the initial state (Population.py:282, :318-321)."""
         S = self.n_of_subvols
-        self.subvol_N_p = np.bincount(self.subvol_id, minlength=S).astype(np.int64)
+        w = self.nranks            # with several ranks the t = 0 row is extrapolated from this rank's share
+        self.subvol_N_p = np.bincount(self.subvol_id, minlength=S).astype(np.int64) * w
         self.N_p = int(self.subvol_N_p.sum())
         om = phonon.omega[modes[:, 0], modes[:, 1]]
         if self.T_reference == 'local':
@@ -342,10 +339,10 @@ class Population(Constants):
             dn = occ - self.reference_occupation[modes[:, 0], modes[:, 1]]
             ref = self.ref_en_density
         e = self.hbar * om * dn
-        self.total_energy = float(e.sum())
-        E_raw = np.bincount(self.subvol_id, weights=e, minlength=S)
+        self.total_energy = float(e.sum()) * w
+        E_raw = np.bincount(self.subvol_id, weights=e, minlength=S) * w
         v = phonon.group_vel[modes[:, 0], modes[:, 1], :]
-        flux_raw = np.stack([np.bincount(self.subvol_id, weights=v[:, d] * e, minlength=S) for d in range(3)], axis=1)
+        flux_raw = np.stack([np.bincount(self.subvol_id, weights=v[:, d] * e, minlength=S) for d in range(3)], axis=1) * w
         self.subvol_energy = self._normalise_energy(phonon, E_raw, self.subvol_N_p) + ref
         self.subvol_heat_flux = self._normalise_flux(phonon, flux_raw, self.subvol_N_p)
         self.calculate_kappa(geometry)

@@ -425,9 +425,10 @@ void nko_boundary_scattering(const nko_material *mat, const nko_mesh *mesh, cons
     P->N = w;
 }
 
-/* refresh_temperatures + calculate_energy, Population.py:685-728 */
-void nko_refresh_temperatures(const nko_material *mat, const nko_subvols *sv, const nko_params *p,
-                              nko_particles *P, double *T_sv, double *E_sv, int64_t *N_sv, double *E_raw) {
+/* The three parts of refresh_temperatures are exposed separately so that a particle-sharded run can sum the tallies
+ * of all ranks between them; nko_refresh_temperatures chains them for the single-rank case. */
+void nko_tally(const nko_material *mat, const nko_subvols *sv, const nko_params *p, nko_particles *P,
+               const double *T_sv, int64_t *N_sv, double *E_raw) {
     int32_t S = sv->S;
     for (int32_t s = 0; s < S; ++s) { N_sv[s] = 0; E_raw[s] = 0.0; }
     for (int64_t i = 0; i < P->N; ++i) {
@@ -441,6 +442,10 @@ void nko_refresh_temperatures(const nko_material *mat, const nko_subvols *sv, co
         P->energy[i] = e;
         E_raw[s] += e;                                                        /* :715-717 */
     }
+}
+void nko_update_T(const nko_material *mat, const nko_subvols *sv, const nko_params *p, const int64_t *N_sv,
+                  const double *E_raw, double *T_sv, double *E_sv) {
+    int32_t S = sv->S;
     for (int32_t s = 0; s < S; ++s) {
         double norm;
         if (p->norm_fixed) norm = mat->active_modes / (p->particle_density * sv->volumes[s]);   /* :720 */
@@ -451,7 +456,16 @@ void nko_refresh_temperatures(const nko_material *mat, const nko_subvols *sv, co
         E_sv[s] = E + ref;                                                    /* :728 */
     }
     for (int32_t s = 0; s < S; ++s) T_sv[s] = T_of_E(mat, E_sv[s]);           /* :692 */
+}
+void nko_assign_T(const nko_subvols *sv, const double *T_sv, nko_particles *P) {
     for (int64_t i = 0; i < P->N; ++i) P->temp[i] = interp_T_one(sv, T_sv, P->pos + 3 * i, P->sv[i]);  /* :694-702 */
+}
+/* refresh_temperatures + calculate_energy, Population.py:685-728 */
+void nko_refresh_temperatures(const nko_material *mat, const nko_subvols *sv, const nko_params *p,
+                              nko_particles *P, double *T_sv, double *E_sv, int64_t *N_sv, double *E_raw) {
+    nko_tally(mat, sv, p, P, T_sv, N_sv, E_raw);
+    nko_update_T(mat, sv, p, N_sv, E_raw, T_sv, E_sv);
+    nko_assign_T(sv, T_sv, P);
 }
 
 /* lifetime_scattering, Population.py:1701-1710 */

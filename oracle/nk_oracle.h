@@ -145,6 +145,11 @@ void nko_boundary_scattering(const nko_material *mat, const nko_mesh *mesh, cons
 /* tally + T update; E_raw[S] = plain sums, E_sv normalised, T_sv in/out */
 void nko_refresh_temperatures(const nko_material *mat, const nko_subvols *sv, const nko_params *p,
                               nko_particles *P, double *T_sv, double *E_sv, int64_t *N_sv, double *E_raw);
+void nko_tally(const nko_material *mat, const nko_subvols *sv, const nko_params *p, nko_particles *P,
+               const double *T_sv, int64_t *N_sv, double *E_raw);
+void nko_update_T(const nko_material *mat, const nko_subvols *sv, const nko_params *p, const int64_t *N_sv,
+                  const double *E_raw, double *T_sv, double *E_sv);
+void nko_assign_T(const nko_subvols *sv, const double *T_sv, nko_particles *P);
 void nko_lifetime_scattering(const nko_material *mat, const nko_params *p, nko_particles *P);
 void nko_heat_flux(const nko_material *mat, const nko_subvols *sv, const nko_params *p,
                    const nko_particles *P, const int64_t *N_sv, double *flux /* [S*3] W/m^2 */);

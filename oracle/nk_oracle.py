@@ -287,6 +287,35 @@ class OracleSim(object):
     def init_boundaries(self):
         self.L.nko_init_boundaries(self.ref(self.mesh), self.ref(self.mat), self.ref(self.p), self.ref(self.P.s))
 
+    def run_timestep_sharded(self, allreduce, emit=True, contains_every=100):
+        """run_timestep for one rank of a particle-sharded ensemble: `allreduce(vec)` sums a float64 vector over the
+        ranks in place (the role RCCL plays in the HIP engine).  Tallied vector: E_raw[S] | N_sv[S]."""
+        L = self.L
+        if contains_every and self.step % contains_every == 0:
+            L.nko_contains_check(self.ref(self.mat), self.ref(self.mesh), self.ref(self.p),
+                                 C.c_int64(self.step), self.ref(self.P.s))
+        L.nko_drift(self.ref(self.mat), self.ref(self.p), self.ref(self.P.s))
+        if emit and self.R > 0:
+            n = L.nko_emit(self.ref(self.mat), self.ref(self.mesh), self.ref(self.res), self.ref(self.p),
+                           C.c_int64(self.step), C.c_int32(self.rank), C.c_int32(self.nranks), self.ref(self.P.s))
+            if n < 0:
+                raise RuntimeError('oracle particle capacity exceeded')
+        L.nko_boundary_scattering(self.ref(self.mat), self.ref(self.mesh), self.ref(self.sv), self.ref(self.res),
+                                  self.ref(self.rough), self.ref(self.p), _p(self.T_sv, c_dp), C.c_int64(self.step),
+                                  self.ref(self.P.s), _p(self.N_leaving, c_lp), _p(self.res_energy, c_dp),
+                                  _p(self.res_flux, c_dp))
+        L.nko_tally(self.ref(self.mat), self.ref(self.sv), self.ref(self.p), self.ref(self.P.s), _p(self.T_sv, c_dp),
+                    _p(self.N_sv, c_lp), _p(self.E_raw, c_dp))
+        vec = np.concatenate((self.E_raw, self.N_sv.astype(np.float64)))
+        allreduce(vec)
+        self.E_raw[:] = vec[:self.S]
+        self.N_sv[:] = np.rint(vec[self.S:]).astype(np.int64)
+        L.nko_update_T(self.ref(self.mat), self.ref(self.sv), self.ref(self.p), _p(self.N_sv, c_lp), _p(self.E_raw, c_dp),
+                       _p(self.T_sv, c_dp), _p(self.E_sv, c_dp))
+        L.nko_assign_T(self.ref(self.sv), _p(self.T_sv, c_dp), self.ref(self.P.s))
+        L.nko_lifetime_scattering(self.ref(self.mat), self.ref(self.p), self.ref(self.P.s))
+        self.step += 1
+
     def run_timestep(self, emit=True, contains_every=100):
         L = self.L
         if contains_every and self.step % contains_every == 0:

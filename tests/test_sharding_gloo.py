@@ -1,0 +1,85 @@
+"""The N > 1 path on CPU: two processes (torch.distributed, gloo) each advance their shard of the ensemble with the
+oracle, summing the per-step tally vector with an all-reduce -- the scheme the HIP engine runs over RCCL.  The union
+of the two shards must reproduce the single-process run particle for particle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from util import case_tables, random_population, make_oracle_sim
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+NSTEPS = 12
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    from nanokappa_amd.sharding import shard_range
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ct = case_tables('ttrrp')
+    pos, mode, occ, counter = random_population(ct, 12000, seed=3)
+    lo, hi = shard_range(pos.shape[0], rank, world)
+    sim = make_oracle_sim(ct, pos[lo:hi], mode[lo:hi], occ[lo:hi], counter, seed=17, cap=30000)
+    sim.P.pid[:hi - lo] = np.arange(lo, hi, dtype=np.uint64)
+    sim.rank, sim.nranks = rank, world
+
+    def allreduce(vec):
+        t = torch.from_numpy(vec)
+        dist.all_reduce(t)
+
+    T_hist = []
+    for _ in range(NSTEPS):
+        sim.run_timestep_sharded(allreduce)
+        T_hist.append(sim.T_sv.copy())
+    n = sim.P.N
+    np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), pid=sim.P.pid[:n], pos=sim.P.pos[:n], occ=sim.P.occ[:n],
+             mode=sim.P.mode[:n], T=np.array(T_hist), N_sv=sim.N_sv)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_union_equals_single_run(tmp_path):
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / 'rank0.npz')
+    r1 = np.load(tmp_path / 'rank1.npz')
+    # single-process reference
+    ct = case_tables('ttrrp')
+    pos, mode, occ, counter = random_population(ct, 12000, seed=3)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=17, cap=30000)
+    T_hist = []
+    for _ in range(NSTEPS):
+        sim.run_timestep()
+        T_hist.append(sim.T_sv.copy())
+    n = sim.P.N
+    # both ranks saw the same (global) temperatures, equal to the single run up to summation order
+    assert np.array_equal(r0['T'], r1['T'])
+    assert np.allclose(r0['T'], np.array(T_hist), rtol=0, atol=1e-9)
+    assert np.array_equal(r0['N_sv'], sim.N_sv)
+    pid = np.concatenate((r0['pid'], r1['pid']))
+    assert pid.shape[0] == n and np.unique(pid).shape[0] == n          # disjoint shards, nothing lost
+    o = np.argsort(pid)
+    o1 = np.argsort(sim.P.pid[:n])
+    assert np.array_equal(pid[o], sim.P.pid[:n][o1])
+    assert np.array_equal(np.concatenate((r0['mode'], r1['mode']))[o], sim.P.mode[:n][o1])
+    assert np.allclose(np.concatenate((r0['pos'], r1['pos']))[o], sim.P.pos[:n][o1], rtol=1e-10, atol=1e-8)
+    assert np.allclose(np.concatenate((r0['occ'], r1['occ']))[o], sim.P.occ[:n][o1], rtol=1e-8, atol=0)
+    # load balance of the emission split
+    assert abs(r0['pid'].shape[0] - r1['pid'].shape[0]) < 0.05 * n
+
+
+def test_sharding_rules():
+    from nanokappa_amd.sharding import shard_range, emission_owner, emission_pid
+    n = 1000003
+    spans = [shard_range(n, r, 8) for r in range(8)]
+    assert spans[0][0] == 0 and spans[-1][1] == n
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(7))
+    owners = [emission_owner(rm, lv, 5, 8) for rm in range(64) for lv in range(1, 5)]
+    assert sorted(set(owners)) == list(range(8))
+    assert emission_pid(3, 2, 0) == (1 << 40) | (3 << 12) | 2
