@@ -1,9 +1,11 @@
 // nk_device.h -- device-side data model and per-particle physics of the MI355X engine.
 //
 // One particle = one lane.  Particle state is SoA in HBM (x, y, z, occupation, time-to-boundary as doubles; mode and
-// next facet as int32; a 64-bit particle id that keys the counter-based RNG).  Small read-only tables (planes, faces,
-// facets, slice centres, subvolume temperatures) and the tally bins live in LDS; per-mode records (64 B: omega, group
-// velocity and the four lifetime rows around the live temperature range) are gathered from L2 / Infinity Cache.
+// next facet as int32; a 64-bit particle id that keys the counter-based RNG), split into `nseg` equal segments; a
+// segment holds its live particles contiguously from its start and is owned by one workgroup at a time.  Small
+// read-only tables (planes, faces, facets, slice centres, subvolume temperatures), the tally bins and the per-workgroup
+// event buffer live in LDS; per-mode records (64 B: omega, group velocity and the four lifetime rows around the live
+// temperature range) are gathered through L2 (particles of one segment come in runs of neighbouring modes).
 //
 // Reference semantics cited as file:line under the reference checkout (classes/Population.py etc.).
 #pragma once
@@ -16,9 +18,7 @@
 #define NK_FACE_DOUBLES 16   // lo(3) hi(3) o(3) iu(3) iw(3) {orig_face, facet}
 #define NK_LDS_FACES 256     // meshes up to this many faces keep their plane/face tables in LDS
 #define NK_TAU_ROWS 4        // lifetime rows packed into each mode record
-#define NK_EVQ_SHARDS 256    // the event queue is split into shards, each with its own counter (one hot counter
-                             // saturates at ~90 atomics/us: 156k wave-level pushes per step would cost 1.8 ms)
-#define NK_EVQ_PAD 32        // ints between shard counters (128 B: one L2 line each)
+#define NK_EVCAP 512         // entries of the per-workgroup LDS event buffer (< NK_WG pending + NK_WG new)
 
 // RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")
 #define NK_TAG_REFLECT 0x00000u
@@ -97,33 +97,22 @@ struct NkDev {
     double particle_density, T_ref;
     uint64_t seed;
     int32_t rank, nranks;
-    // ---- particles (SoA, capacity `cap`)
+    // ---- particles: SoA arrays of nseg * segcap slots; segment s = slots [s*segcap, s*segcap + seg_count[s])
     int64_t cap;
+    int32_t nseg, segcap;
+    int32_t *seg_count;               // [nseg] live particles per segment (contiguous from the segment start)
+    int64_t *seg_free_prefix;         // [nseg+1] exclusive prefix of the free slots per segment (after the last step):
+                                      // entering particles are dealt to segments in proportion to their free space
     double *x, *y, *z, *occ, *nts;
     int32_t *mode, *facet;
     uint64_t *pid;
     // ---- bookkeeping words in device memory
-    int64_t *n_slots;                 // high-water slot count
-    int32_t *free_ring;               // [cap] FIFO of dead slots: pushes at tail (k_events), pops at head (k_spawn)
-    unsigned long long *fl_head, *fl_tail;
-    int64_t *fl_avail;                // tail - head snapshot taken by k_update = slots the next emission may reuse
-    int32_t *evq;                     // [NK_EVQ_SHARDS][evq_seg] slots whose particle meets a boundary this step
-    int32_t *evq_count;               // [NK_EVQ_SHARDS*NK_EVQ_PAD] entries per shard
-    int64_t evq_seg;                  // capacity of one shard
-    int32_t *alloc_count;             // particles entering this step (this rank)
+    int32_t *alloc_count;             // particles entering this step (this rank) = length of spawn_list
     int32_t *overflow;                // set when a particle had to be dropped for lack of capacity
     double *partials;                 // [rows][NB] per-workgroup tally rows
     int32_t NB;                       // bins per row = 5*S + 5*R + 1
     int32_t dbg;                      // developer ablation mask (env NK_DEBUG; 0 in production): see k_step
 };
-
-// Append slot `i` to the event queue shard of this workgroup.
-__device__ __forceinline__ void nk_evq_push(const NkDev &d, int64_t i) {
-    const int q = blockIdx.x & (NK_EVQ_SHARDS - 1);
-    const int k = atomicAdd(d.evq_count + q * NK_EVQ_PAD, 1);
-    if (k < d.evq_seg) d.evq[(int64_t)q * d.evq_seg + k] = (int32_t)i;
-    else *d.overflow = 1;
-}
 
 // ------------------------------------------------------------------------------------------------ RNG
 // Philox4x32-10, counter = {pid_lo, pid_hi, step, tag}, key = seed.  Stateless: nothing is stored per particle.
@@ -189,15 +178,16 @@ __device__ __forceinline__ double nk_E_of_T(const NkDev &d, double T) {
 // lifetime_function = RegularGridInterpolator((T,q,j), tau) at integer (q,j): linear in tau along T (Phonon.py:336).
 // Out-of-table T gives NaN (the reference raises ValueError there).  `rec` is the particle's mode record; its four
 // packed rows serve the live temperature range, anything else falls back to the full table.
-__device__ __forceinline__ double nk_lifetime(const NkDev &d, const NkMode &rec, double T, int mode) {
+__device__ __forceinline__ double nk_lifetime(const NkDev &d, double tau0, double tau1, double tau2, double tau3, double T,
+                                              int mode) {
     // Fast path: T strictly inside the packed window (g0, g3].  searchsorted-left - 1 puts T in (g_k, g_k+1] at
     // interval k, so two compares select it; grid values come from scalar registers, lifetimes from the mode record.
     if (T > d.tau_g[0] && T <= d.tau_g[3]) {
         const bool b1 = T > d.tau_g[1], b2 = T > d.tau_g[2];
         const double glo = b2 ? d.tau_g[2] : (b1 ? d.tau_g[1] : d.tau_g[0]);
         const double ghi = b2 ? d.tau_g[3] : (b1 ? d.tau_g[2] : d.tau_g[1]);
-        const double t0 = b2 ? rec.tau[2] : (b1 ? rec.tau[1] : rec.tau[0]);
-        const double t1 = b2 ? rec.tau[3] : (b1 ? rec.tau[2] : rec.tau[1]);
+        const double t0 = b2 ? tau2 : (b1 ? tau1 : tau0);
+        const double t1 = b2 ? tau3 : (b1 ? tau2 : tau1);
         const double y = (T - glo) / (ghi - glo);
         return t0 * (1.0 - y) + t1 * y;
     }
@@ -214,8 +204,8 @@ __device__ __forceinline__ double nk_lifetime(const NkDev &d, const NkMode &rec,
     const int k = i - d.tau_row0;
     double t0, t1;
     if (k >= 0 && k < NK_TAU_ROWS - 1) {
-        t0 = k == 0 ? rec.tau[0] : (k == 1 ? rec.tau[1] : rec.tau[2]);
-        t1 = k == 0 ? rec.tau[1] : (k == 1 ? rec.tau[2] : rec.tau[3]);
+        t0 = k == 0 ? tau0 : (k == 1 ? tau1 : tau2);
+        t1 = k == 0 ? tau1 : (k == 1 ? tau2 : tau3);
     } else {
         t0 = d.tau[(int64_t)i * d.M + mode];
         t1 = d.tau[(int64_t)(i + 1) * d.M + mode];

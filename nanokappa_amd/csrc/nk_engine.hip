@@ -35,7 +35,8 @@ struct nk_ctx {
     bool have_material = false, have_mesh = false, have_sv = false, have_params = false;
     int64_t step = 0;
     bool pending_relax = false;
-    int g_step = 0, g_spawn = 0, g_events = 0;   // grids of the three tallying kernels = rows of `partials`
+    int g_sweep = 0;               // persistent grid of k_sweep = rows of `partials`
+    std::vector<int32_t> h_seg_count;
     double *acc = nullptr;         // [NB]
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -77,9 +78,9 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 #define NK_UP(src, n, dst)                                                                             \
     do { int rc_ = nk_upload(ctx, src, n, dst); if (rc_) return rc_; } while (0)
 
-static inline size_t nk_lds(const nk_ctx *ctx, bool geom) {
+static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool evbuf = false) {
     const NkDev &d = ctx->d;
-    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, geom);
+    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, geom, evbuf);
 }
 static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
 
@@ -152,25 +153,16 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     { const char *dbg = getenv("NK_DEBUG"); ctx->d.dbg = dbg ? atoi(dbg) : 0; }
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
-    // bookkeeping words: n_slots, fl_head, fl_tail, fl_avail (64-bit); evq_count, alloc_count, overflow (32-bit)
-    const int64_t *p64 = nullptr;
+    // bookkeeping words in device memory: alloc_count, overflow
     const int32_t *p32 = nullptr;
     int rc;
-    if ((rc = nk_upload<int64_t>(ctx, nullptr, 4, &p64)) ||
-        (rc = nk_upload<int32_t>(ctx, nullptr, NK_EVQ_SHARDS * NK_EVQ_PAD + 4, &p32))) {
+    if ((rc = nk_upload<int32_t>(ctx, nullptr, 4, &p32))) {
         g_create_error = ctx->err;
         delete ctx;
         return rc;
     }
-    int64_t *w = (int64_t *)p64;
-    ctx->d.n_slots = w;
-    ctx->d.fl_head = (unsigned long long *)(w + 1);
-    ctx->d.fl_tail = (unsigned long long *)(w + 2);
-    ctx->d.fl_avail = w + 3;
-    int32_t *v = (int32_t *)p32;
-    ctx->d.evq_count = v;
-    ctx->d.alloc_count = v + NK_EVQ_SHARDS * NK_EVQ_PAD;
-    ctx->d.overflow = v + NK_EVQ_SHARDS * NK_EVQ_PAD + 1;
+    ctx->d.alloc_count = (int32_t *)p32;
+    ctx->d.overflow = (int32_t *)p32 + 1;
     *out = ctx;
     return NK_OK;
 }
@@ -310,11 +302,8 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     d.NB = 5 * d.S + 5 * d.R + 1;
     if (ctx->acc) { hipFree(ctx->acc); ctx->acc = nullptr; }
     NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)d.NB * sizeof(double)));
-    ctx->g_step = ctx->num_cu * 8;
-    ctx->g_spawn = ctx->num_cu * 4;
-    ctx->g_events = ((ctx->num_cu * 8 + NK_EVQ_SHARDS - 1) / NK_EVQ_SHARDS) * NK_EVQ_SHARDS;   // whole shards
     const double *p;
-    NK_UP((const double *)nullptr, (size_t)(ctx->g_step + ctx->g_spawn + ctx->g_events) * d.NB, &p);
+    NK_UP((const double *)nullptr, (size_t)(ctx->num_cu * 8) * d.NB, &p);      // >= any persistent grid we launch
     d.partials = (double *)p;
     return NK_OK;
 }
@@ -420,51 +409,127 @@ static int nk_check_ready(nk_ctx *ctx) {
         NK_ARG(!(hf.bc == 'T' || hf.bc == 'F') || hf.res >= 0, "a facet has BC 'T' but nk_set_reservoirs did not cover it");
     }
     NK_ARG(d.cap > 0, "no particle storage: call nk_reserve / nk_upload_particles");
-    NK_ARG(nk_lds(ctx, true) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
+    NK_ARG(nk_lds(ctx, true, true) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
+    return NK_OK;
+}
+
+// Host copy of the live particles, segment by segment (used by download and by re-layouts).
+struct NkHostParticles {
+    std::vector<double> x, y, z, occ, nts;
+    std::vector<int32_t> mode, facet;
+    std::vector<uint64_t> pid;
+};
+static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
+    NkDev &d = ctx->d;
+    if (d.cap == 0) return NK_OK;
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    std::vector<int32_t> cnt((size_t)d.nseg);
+    NK_HIP(hipMemcpy(cnt.data(), d.seg_count, (size_t)d.nseg * 4, hipMemcpyDeviceToHost));
+    int64_t live = 0;
+    for (int c : cnt) live += c;
+    ctx->h_seg_count = cnt;
+    if (!want_all) { h.x.resize((size_t)live); return NK_OK; }
+    std::vector<double> bd((size_t)d.cap);
+    auto pack = [&](const void *src, size_t esz, void *dst) -> int {
+        NK_HIP(hipMemcpy(bd.data(), src, (size_t)d.cap * esz, hipMemcpyDeviceToHost));
+        char *o = (char *)dst;
+        const char *in = (const char *)bd.data();
+        for (int sgm = 0; sgm < d.nseg; ++sgm) {
+            memcpy(o, in + (size_t)sgm * d.segcap * esz, (size_t)cnt[sgm] * esz);
+            o += (size_t)cnt[sgm] * esz;
+        }
+        return NK_OK;
+    };
+    h.x.resize(live); h.y.resize(live); h.z.resize(live); h.occ.resize(live); h.nts.resize(live);
+    h.mode.resize(live); h.facet.resize(live); h.pid.resize(live);
+    int rc;
+    if ((rc = pack(d.x, 8, h.x.data())) || (rc = pack(d.y, 8, h.y.data())) || (rc = pack(d.z, 8, h.z.data())) ||
+        (rc = pack(d.occ, 8, h.occ.data())) || (rc = pack(d.nts, 8, h.nts.data())) || (rc = pack(d.mode, 4, h.mode.data())) ||
+        (rc = pack(d.facet, 4, h.facet.data())) || (rc = pack(d.pid, 8, h.pid.data())))
+        return rc;
+    return NK_OK;
+}
+
+// Lay N particles out over the segments (equal shares, contiguous index ranges).
+static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, const double *z, const int32_t *mode,
+                      const double *occ, const double *n_ts, const int32_t *facet, const uint64_t *pid, uint64_t pid_offset) {
+    NkDev &d = ctx->d;
+    std::vector<int32_t> cnt((size_t)d.nseg);
+    std::vector<int64_t> start((size_t)d.nseg + 1, 0);
+    for (int sgm = 0; sgm < d.nseg; ++sgm) {
+        int64_t lo = (N * sgm) / d.nseg, hi = (N * (sgm + 1)) / d.nseg;
+        cnt[sgm] = (int32_t)(hi - lo);
+        start[sgm] = lo;
+        NK_ARG(cnt[sgm] <= d.segcap, "nk_upload_particles: segment capacity too small");
+    }
+    std::vector<double> bd((size_t)d.cap);
+    auto put = [&](const void *src, size_t esz, void *dst) -> int {
+        if (!src) return NK_OK;
+        char *o = (char *)bd.data();
+        const char *in = (const char *)src;
+        for (int sgm = 0; sgm < d.nseg; ++sgm)
+            memcpy(o + (size_t)sgm * d.segcap * esz, in + (size_t)start[sgm] * esz, (size_t)cnt[sgm] * esz);
+        NK_HIP(hipMemcpy(dst, bd.data(), (size_t)d.cap * esz, hipMemcpyHostToDevice));
+        return NK_OK;
+    };
+    int rc;
+    if ((rc = put(x, 8, d.x)) || (rc = put(y, 8, d.y)) || (rc = put(z, 8, d.z)) || (rc = put(occ, 8, d.occ)) ||
+        (rc = put(n_ts, 8, d.nts)) || (rc = put(mode, 4, d.mode)) || (rc = put(facet, 4, d.facet)))
+        return rc;
+    if (pid) { if ((rc = put(pid, 8, d.pid))) return rc; }
+    else {
+        std::vector<uint64_t> ids((size_t)N);
+        for (int64_t i = 0; i < N; ++i) ids[(size_t)i] = pid_offset + (uint64_t)i;
+        if ((rc = put(ids.data(), 8, d.pid))) return rc;
+    }
+    NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
+    std::vector<int64_t> fp((size_t)d.nseg + 1, 0);
+    for (int sgm = 0; sgm < d.nseg; ++sgm) fp[sgm + 1] = fp[sgm] + (d.segcap - cnt[sgm]);
+    NK_HIP(hipMemcpy(d.seg_free_prefix, fp.data(), fp.size() * 8, hipMemcpyHostToDevice));
+    return NK_OK;
+}
+
+static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
+    NkDev &d = ctx->d;
+    for (void *p : ctx->pallocs) hipFree(p);
+    ctx->pallocs.clear();
+    // segments: load-balance granularity of the persistent sweep (a few tiles of 256 each)
+    int64_t nseg = capacity / 2048;
+    nseg = nseg < 64 ? 64 : (nseg > 8192 ? 8192 : nseg);
+    int64_t segcap = (capacity + nseg - 1) / nseg;
+    segcap = ((segcap + 63) / 64) * 64;
+    d.nseg = (int32_t)nseg;
+    d.segcap = (int32_t)segcap;
+    d.cap = nseg * segcap;
+    d.spawn_cap = d.cap;
+    const double *pd; const int32_t *pi; const uint64_t *pu;
+#define NK_PALLOC(T, field, ptr, count)                                                                \
+    do { int rc_ = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (rc_) return rc_; d.field = (T *)ptr; } while (0)
+    NK_PALLOC(double, x, pd, d.cap); NK_PALLOC(double, y, pd, d.cap); NK_PALLOC(double, z, pd, d.cap);
+    NK_PALLOC(double, occ, pd, d.cap); NK_PALLOC(double, nts, pd, d.cap);
+    NK_PALLOC(int32_t, mode, pi, d.cap); NK_PALLOC(int32_t, facet, pi, d.cap);
+    NK_PALLOC(uint64_t, pid, pu, d.cap);
+    NK_PALLOC(uint64_t, spawn_list, pu, d.spawn_cap);
+    NK_PALLOC(int32_t, seg_count, pi, d.nseg);
+    { const int64_t *pl; int rc_ = nk_upload<int64_t>(ctx, nullptr, (size_t)d.nseg + 1, &pl, true); if (rc_) return rc_; d.seg_free_prefix = (int64_t *)pl; }
+#undef NK_PALLOC
     return NK_OK;
 }
 
 int nk_reserve(nk_ctx *ctx, int64_t capacity) {
     NK_ARG(ctx, "nk_reserve: NULL context");
-    NK_ARG(capacity > 0 && capacity < (1ll << 31) - 1024, "nk_reserve: capacity out of range");
+    NK_ARG(capacity > 0 && capacity < (1ll << 31) - (1 << 20), "nk_reserve: capacity out of range");
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     if (capacity <= d.cap) return NK_OK;
-    NK_HIP(hipStreamSynchronize(ctx->stream));
-    int64_t w[4] = {0, 0, 0, 0};                 // n_slots, head, tail, avail
-    if (d.cap > 0) NK_HIP(hipMemcpy(w, d.n_slots, 32, hipMemcpyDeviceToHost));
-    const int64_t ns = w[0];
-    std::vector<int32_t> ring;
-    if (d.cap > 0 && w[2] > w[1]) {              // linearise the free ring
-        std::vector<int32_t> old((size_t)d.cap);
-        NK_HIP(hipMemcpy(old.data(), d.free_ring, (size_t)d.cap * 4, hipMemcpyDeviceToHost));
-        for (int64_t k = w[1]; k < w[2]; ++k) ring.push_back(old[(size_t)(k % d.cap)]);
-    }
-    std::vector<void *> old = ctx->pallocs;
-    ctx->pallocs.clear();
-    NkDev nd = d;
-    const double *pd; const int32_t *pi; const uint64_t *pu;
-#define NK_PALLOC(T, field, ptr, copy)                                                                 \
-    do { int rc_ = nk_upload<T>(ctx, nullptr, (size_t)capacity, &ptr, true); if (rc_) return rc_;      \
-         if (copy && d.cap > 0 && ns > 0) NK_HIP(hipMemcpy((void *)ptr, d.field, (size_t)ns * sizeof(T), hipMemcpyDeviceToDevice)); \
-         nd.field = (T *)ptr; } while (0)
-    NK_PALLOC(double, x, pd, true); NK_PALLOC(double, y, pd, true); NK_PALLOC(double, z, pd, true);
-    NK_PALLOC(double, occ, pd, true); NK_PALLOC(double, nts, pd, true);
-    NK_PALLOC(int32_t, mode, pi, true); NK_PALLOC(int32_t, facet, pi, true);
-    NK_PALLOC(uint64_t, pid, pu, true);
-    NK_PALLOC(int32_t, free_ring, pi, false);
-    NK_PALLOC(uint64_t, spawn_list, pu, false);
-#undef NK_PALLOC
-    nd.cap = capacity;
-    nd.spawn_cap = capacity;
-    // event queue shards: a shard receives at most the particles swept / spawned by the workgroups of its residue
-    nd.evq_seg = (2 * capacity) / NK_EVQ_SHARDS + 4096;
-    { int rc_ = nk_upload<int32_t>(ctx, nullptr, (size_t)nd.evq_seg * NK_EVQ_SHARDS, &pi, true); if (rc_) return rc_; nd.evq = (int32_t *)pi; }
-    if (!ring.empty()) NK_HIP(hipMemcpy(nd.free_ring, ring.data(), ring.size() * 4, hipMemcpyHostToDevice));
-    w[1] = 0; w[2] = (int64_t)ring.size(); w[3] = std::min<int64_t>(w[3], (int64_t)ring.size());
-    NK_HIP(hipMemcpy(d.n_slots, w, 32, hipMemcpyHostToDevice));
-    for (void *p : old) hipFree(p);
-    d = nd;
+    NkHostParticles h;
+    const bool had = d.cap > 0;
+    if (had) { int rc = nk_gather_live(ctx, h, true); if (rc) return rc; }
+    int rc = nk_alloc_particles(ctx, capacity);
+    if (rc) return rc;
+    if (had && !h.x.empty())
+        return nk_scatter(ctx, (int64_t)h.x.size(), h.x.data(), h.y.data(), h.z.data(), h.mode.data(), h.occ.data(),
+                          h.nts.data(), h.facet.data(), h.pid.data(), 0);
     return NK_OK;
 }
 
@@ -475,33 +540,15 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     NK_ARG(N == 0 || (x && y && z && mode && occ), "nk_upload_particles: x, y, z, mode, occ are required");
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
-    int64_t zero64[4] = {0, 0, 0, 0};
-    std::vector<int32_t> zero32(NK_EVQ_SHARDS * NK_EVQ_PAD + 4, 0);
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    NK_HIP(hipMemcpy(d.n_slots, zero64, 32, hipMemcpyHostToDevice));       // forget old contents
-    if (N > d.cap) {
-        int rc = nk_reserve(ctx, N + N / 2 + 4096);
+    if (N + N / 5 + 1024 > d.cap) {               // forget old contents and size for 1.5 N
+        int rc = nk_alloc_particles(ctx, N + N / 2 + 65536);
         if (rc) return rc;
     }
-    size_t n = (size_t)N;
-    if (n) {
-        NK_HIP(hipMemcpy(d.x, x, n * 8, hipMemcpyHostToDevice));
-        NK_HIP(hipMemcpy(d.y, y, n * 8, hipMemcpyHostToDevice));
-        NK_HIP(hipMemcpy(d.z, z, n * 8, hipMemcpyHostToDevice));
-        NK_HIP(hipMemcpy(d.occ, occ, n * 8, hipMemcpyHostToDevice));
-        NK_HIP(hipMemcpy(d.mode, mode, n * 4, hipMemcpyHostToDevice));
-        if (n_ts) NK_HIP(hipMemcpy(d.nts, n_ts, n * 8, hipMemcpyHostToDevice));
-        if (facet) NK_HIP(hipMemcpy(d.facet, facet, n * 4, hipMemcpyHostToDevice));
-        if (pid) NK_HIP(hipMemcpy(d.pid, pid, n * 8, hipMemcpyHostToDevice));
-        else {
-            std::vector<uint64_t> ids(n);
-            for (size_t i = 0; i < n; ++i) ids[i] = pid_offset + i;
-            NK_HIP(hipMemcpy(d.pid, ids.data(), n * 8, hipMemcpyHostToDevice));
-        }
-    }
-    zero64[0] = N;
-    NK_HIP(hipMemcpy(d.n_slots, zero64, 32, hipMemcpyHostToDevice));
-    NK_HIP(hipMemcpy(d.evq_count, zero32.data(), zero32.size() * 4, hipMemcpyHostToDevice));
+    int rc = nk_scatter(ctx, N, x, y, z, mode, occ, n_ts, facet, pid, pid_offset);
+    if (rc) return rc;
+    int32_t zero32[4] = {0, 0, 0, 0};
+    NK_HIP(hipMemcpy(d.alloc_count, zero32, 16, hipMemcpyHostToDevice));
     ctx->pending_relax = false;
     return NK_OK;
 }
@@ -540,10 +587,16 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)nsteps * HROW * sizeof(double)));
         ctx->hist_cap = nsteps;
     }
-    const size_t lds_s = nk_lds(ctx, false), lds_g = nk_lds(ctx, true);
+    const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, true);
     const int count_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
-    const int rows_spawn = R > 0 ? ctx->g_spawn : 0;
-    const int rows = ctx->g_step + rows_spawn + ctx->g_events;
+    if (ctx->g_sweep == 0) {                               // persistent grid = what the device keeps resident
+        int per_cu = 0;
+        NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep, NK_WG, lds_w));
+        if (per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        ctx->g_sweep = ctx->num_cu * per_cu;
+    }
+    const int g_sweep = ctx->g_sweep < d.nseg ? ctx->g_sweep : d.nseg;
     const int nev = nsteps < 64 ? nsteps : 64;          // per-kernel timing on (up to) the first 64 steps
     std::vector<hipEvent_t> ev((size_t)nev * 4);
     for (auto &e : ev) NK_HIP(hipEventCreate(&e));
@@ -560,21 +613,17 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         const int fe = ctx->params.flux_every;
         const int do_flux = (fe > 0 && ((ctx->step + 1) % fe) == 0) ? 1 : 0;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
-        k_step<<<ctx->g_step, NK_WG, lds_s, ctx->stream>>>(d, ctx->pending_relax ? 1 : 0, do_flux);
+        if (R > 0) k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
-        if (R > 0) {
-            k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
-            k_spawn<<<ctx->g_spawn, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, ctx->g_step);
-        }
+        k_sweep<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, ctx->pending_relax ? 1 : 0, do_flux);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
-        k_events<<<ctx->g_events, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, ctx->g_step + rows_spawn);
-        if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
-        k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d.partials, rows, NB, ctx->acc);
+        k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d.partials, g_sweep, NB, ctx->acc);
         if (ctx->comm) {
             ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB, ncclDouble, ncclSum, ctx->comm, ctx->stream);
             if (nrc != ncclSuccess) { ctx->err = "ncclAllReduce failed"; return NK_ERR_COMM; }
         }
         k_update<<<1, 512, 0, ctx->stream>>>(d, ctx->acc, ctx->hist + (size_t)s * HROW, do_flux);
+        if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
         ctx->pending_relax = true;
         ctx->step += 1;
     }
@@ -584,8 +633,8 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     float ms = 0.f;
     double sk = 0.0, ek = 0.0, vk = 0.0;
     for (int s = 0; s < nev; ++s) {
-        NK_HIP(hipEventElapsedTime(&ms, ev[4 * s], ev[4 * s + 1])); sk += ms;
-        NK_HIP(hipEventElapsedTime(&ms, ev[4 * s + 1], ev[4 * s + 2])); ek += ms;
+        NK_HIP(hipEventElapsedTime(&ms, ev[4 * s], ev[4 * s + 1])); ek += ms;
+        NK_HIP(hipEventElapsedTime(&ms, ev[4 * s + 1], ev[4 * s + 2])); sk += ms;
         NK_HIP(hipEventElapsedTime(&ms, ev[4 * s + 2], ev[4 * s + 3])); vk += ms;
     }
     NK_HIP(hipEventElapsedTime(&ms, t0, t1));
@@ -617,7 +666,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     }
     const double *last = &h[(size_t)(nsteps - 1) * HROW];
     nk_track_T(ctx, last + NB, S);
-    ctx->timing.slots = (int64_t)last[NB + 2 * S + 1];
+    ctx->timing.slots = d.cap;
     double live = 0.0;
     for (int k = 0; k < S; ++k) live += last[S + k];
     ctx->timing.live = (int64_t)live;
@@ -636,41 +685,21 @@ int nk_download_particles(nk_ctx *ctx, int64_t capacity, double *x, double *y, d
     *N_out = 0;
     if (d.cap == 0) return NK_OK;
     if (ctx->have_material && ctx->have_sv && ctx->have_mesh) { int rc = nk_flush_relax(ctx); if (rc) return rc; }
-    NK_HIP(hipStreamSynchronize(ctx->stream));
-    int64_t ns = 0;
-    NK_HIP(hipMemcpy(&ns, d.n_slots, 8, hipMemcpyDeviceToHost));
-    std::vector<int32_t> hm((size_t)ns);
-    if (ns) NK_HIP(hipMemcpy(hm.data(), d.mode, (size_t)ns * 4, hipMemcpyDeviceToHost));
-    int64_t live = 0;
-    for (int64_t i = 0; i < ns; ++i) live += hm[i] >= 0;
+    NkHostParticles h;
+    int rc = nk_gather_live(ctx, h, capacity != 0);
+    if (rc) return rc;
+    const int64_t live = (int64_t)h.x.size();
     *N_out = live;
     if (capacity == 0) return NK_OK;
     NK_ARG(capacity >= live, "nk_download_particles: capacity smaller than the live particle count");
-    std::vector<double> buf((size_t)ns);
-    auto pack_d = [&](const double *src, double *dst) -> int {
-        if (!dst || !ns) return NK_OK;
-        NK_HIP(hipMemcpy(buf.data(), src, (size_t)ns * 8, hipMemcpyDeviceToHost));
-        int64_t w = 0;
-        for (int64_t i = 0; i < ns; ++i) if (hm[i] >= 0) dst[w++] = buf[i];
-        return NK_OK;
-    };
-    int rc;
-    if ((rc = pack_d(d.x, x)) || (rc = pack_d(d.y, y)) || (rc = pack_d(d.z, z)) || (rc = pack_d(d.occ, occ)) ||
-        (rc = pack_d(d.nts, n_ts)))
-        return rc;
-    if (facet && ns) {
-        std::vector<int32_t> b((size_t)ns);
-        NK_HIP(hipMemcpy(b.data(), d.facet, (size_t)ns * 4, hipMemcpyDeviceToHost));
-        int64_t w = 0;
-        for (int64_t i = 0; i < ns; ++i) if (hm[i] >= 0) facet[w++] = b[i];
-    }
-    if (pid && ns) {
-        std::vector<uint64_t> b((size_t)ns);
-        NK_HIP(hipMemcpy(b.data(), d.pid, (size_t)ns * 8, hipMemcpyDeviceToHost));
-        int64_t w = 0;
-        for (int64_t i = 0; i < ns; ++i) if (hm[i] >= 0) pid[w++] = b[i];
-    }
-    if (mode) { int64_t w = 0; for (int64_t i = 0; i < ns; ++i) if (hm[i] >= 0) mode[w++] = hm[i]; }
+    if (x) memcpy(x, h.x.data(), live * 8);
+    if (y) memcpy(y, h.y.data(), live * 8);
+    if (z) memcpy(z, h.z.data(), live * 8);
+    if (occ) memcpy(occ, h.occ.data(), live * 8);
+    if (n_ts) memcpy(n_ts, h.nts.data(), live * 8);
+    if (mode) memcpy(mode, h.mode.data(), live * 4);
+    if (facet) memcpy(facet, h.facet.data(), live * 4);
+    if (pid) memcpy(pid, h.pid.data(), live * 8);
     return NK_OK;
 }
 
@@ -812,9 +841,10 @@ int nk_calibrate_stream(nk_ctx *ctx, int32_t launches, int64_t *bytes_read, int6
     NK_ARG(ctx && launches > 0 && ctx->d.cap > 0, "nk_calibrate_stream: bad arguments");
     NK_HIP(hipSetDevice(ctx->device));
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    int64_t ns = 0;
-    NK_HIP(hipMemcpy(&ns, ctx->d.n_slots, 8, hipMemcpyDeviceToHost));
-    for (int k = 0; k < launches; ++k) k_cal_stream<<<ctx->g_step, NK_WG, 0, ctx->stream>>>(ctx->d);
+    NkHostParticles h;
+    { int rc = nk_gather_live(ctx, h, false); if (rc) return rc; }
+    const int64_t ns = (int64_t)h.x.size();
+    for (int k = 0; k < launches; ++k) k_cal_stream<<<nk_sweep_grid(ctx), NK_WG, 0, ctx->stream>>>(ctx->d);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
     if (bytes_read) *bytes_read = ns * 44;

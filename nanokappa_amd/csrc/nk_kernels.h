@@ -1,51 +1,64 @@
 // nk_kernels.h -- the HIP kernels of libnanokappa_hip.so (gfx950 / MI355X only).
 //
 // Stream order of one timestep (reference Population.run_timestep, Population.py:1724-1769):
-//   [k_relax + k_contains every `contains_every` steps]           contains_check       :1712-1722
-//   k_step        relax(previous step) -> drift -> tally, or hand the particle to the event queue
-//                                                                  lifetime_scattering  :1701-1710 (deferred, see below)
-//                                                                  drift                :790-795
-//                                                                  calculate_energy     :704-717
-//   k_emit_count  which modes enter at each reservoir, how many    fill_reservoirs      :356-455
-//   k_spawn       one lane per entering particle                   Mesh.sample_surface  Mesh.py:923-951,
-//                                                                  add_reservoir_particles :525-552
-//   k_events      one lane per particle that meets a boundary      boundary_scattering  :1546-1683
+//   [k_relax + k_contains every `contains_every` steps]            contains_check       :1712-1722
+//   k_emit_count  which modes enter at each reservoir, how many     fill_reservoirs      :356-455
+//   k_sweep       per segment: relax(previous step) -> drift -> boundary events -> tally -> compaction,
+//                 then the segment's share of the entering particles
+//                                                                   lifetime_scattering  :1701-1710 (deferred)
+//                                                                   drift                :790-795
+//                                                                   boundary_scattering  :1546-1683
+//                                                                   add_reservoir_particles :525-552
+//                                                                   calculate_energy     :704-717
 //   k_reduce      deterministic column sums of the per-workgroup tally rows
 //   (RCCL all-reduce of the tally vector when nranks > 1)
-//   k_update      normalisation, E -> T, bookkeeping, history row  calculate_energy :719-728, refresh_temperatures :692
+//   k_update      normalisation, E -> T, history row                calculate_energy :719-728, refresh_temperatures :692
 //
 // Deferred relaxation: the reference relaxes occupations at the END of step k with the temperatures of step k.  Those
-// need the global tally of step k, so the relaxation is carried into the BEGINNING of the step kernel of step k+1
-// (same positions, same T_sv): one streaming pass per step instead of two.  A pending relaxation is flushed by
+// need the global tally of step k, so the relaxation is carried into the BEGINNING of the sweep of step k+1 (same
+// positions, same T_sv): one pass over the particles per step instead of two.  A pending relaxation is flushed by
 // k_relax before anything observes the particles (download, contains_check).
 //
-// Event queue: in a 20 nm box a third of the particles meets a boundary every step.  Running the event loop inside
-// the streaming kernel would make every wave pay for it; instead k_step appends those slots to a queue and k_events
-// processes them densely (64 busy lanes per wave), with the ray-casting tables in LDS.
+// Why one fused sweep (measured, profiles/r01_pmc_traffic.json): with a separate event kernel and free-slot reuse the
+// step kernel moved 2.8 GB per launch for 0.68 GB of algorithmic traffic -- random 64-B mode gathers (1.2 GB) and
+// line-granular write-backs of the scattered event kernel -- and ran AT the HBM roof (6.3 TB/s).  Here
+//   * a workgroup owns a segment and walks it tile by tile (256 particles, coalesced loads, next tile prefetched);
+//   * particles that meet a boundary inside the step (a third of them in a 20 nm box) are parked in an LDS buffer and
+//     processed 256 at a time by all lanes (no divergence against the streaming lanes, no second pass over HBM);
+//   * survivors are written back compacted IN PLACE (write cursor <= read cursor), absorbed particles simply vanish;
+//   * entering particles are appended to the segment in (reservoir, mode) order, so a segment is a few sorted runs of
+//     neighbouring modes and its mode gathers hit L1/L2 instead of the Infinity Cache.
 #pragma once
 #include "nk_device.h"
 
 // =================================================================================== LDS carve-up
+struct NkEvBuf {          // parked boundary-event particles of the workgroup
+    double *x, *y, *z, *occ, *nts;
+    unsigned long long *pid;
+    int *mode, *facet;
+};
 struct NkLds {
     double *Tsv, *cen;
     NkBins bins;
     const double *planes, *faces;
     const NkFacet *facets;
+    NkEvBuf ev;
+    int *wtot;            // [2][8] per-wave counts of the block prefix sums (double-buffered)
 };
 
-__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, bool geom) {
+__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, bool geom, bool evbuf) {
     int Fl = (geom && F <= NK_LDS_FACES) ? F : 0;
     int Pl = Fl ? NP : 0;
     int Fcl = (geom && Fc <= NK_LDS_FACES) ? Fc : 0;
     size_t nd = (size_t)S + 3 * S + NK_NREP * S + NK_NREP * 3 * S + 4 * R + (size_t)Fl * NK_FACE_DOUBLES +
-                (size_t)Pl * NK_PLANE_DOUBLES;
-    size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) + (size_t)(NK_NREP * S + R + 1) * 4;
+                (size_t)Pl * NK_PLANE_DOUBLES + (evbuf ? 6 * NK_EVCAP : 0);
+    size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) + (size_t)(NK_NREP * S + R + 1 + 16 + (evbuf ? 2 * NK_EVCAP : 0)) * 4;
     return (bytes + 15) & ~(size_t)15;
 }
 
 // Cooperative fill of the read-only tables and zeroing of the bins; ends with a barrier.  GEOM = also stage the
-// ray-casting tables (kernels that never cast rays skip them).
-template <bool GEOM>
+// ray-casting tables; EVBUF = carve the event buffer.
+template <bool GEOM, bool EVBUF>
 __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem, NkLds &L) {
     const int S = d.S, R = d.R;
     const int Fl = (GEOM && d.F <= NK_LDS_FACES) ? d.F : 0;
@@ -59,11 +72,18 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     L.bins.resb = p; p += 4 * R;
     double *faces = p; p += (size_t)Fl * NK_FACE_DOUBLES;
     double *planes = p; p += (size_t)Pl * NK_PLANE_DOUBLES;
+    if (EVBUF) {
+        L.ev.x = p; p += NK_EVCAP; L.ev.y = p; p += NK_EVCAP; L.ev.z = p; p += NK_EVCAP;
+        L.ev.occ = p; p += NK_EVCAP; L.ev.nts = p; p += NK_EVCAP;
+        L.ev.pid = (unsigned long long *)p; p += NK_EVCAP;
+    }
     NkFacet *facets = (NkFacet *)p;
     unsigned int *u = (unsigned int *)(facets + Fcl);
     L.bins.N = u; u += NK_NREP * S;
     L.bins.nleave = u; u += R;
-    L.bins.misc = u;
+    L.bins.misc = u; u += 1;
+    L.wtot = (int *)u; u += 16;
+    if (EVBUF) { L.ev.mode = (int *)u; u += NK_EVCAP; L.ev.facet = (int *)u; u += NK_EVCAP; }
     const int t = threadIdx.x;
     for (int i = t; i < S; i += NK_WG) L.Tsv[i] = d.T_sv[i];
     for (int i = t; i < 3 * S; i += NK_WG) L.cen[i] = d.centers[i];
@@ -104,56 +124,105 @@ __device__ __forceinline__ void nk_lds_flush(const NkDev &d, const NkLds &L, int
     }
 }
 
-// ========================================================================================= kernels
+// Exclusive prefix over the workgroup of two predicates at once (ballot + per-wave totals in LDS, one barrier).
+// `parity` alternates between calls so that the per-wave totals of consecutive calls never alias.
+__device__ __forceinline__ void nk_prefix2(bool a, bool b, int *wtot, int parity, int &offA, int &totA, int &offB,
+                                           int &totB) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long ma = __ballot(a), mb = __ballot(b);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    offA = __popcll(ma & lower);
+    offB = __popcll(mb & lower);
+    if (lane == 0) { wtot[parity * 8 + wave] = __popcll(ma); wtot[parity * 8 + 4 + wave] = __popcll(mb); }
+    __syncthreads();
+    totA = 0; totB = 0;
+#pragma unroll
+    for (int w = 0; w < NK_WG / 64; ++w) {
+        const int ca = wtot[parity * 8 + w], cb = wtot[parity * 8 + 4 + w];
+        if (w < wave) { offA += ca; offB += cb; }
+        totA += ca; totB += cb;
+    }
+}
+
 // Deferred lifetime_scattering (Population.py:1701-1710) for one particle.
-__device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const NkMode &rec, double x, double y, double z,
-                                           double occ, int mode) {
+// The mode record is passed as two 32-byte halves {omega, vx, vy, vz} {tau0..tau3} (two dwordx4 pairs, no struct copy).
+__device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const double4 &ra, const double4 &rb, double x,
+                                           double y, double z, double occ, int mode) {
     double T = nk_interp_T(d, L.cen, L.Tsv, x, y, z, -1);
-    double tau = nk_lifetime(d, rec, T, mode);
-    double n0 = nk_occupation(d, T, rec.omega);
+    double tau = nk_lifetime(d, rb.x, rb.y, rb.z, rb.w, T, mode);
+    double n0 = nk_occupation(d, T, ra.x);
     return (tau > 0.0) ? n0 + (occ - n0) * exp(-d.dt / tau) : n0;
 }
 
-// The streaming kernel: every live slot once per step.
-__global__ __launch_bounds__(NK_WG) void k_step(NkDev d, int do_relax, int do_flux) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    NkLds L;
-    nk_lds_setup<false>(d, smem, L);
-    const int64_t n = *d.n_slots;
-    const int rep = threadIdx.x & (NK_NREP - 1);
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    // Software pipeline: the next slot's state is requested before this slot's arithmetic starts, so the HBM round
-    // trip of iteration k+1 overlaps the exp/divide chains of iteration k (the kernel is latency-bound: 86 % of wave
-    // cycles were s_waitcnt stalls without it).
-    int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
-    int modeN = -1;
-    double xN = 0, yN = 0, zN = 0, occN = 0, ntsN = 0;
-    if (i < n) { modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i]; }
-    for (; i < n; i += stride) {
-        const int mode = modeN;
-        double x = xN, y = yN, z = zN, occ = occN, nts = ntsN;
-        NkMode rec = d.modetab[(mode >= 0 && !(d.dbg & 4)) ? mode : 0];   // gather first, prefetch behind it (vmcnt is in-order)
-        if (d.dbg & 4) { rec.omega = 10.0 + (mode & 63); rec.vx = (mode & 7) - 3.5; rec.vy = ((mode >> 3) & 7) - 3.5; rec.vz = ((mode >> 6) & 7) - 3.5; }
-        const int64_t in = i + stride;
-        if (in < n) { modeN = d.mode[in]; xN = d.x[in]; yN = d.y[in]; zN = d.z[in]; occN = d.occ[in]; ntsN = d.nts[in]; }
-        if (mode < 0) continue;                                   // dead slot (absorbed, not yet reused)
-        if (do_relax && !(d.dbg & 16)) occ = nk_relax(d, L, rec, x, y, z, occ, mode);
-        x += rec.vx * d.dt; y += rec.vy * d.dt; z += rec.vz * d.dt;                 // drift, Population.py:793
-        nts -= 1.0;                                                                 // :795
-        if (!(d.dbg & 8)) { d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts; }
-        if (do_relax) d.occ[i] = occ;
-        if (nts < 0.0) {
-            if (!(d.dbg & 2)) nk_evq_push(d, i);                  // boundary reached inside this step -> k_events
-        } else if (!(d.dbg & 1)) {
-            nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, rec.omega, rec.vx, rec.vy, rec.vz, do_flux != 0, rep);
-        }
-    }
-    nk_lds_flush(d, L, blockIdx.x);
+__device__ __forceinline__ void nk_store(const NkDev &d, int64_t i, double x, double y, double z, double occ, double nts,
+                                         int mode, int facet, unsigned long long pid) {
+    d.x[i] = x; d.y[i] = y; d.z[i] = z; d.occ[i] = occ; d.nts[i] = nts;
+    d.mode[i] = mode; d.facet[i] = facet; d.pid[i] = pid;
 }
 
+// Process the parked event particles 256 at a time (all of them when keep == 0, only full batches when keep == 255):
+// boundary event loop, tally, append the survivors at the segment's write cursor.  Uniform control flow.
+__device__ __forceinline__ void nk_drain(const NkDev &d, NkLds &L, int &ev_n, int keep, int64_t base, int &w,
+                                         int &parity, uint32_t step, bool do_flux, int rep) {
+    while (ev_n > keep) {
+        const int n = ev_n >= NK_WG ? NK_WG : ev_n;
+        const int e = ev_n - n + (int)threadIdx.x;
+        const bool act = (int)threadIdx.x < n;
+        NkParticle p;
+        unsigned long long pid = 0;
+        p.alive = false;
+        if (act) {
+            p.x = L.ev.x[e]; p.y = L.ev.y[e]; p.z = L.ev.z[e]; p.occ = L.ev.occ[e]; p.nts = L.ev.nts[e];
+            p.mode = L.ev.mode[e]; p.facet = L.ev.facet[e]; pid = L.ev.pid[e];
+            const NkMode *rec = d.modetab + p.mode;
+            p.omega = rec->omega; p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
+            p.alive = true;
+            nk_events(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.bins, p, pid, step);
+        }
+        const bool alive = act && p.alive;
+        if (alive) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
+        int off, tot, o2, t2;
+        nk_prefix2(alive, false, L.wtot, parity, off, tot, o2, t2);
+        if (alive) {
+            if (w + off < d.segcap) nk_store(d, base + w + off, p.x, p.y, p.z, p.occ, p.nts, p.mode, p.facet, pid);
+            else *d.overflow = 1;
+        }
+        w += tot;
+        ev_n -= n;
+        parity ^= 1;
+        __syncthreads();              // the popped entries may be overwritten by the next pushes
+    }
+}
+
+// Hand one tile's particles over: `done` lanes are final (tally + compacted store), `ev` lanes are parked in LDS.
+__device__ __forceinline__ void nk_commit_tile(const NkDev &d, NkLds &L, bool done, bool ev, double x, double y, double z,
+                                               double occ, double nts, int mode, int facet, unsigned long long pid,
+                                               double omega, double vx, double vy, double vz, int &ev_n, int64_t base,
+                                               int &w, int &parity, uint32_t step, bool do_flux, int rep) {
+    if (done) nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, omega, vx, vy, vz, do_flux, rep);
+    int offD, totD, offE, totE;
+    nk_prefix2(done, ev, L.wtot, parity, offD, totD, offE, totE);
+    if (done) {
+        if (w + offD < d.segcap) nk_store(d, base + w + offD, x, y, z, occ, nts, mode, facet, pid);
+        else *d.overflow = 1;
+    }
+    if (ev) {
+        const int e = ev_n + offE;
+        L.ev.x[e] = x; L.ev.y[e] = y; L.ev.z[e] = z; L.ev.occ[e] = occ; L.ev.nts[e] = nts;
+        L.ev.mode[e] = mode; L.ev.facet[e] = facet; L.ev.pid[e] = pid;
+    }
+    w += totD;
+    ev_n += totE;
+    parity ^= 1;
+    __syncthreads();
+    nk_drain(d, L, ev_n, NK_WG - 1, base, w, parity, step, do_flux, rep);
+}
+
+// ========================================================================================= kernels
 // Which modes enter at each reservoir this step, and how many particles of each:
 // fill_reservoirs 'constant' (Population.py:358-370) / 'fixed_rate' (:408-420).  One lane per (reservoir, mode);
-// every entering particle gets one 64-bit record (rm << 12 | level) in spawn_list.
+// every entering particle gets one 64-bit record (rm << 12 | level) in spawn_list, in (reservoir, mode) order within a
+// workgroup's chunk.
 __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
     const int64_t RM = (int64_t)d.R * d.M;
     const int64_t rm = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
@@ -179,12 +248,11 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
         if (d.nranks == 1) c_mine = c;
         else for (int level = c; level >= 1; --level) c_mine += (((rm + level + (int64_t)step) % d.nranks) == d.rank);
     }
-    // wave-aggregated allocation in spawn_list: inclusive scan over the 64 lanes, one atomic per wave
+    // allocation in spawn_list: wave scan, then ONE global atomic per workgroup (a hot counter serves ~90 atomics/us)
     int incl = c_mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     const int total = __shfl(incl, 63, 64);
-    // one global atomic per workgroup (a single hot counter serves only ~90 atomics/us)
     __shared__ int wsum[NK_WG / 64];
     __shared__ int bbase;
     const int wave = threadIdx.x >> 6;
@@ -207,93 +275,106 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
     }
 }
 
-// One lane per entering particle: position on the facet (Mesh.sample_surface, Mesh.py:923-951), entry time
-// (Population.py:391-394 / :440-443), first boundary, advance by the time spent inside (:535-536).
-__global__ __launch_bounds__(NK_WG) void k_spawn(NkDev d, uint32_t step, int do_flux, int row0) {
+// The sweep: persistent workgroups, each taking segments b, b + grid, ...
+__global__ __launch_bounds__(NK_WG) void k_sweep(NkDev d, uint32_t step, int do_relax, int do_flux_i) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<true>(d, smem, L);
-    int64_t total = *d.alloc_count;
+    nk_lds_setup<true, true>(d, smem, L);
+    const bool do_flux = do_flux_i != 0;
+    const int rep = threadIdx.x & (NK_NREP - 1);
+    const int tid = threadIdx.x;
+    int parity = 0;
+    int64_t total = d.R > 0 ? (int64_t)*d.alloc_count : 0;
     if (total > d.spawn_cap) total = d.spawn_cap;
-    const unsigned long long head = *d.fl_head;
-    const int64_t avail = *d.fl_avail;
-    const int64_t ns0 = *d.n_slots;
-    const int rep = threadIdx.x & (NK_NREP - 1);
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    if (threadIdx.x == 0 && blockIdx.x == 0) L.bins.misc[0] = (unsigned int)total;   // "emitted" column
-    for (int64_t g = (int64_t)blockIdx.x * NK_WG + threadIdx.x; g < total; g += stride) {
-        const uint64_t recd = d.spawn_list[g];
-        const int64_t rm = (int64_t)(recd >> 12);
-        const int level = (int)(recd & 0xFFFu);
-        const int r = (int)(rm / d.M), m = (int)(rm - (int64_t)r * d.M);
-        const int64_t slot = g < avail ? (int64_t)d.free_ring[(head + (unsigned long long)g) % (unsigned long long)d.cap]
-                                       : ns0 + (g - avail);
-        if (slot >= d.cap) { *d.overflow = 1; continue; }
-        const uint64_t pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level;
-        double uf, us, ur, ut;
-        nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
-        nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
-        const double prob = d.enter_prob[rm];
-        const double dt_in = (level == 1) ? d.dt * (1.0 - (d.res_cval[rm] / prob))
-                                          : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
-        const int facet = d.res_facet[r];
-        const int f0 = d.facet_face_off[facet], nf = d.facet_face_off[facet + 1] - f0;
-        int a = nk_ss_right(d.facet_face_cdf + f0, nf, uf);                          // np.random.choice, Mesh.py:937
-        a = a > nf - 1 ? nf - 1 : a;
-        const double *vx = d.face_verts + 9 * (int64_t)d.facet_face_idx[f0 + a];
-        const double sq = sqrt(us);
-        const double a0 = 1.0 - sq, a1 = (1.0 - ur) * sq, a2 = ur * sq;              // Mesh.py:945-947
-        const double x0 = a0 * vx[0] + a1 * vx[3] + a2 * vx[6];
-        const double y0 = a0 * vx[1] + a1 * vx[4] + a2 * vx[7];
-        const double z0 = a0 * vx[2] + a1 * vx[5] + a2 * vx[8];
-        const NkMode rec = d.modetab[m];
-        const double occ = nk_occupation(d, d.res_T[r], rec.omega);                  // Population.py:506
-        double tc; int fcn;
-        nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x0, y0, z0, rec.vx, rec.vy, rec.vz, tc, fcn);
-        const double nts = tc / d.dt - dt_in / d.dt;                                 // :535
-        const double x = x0 + rec.vx * dt_in, y = y0 + rec.vy * dt_in, z = z0 + rec.vz * dt_in;   // :536
-        d.x[slot] = x; d.y[slot] = y; d.z[slot] = z; d.occ[slot] = occ; d.nts[slot] = nts;
-        d.mode[slot] = m; d.facet[slot] = fcn; d.pid[slot] = pid;
-        if (nts < 0.0) {
-            nk_evq_push(d, slot);
-        } else {
-            nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, rec.omega, rec.vx, rec.vy, rec.vz, do_flux != 0, rep);
+    const int64_t total_free = d.seg_free_prefix[d.nseg];
+    if (total > total_free) { total = total_free; if (tid == 0) *d.overflow = 1; }
+    if (tid == 0 && blockIdx.x == 0) L.bins.misc[0] = (unsigned int)total;          // "emitted" column
+    for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg];
+        int w = 0, ev_n = 0;
+        // ---- phase A: the particles already in the segment.  Next tile requested before this tile's arithmetic.
+        int modeN = 0, facetN = 0;
+        double xN = 0, yN = 0, zN = 0, occN = 0, ntsN = 0;
+        unsigned long long pidN = 0;
+        if (tid < count) {
+            const int64_t i = base + tid;
+            modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
+            facetN = d.facet[i]; pidN = d.pid[i];
         }
-    }
-    nk_lds_flush(d, L, row0 + blockIdx.x);
-}
-
-// One lane per queued particle: the boundary event loop, then the tally (or the free ring if it was absorbed).
-__global__ __launch_bounds__(NK_WG) void k_events(NkDev d, uint32_t step, int do_flux, int row0) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    NkLds L;
-    nk_lds_setup<true>(d, smem, L);
-    // workgroup b drains shard b % SHARDS together with the other workgroups of the same residue
-    const int shard = blockIdx.x & (NK_EVQ_SHARDS - 1);
-    int64_t n = d.evq_count[shard * NK_EVQ_PAD];
-    if (n > d.evq_seg) n = d.evq_seg;
-    const int32_t *queue = d.evq + (int64_t)shard * d.evq_seg;
-    const int rep = threadIdx.x & (NK_NREP - 1);
-    const int64_t stride = (int64_t)(gridDim.x / NK_EVQ_SHARDS) * NK_WG;
-    for (int64_t q = (int64_t)(blockIdx.x / NK_EVQ_SHARDS) * NK_WG + threadIdx.x; q < n; q += stride) {
-        const int64_t i = queue[q];
-        NkParticle p;
-        p.x = d.x[i]; p.y = d.y[i]; p.z = d.z[i]; p.occ = d.occ[i]; p.nts = d.nts[i];
-        p.mode = d.mode[i]; p.facet = d.facet[i]; p.alive = true;
-        const NkMode *rec = d.modetab + p.mode;
-        p.omega = rec->omega; p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
-        nk_events(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.bins, p, d.pid[i], step);
-        if (p.alive) {
-            nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux != 0, rep);
-            d.x[i] = p.x; d.y[i] = p.y; d.z[i] = p.z; d.occ[i] = p.occ; d.nts[i] = p.nts;
-            d.mode[i] = p.mode; d.facet[i] = p.facet;
-        } else {
-            d.mode[i] = -1;
-            unsigned long long t = atomicAdd(d.fl_tail, 1ull);
-            d.free_ring[t % (unsigned long long)d.cap] = (int32_t)i;
+        for (int r = 0; r < count; r += NK_WG) {
+            const bool act = r + tid < count;
+            const int mode = modeN, facet = facetN;
+            double x = xN, y = yN, z = zN, occ = occN, nts = ntsN;
+            const unsigned long long pid = pidN;
+            const double4 *mrec = reinterpret_cast<const double4 *>(d.modetab + (act ? mode : 0));
+            const double4 ra = mrec[0], rb = mrec[1];                                // {omega, v} {tau rows}
+            if (r + NK_WG + tid < count) {
+                const int64_t i = base + r + NK_WG + tid;
+                modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
+                facetN = d.facet[i]; pidN = d.pid[i];
+            }
+            if (act) {
+                if (do_relax) occ = nk_relax(d, L, ra, rb, x, y, z, occ, mode);
+                x += ra.y * d.dt; y += ra.z * d.dt; z += ra.w * d.dt;               // drift, Population.py:793
+                nts -= 1.0;                                                         // :795
+            }
+            const bool ev = act && nts < 0.0;                                      // boundary reached inside this step
+            nk_commit_tile(d, L, act && !ev, ev, x, y, z, occ, nts, mode, facet, pid, ra.x, ra.y, ra.z, ra.w, ev_n, base, w,
+                           parity, step, do_flux, rep);
         }
+        // ---- phase B: this segment's share of the entering particles (Mesh.sample_surface, Mesh.py:923-951; entry
+        // times Population.py:391-394 / :440-443; add_reservoir_particles :525-552)
+        // dealt in proportion to the segment's free space (snapshot of the previous step): self-balancing, and the
+        // share always fits.  128-bit-safe: total, prefix < 2^31.
+        const int64_t g0 = total_free > 0 ? total * d.seg_free_prefix[seg] / total_free : 0;
+        const int64_t g1 = total_free > 0 ? total * d.seg_free_prefix[seg + 1] / total_free : 0;
+        for (int64_t gb = g0; gb < g1; gb += NK_WG) {
+            const int64_t g = gb + tid;
+            const bool act = g < g1;
+            double x = 0, y = 0, z = 0, occ = 0, nts = 0, omega = 0, vx = 0, vy = 0, vz = 0;
+            int m = 0, fcn = -1;
+            unsigned long long pid = 0;
+            if (act) {
+                const uint64_t recd = d.spawn_list[g];
+                const int64_t rm = (int64_t)(recd >> 12);
+                const int level = (int)(recd & 0xFFFu);
+                const int r = (int)(rm / d.M);
+                m = (int)(rm - (int64_t)r * d.M);
+                pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level;
+                double uf, us, ur, ut;
+                nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
+                nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
+                const double prob = d.enter_prob[rm];
+                const double dt_in = (level == 1) ? d.dt * (1.0 - (d.res_cval[rm] / prob))
+                                                  : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
+                const int facet = d.res_facet[r];
+                const int f0 = d.facet_face_off[facet], nf = d.facet_face_off[facet + 1] - f0;
+                int a = nk_ss_right(d.facet_face_cdf + f0, nf, uf);                  // np.random.choice, Mesh.py:937
+                a = a > nf - 1 ? nf - 1 : a;
+                const double *fv = d.face_verts + 9 * (int64_t)d.facet_face_idx[f0 + a];
+                const double sq = sqrt(us);
+                const double a0 = 1.0 - sq, a1 = (1.0 - ur) * sq, a2 = ur * sq;      // Mesh.py:945-947
+                const double x0 = a0 * fv[0] + a1 * fv[3] + a2 * fv[6];
+                const double y0 = a0 * fv[1] + a1 * fv[4] + a2 * fv[7];
+                const double z0 = a0 * fv[2] + a1 * fv[5] + a2 * fv[8];
+                const NkMode *rec = d.modetab + m;
+                omega = rec->omega; vx = rec->vx; vy = rec->vy; vz = rec->vz;
+                occ = nk_occupation(d, d.res_T[r], omega);                           // Population.py:506
+                double tc;
+                nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x0, y0, z0, vx, vy, vz, tc, fcn);
+                nts = tc / d.dt - dt_in / d.dt;                                      // :535
+                x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;       // :536
+            }
+            const bool ev = act && nts < 0.0;
+            nk_commit_tile(d, L, act && !ev, ev, x, y, z, occ, nts, m, fcn, pid, omega, vx, vy, vz, ev_n, base, w, parity,
+                           step, do_flux, rep);
+        }
+        // ---- phase C: whatever is still parked
+        nk_drain(d, L, ev_n, 0, base, w, parity, step, do_flux, rep);
+        if (tid == 0) d.seg_count[seg] = w < d.segcap ? w : d.segcap;
     }
-    nk_lds_flush(d, L, row0 + blockIdx.x);
+    nk_lds_flush(d, L, blockIdx.x);
 }
 
 // Column sums of the tally rows, fixed order -> bitwise reproducible for a given grid.
@@ -311,9 +392,9 @@ __global__ __launch_bounds__(NK_WG) void k_reduce(const double *partials, int ro
     if (threadIdx.x == 0) acc[b] = sh[0];
 }
 
-// Normalise, invert E(T), publish the new subvolume temperatures, bookkeeping, history row.
+// Normalise, invert E(T), publish the new subvolume temperatures, history row.
 // calculate_energy (Population.py:719-728) + refresh_temperatures (:692).
-// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, n_slots, free slots, overflow
+// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, live (this rank), 0, overflow
 __global__ void k_update(NkDev d, const double *acc, double *hist_row, int do_flux) {
     const int t = threadIdx.x;
     const int S = d.S, NB = d.NB;
@@ -333,22 +414,29 @@ __global__ void k_update(NkDev d, const double *acc, double *hist_row, int do_fl
     for (int b = t; b < NB; b += blockDim.x) hist_row[b] = acc[b];
     __syncthreads();
     if (t < S) d.T_sv[t] = Tnew;
-    if (t < NK_EVQ_SHARDS) d.evq_count[t * NK_EVQ_PAD] = 0;
+    // free-space prefix over the segments for the next step's spawn distribution
+    {
+        __shared__ long long part[512];
+        const int per = (d.nseg + (int)blockDim.x - 1) / (int)blockDim.x;
+        const int lo = t * per, hi = (lo + per < d.nseg) ? lo + per : d.nseg;
+        long long sum = 0;
+        for (int k = lo; k < hi; ++k) sum += d.segcap - d.seg_count[k];
+        part[t] = sum;
+        __syncthreads();
+        if (t == 0) {
+            long long run = 0;
+            for (int k = 0; k < (int)blockDim.x; ++k) { long long v = part[k]; part[k] = run; run += v; }
+            d.seg_free_prefix[d.nseg] = run;
+        }
+        __syncthreads();
+        long long run = part[t];
+        for (int k = lo; k < hi; ++k) { d.seg_free_prefix[k] = run; run += d.segcap - d.seg_count[k]; }
+    }
     if (t == 0) {
-        int64_t em = *d.alloc_count;
-        if (em > d.spawn_cap) em = d.spawn_cap;
-        const int64_t avail = *d.fl_avail;
-        const int64_t popped = em < avail ? em : avail;
-        int64_t ns = *d.n_slots + (em - popped);
-        if (ns > d.cap) ns = d.cap;
-        const unsigned long long head = *d.fl_head + (unsigned long long)popped;
-        *d.fl_head = head;
-        *d.n_slots = ns;
-        *d.fl_avail = (int64_t)(*d.fl_tail - head);
         *d.alloc_count = 0;
         hist_row[NB + 2 * S + 0] = (double)do_flux;
-        hist_row[NB + 2 * S + 1] = (double)ns;
-        hist_row[NB + 2 * S + 2] = (double)(*d.fl_tail - head);
+        hist_row[NB + 2 * S + 1] = 0.0;
+        hist_row[NB + 2 * S + 2] = 0.0;
         hist_row[NB + 2 * S + 3] = (double)*d.overflow;
     }
 }
@@ -357,14 +445,17 @@ __global__ void k_update(NkDev d, const double *acc, double *hist_row, int do_fl
 __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<false>(d, smem, L);
-    const int64_t n = *d.n_slots;
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode = d.mode[i];
-        if (mode < 0) continue;
-        const NkMode rec = d.modetab[mode];
-        d.occ[i] = nk_relax(d, L, rec, d.x[i], d.y[i], d.z[i], d.occ[i], mode);
+    nk_lds_setup<false, false>(d, smem, L);
+    for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg];
+        for (int k = threadIdx.x; k < count; k += NK_WG) {
+            const int64_t i = base + k;
+            const int mode = d.mode[i];
+            const double4 *mrec = reinterpret_cast<const double4 *>(d.modetab + mode);
+            const double4 ra = mrec[0], rb = mrec[1];
+            d.occ[i] = nk_relax(d, L, ra, rb, d.x[i], d.y[i], d.z[i], d.occ[i], mode);
+        }
     }
 }
 
@@ -372,17 +463,18 @@ __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d) {
 __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<true>(d, smem, L);
-    const int64_t n = *d.n_slots;
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode = d.mode[i];
-        if (mode < 0) continue;
-        const NkMode *rec = d.modetab + mode;
-        double tc; int fc;
-        nk_find_boundary(L.planes, L.faces, d.NP, d.tol, d.x[i], d.y[i], d.z[i], rec->vx, rec->vy, rec->vz, tc, fc);
-        d.nts[i] = tc / d.dt;
-        d.facet[i] = fc;
+    nk_lds_setup<true, false>(d, smem, L);
+    for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg];
+        for (int k = threadIdx.x; k < count; k += NK_WG) {
+            const int64_t i = base + k;
+            const NkMode *rec = d.modetab + d.mode[i];
+            double tc; int fc;
+            nk_find_boundary(L.planes, L.faces, d.NP, d.tol, d.x[i], d.y[i], d.z[i], rec->vx, rec->vy, rec->vz, tc, fc);
+            d.nts[i] = tc / d.dt;
+            d.facet[i] = fc;
+        }
     }
 }
 
@@ -390,32 +482,33 @@ __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
 __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<true>(d, smem, L);
-    const int64_t n = *d.n_slots;
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode = d.mode[i];
-        if (mode < 0) continue;
-        double x = d.x[i], y = d.y[i], z = d.z[i];
-        bool out = x < d.bbox[0] - 1e-10 || y < d.bbox[1] - 1e-10 || z < d.bbox[2] - 1e-10 || x > d.bbox[3] + 1e-10 ||
-                   y > d.bbox[4] + 1e-10 || z > d.bbox[5] + 1e-10;
-        if (!out) continue;
-        const uint64_t pid = d.pid[i];
-        double u[6];
-        nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 0, u[0], u[1]);
-        nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 1, u[2], u[3]);
-        nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 2, u[4], u[5]);
-        int s = nk_ss_right(d.simplex_cdf, d.nS, u[0]);
-        s = s > d.nS - 1 ? d.nS - 1 : s;
-        double a[4], asum = 0.0;
-        for (int k = 0; k < 4; ++k) { a[k] = -log(u[1 + k]); asum += a[k]; }
-        const double *sp = d.simplex_pts + 12 * (int64_t)s;
-        x = y = z = 0.0;
-        for (int k = 0; k < 4; ++k) { double w = a[k] / asum; x += w * sp[3 * k]; y += w * sp[3 * k + 1]; z += w * sp[3 * k + 2]; }
-        const NkMode *rec = d.modetab + mode;
-        double tc; int fc;
-        nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
-        d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = tc / d.dt; d.facet[i] = fc;
+    nk_lds_setup<true, false>(d, smem, L);
+    for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg];
+        for (int k = threadIdx.x; k < count; k += NK_WG) {
+            const int64_t i = base + k;
+            double x = d.x[i], y = d.y[i], z = d.z[i];
+            bool out = x < d.bbox[0] - 1e-10 || y < d.bbox[1] - 1e-10 || z < d.bbox[2] - 1e-10 || x > d.bbox[3] + 1e-10 ||
+                       y > d.bbox[4] + 1e-10 || z > d.bbox[5] + 1e-10;
+            if (!out) continue;
+            const uint64_t pid = d.pid[i];
+            double u[6];
+            nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 0, u[0], u[1]);
+            nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 1, u[2], u[3]);
+            nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 2, u[4], u[5]);
+            int s = nk_ss_right(d.simplex_cdf, d.nS, u[0]);
+            s = s > d.nS - 1 ? d.nS - 1 : s;
+            double a[4], asum = 0.0;
+            for (int q = 0; q < 4; ++q) { a[q] = -log(u[1 + q]); asum += a[q]; }
+            const double *sp = d.simplex_pts + 12 * (int64_t)s;
+            x = y = z = 0.0;
+            for (int q = 0; q < 4; ++q) { double wq = a[q] / asum; x += wq * sp[3 * q]; y += wq * sp[3 * q + 1]; z += wq * sp[3 * q + 2]; }
+            const NkMode *rec = d.modetab + d.mode[i];
+            double tc; int fc;
+            nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
+            d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = tc / d.dt; d.facet[i] = fc;
+        }
     }
 }
 
@@ -438,7 +531,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n,
                                                              double *xc, double *tc, int32_t *fc) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<true>(d, smem, L);
+    nk_lds_setup<true, false>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
     double t; int f;
@@ -457,7 +550,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, int what, int64_t n
     if (i >= n) return;
     switch (what) {
         case 0: out[i] = nk_occupation(d, a[i], d.modetab[mode[i]].omega); break;
-        case 1: { const NkMode rec = d.modetab[mode[i]]; out[i] = nk_lifetime(d, rec, a[i], mode[i]); break; }
+        case 1: { const NkMode *rec = d.modetab + mode[i]; out[i] = nk_lifetime(d, rec->tau[0], rec->tau[1], rec->tau[2], rec->tau[3], a[i], mode[i]); break; }
         case 2: out[i] = nk_T_of_E(d, a[i]); break;
         case 3: out[i] = nk_E_of_T(d, a[i]); break;
         default: out[i] = nk_interp_T(d, d.centers, d.T_sv, a[3 * i], a[3 * i + 1], a[3 * i + 2], -1); break;
@@ -474,17 +567,20 @@ __global__ __launch_bounds__(NK_WG) void k_tap_reflect(NkDev d, int64_t n, const
                n_in[i], om_in[i], r_spec[i], r_deg ? r_deg[i] : 0.0, r_diff[i], mo, no, oo);
     mode_out[i] = mo; n_out[i] = no; om_out[i] = oo;
 }
-// Counter calibration: the same coalesced 8-byte-per-lane sweep as k_step with a KNOWN byte count
-// (44 B read + 32 B written per slot), so FETCH_SIZE / WRITE_SIZE readings of k_step can be scaled
-// (MI355X_MICROARCH.md: FETCH_SIZE is uncalibrated for accesses other than 16 B/lane).
+// Counter calibration: coalesced 8-byte-per-lane sweeps with a KNOWN byte count (44 B read + 32 B written per live
+// particle), so FETCH_SIZE / WRITE_SIZE readings of k_sweep can be scaled (MI355X_MICROARCH.md: FETCH_SIZE is
+// uncalibrated for accesses other than 16 B/lane).
 __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
-    const int64_t n = *d.n_slots;
-    const int64_t stride = (int64_t)gridDim.x * NK_WG;
-    for (int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x; i < n; i += stride) {
-        const int mode = d.mode[i];
-        double x = d.x[i], y = d.y[i], z = d.z[i], occ = d.occ[i], nts = d.nts[i];
-        if (mode == -123456789) { x += occ; }                     // keeps the occ load alive; never true
-        d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts;
+    for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg];
+        for (int k = threadIdx.x; k < count; k += NK_WG) {
+            const int64_t i = base + k;
+            const int mode = d.mode[i];
+            double x = d.x[i], y = d.y[i], z = d.z[i], occ = d.occ[i], nts = d.nts[i];
+            if (mode == -123456789) { x += occ; }                 // keeps the occ load alive; never true
+            d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts;
+        }
     }
 }
 __global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *out) {
