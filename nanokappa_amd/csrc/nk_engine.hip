@@ -78,10 +78,17 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 #define NK_UP(src, n, dst)                                                                             \
     do { int rc_ = nk_upload(ctx, src, n, dst); if (rc_) return rc_; } while (0)
 
+// 1 = ray-casting tables fit LDS, 2 = they stay in global memory
+static inline int nk_geom_mode(const nk_ctx *ctx) { return (ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES) ? 1 : 2; }
 static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool evbuf = false) {
     const NkDev &d = ctx->d;
-    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, geom, evbuf);
+    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, geom ? nk_geom_mode(ctx) : 0, evbuf);
 }
+#define NK_GEOM_LAUNCH(kernel, grid, lds, ...)                                                        \
+    do {                                                                                               \
+        if (nk_geom_mode(ctx) == 1) kernel<1><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);         \
+        else kernel<2><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);                                \
+    } while (0)
 static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
 
 // Choose the four lifetime rows packed into the mode records so that they bracket [T_lo, T_hi]; rebuild on change.
@@ -558,7 +565,7 @@ int nk_init_boundaries(nk_ctx *ctx) {
     int rc = nk_check_ready(ctx);
     if (rc) return rc;
     NK_HIP(hipSetDevice(ctx->device));
-    k_init_boundaries<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, true), ctx->stream>>>(ctx->d);
+    NK_GEOM_LAUNCH(k_init_boundaries, nk_sweep_grid(ctx), nk_lds(ctx, true), ctx->d);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
     return NK_OK;
@@ -591,7 +598,8 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     const int count_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
     if (ctx->g_sweep == 0) {                               // persistent grid = what the device keeps resident
         int per_cu = 0;
-        NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep, NK_WG, lds_w));
+        if (nk_geom_mode(ctx) == 1) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1>, NK_WG, lds_w));
+        else NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<2>, NK_WG, lds_w));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
         ctx->g_sweep = ctx->num_cu * per_cu;
@@ -608,14 +616,14 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         const uint32_t step = (uint32_t)ctx->step;
         if (ctx->params.contains_every > 0 && (ctx->step % ctx->params.contains_every) == 0 && d.nS > 0) {
             if ((rc = nk_flush_relax(ctx))) return rc;
-            k_contains<<<nk_sweep_grid(ctx), NK_WG, lds_g, ctx->stream>>>(d, step);
+            NK_GEOM_LAUNCH(k_contains, nk_sweep_grid(ctx), lds_g, d, step);
         }
         const int fe = ctx->params.flux_every;
         const int do_flux = (fe > 0 && ((ctx->step + 1) % fe) == 0) ? 1 : 0;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
         if (R > 0) k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
-        k_sweep<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, ctx->pending_relax ? 1 : 0, do_flux);
+        NK_GEOM_LAUNCH(k_sweep, g_sweep, lds_w, d, step, ctx->pending_relax ? 1 : 0, do_flux);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
         k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d.partials, g_sweep, NB, ctx->acc);
         if (ctx->comm) {
@@ -783,7 +791,7 @@ int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x, const double *v, d
     NK_DEV_IN(double, dx, x, n * 3); NK_DEV_IN(double, dv, v, n * 3);
     NK_DEV_IN(double, dxc, (double *)nullptr, n * 3); NK_DEV_IN(double, dtc, (double *)nullptr, n);
     NK_DEV_IN(int32_t, dfc, (int32_t *)nullptr, n);
-    k_tap_find_boundary<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, nk_lds(ctx, true), ctx->stream>>>(d, n, dx, dv, dxc, dtc, dfc);
+    NK_GEOM_LAUNCH(k_tap_find_boundary, (int)((n + NK_WG - 1) / NK_WG), nk_lds(ctx, true), d, n, dx, dv, dxc, dtc, dfc);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
     NK_DEV_OUT(double, dxc, xc, n * 3); NK_DEV_OUT(double, dtc, tc, n); NK_DEV_OUT(int32_t, dfc, fc, n);

@@ -46,24 +46,26 @@ struct NkLds {
     int *wtot;            // [2][8] per-wave counts of the block prefix sums (double-buffered)
 };
 
-__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, bool geom, bool evbuf) {
-    int Fl = (geom && F <= NK_LDS_FACES) ? F : 0;
+// geom: 0 = no ray-casting tables, 1 = planes/faces/facets staged in LDS, 2 = read from global memory (large meshes)
+__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, bool evbuf) {
+    int Fl = geom == 1 ? F : 0;
     int Pl = Fl ? NP : 0;
-    int Fcl = (geom && Fc <= NK_LDS_FACES) ? Fc : 0;
+    int Fcl = geom == 1 ? Fc : 0;
     size_t nd = (size_t)S + 3 * S + NK_NREP * S + NK_NREP * 3 * S + 4 * R + (size_t)Fl * NK_FACE_DOUBLES +
                 (size_t)Pl * NK_PLANE_DOUBLES + (evbuf ? 6 * NK_EVCAP : 0);
     size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) + (size_t)(NK_NREP * S + R + 1 + 16 + (evbuf ? 2 * NK_EVCAP : 0)) * 4;
     return (bytes + 15) & ~(size_t)15;
 }
 
-// Cooperative fill of the read-only tables and zeroing of the bins; ends with a barrier.  GEOM = also stage the
-// ray-casting tables; EVBUF = carve the event buffer.
-template <bool GEOM, bool EVBUF>
+// Cooperative fill of the read-only tables and zeroing of the bins; ends with a barrier.  GEOM as in nk_lds_bytes (a
+// compile-time choice, so that the table pointers are provably LDS and are read with ds_read, not flat loads);
+// EVBUF = carve the event buffer.
+template <int GEOM, bool EVBUF>
 __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem, NkLds &L) {
     const int S = d.S, R = d.R;
-    const int Fl = (GEOM && d.F <= NK_LDS_FACES) ? d.F : 0;
+    const int Fl = GEOM == 1 ? d.F : 0;
     const int Pl = Fl ? d.NP : 0;
-    const int Fcl = (GEOM && d.Fc <= NK_LDS_FACES) ? d.Fc : 0;
+    const int Fcl = GEOM == 1 ? d.Fc : 0;
     double *p = (double *)smem;
     L.Tsv = p; p += S;
     L.cen = p; p += 3 * S;
@@ -100,9 +102,8 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
         int32_t *dst = (int32_t *)facets;
         for (int i = t; i < nw; i += NK_WG) dst[i] = src[i];
     }
-    L.faces = Fl ? faces : d.faces;
-    L.planes = Fl ? planes : d.planes;
-    L.facets = Fcl ? facets : d.facets;
+    if (GEOM == 1) { L.faces = faces; L.planes = planes; L.facets = facets; }
+    else { L.faces = d.faces; L.planes = d.planes; L.facets = d.facets; }
     __syncthreads();
 }
 
@@ -158,64 +159,6 @@ __device__ __forceinline__ void nk_store(const NkDev &d, int64_t i, double x, do
                                          int mode, int facet, unsigned long long pid) {
     d.x[i] = x; d.y[i] = y; d.z[i] = z; d.occ[i] = occ; d.nts[i] = nts;
     d.mode[i] = mode; d.facet[i] = facet; d.pid[i] = pid;
-}
-
-// Process the parked event particles 256 at a time (all of them when keep == 0, only full batches when keep == 255):
-// boundary event loop, tally, append the survivors at the segment's write cursor.  Uniform control flow.
-__device__ __forceinline__ void nk_drain(const NkDev &d, NkLds &L, int &ev_n, int keep, int64_t base, int &w,
-                                         int &parity, uint32_t step, bool do_flux, int rep) {
-    while (ev_n > keep) {
-        const int n = ev_n >= NK_WG ? NK_WG : ev_n;
-        const int e = ev_n - n + (int)threadIdx.x;
-        const bool act = (int)threadIdx.x < n;
-        NkParticle p;
-        unsigned long long pid = 0;
-        p.alive = false;
-        if (act) {
-            p.x = L.ev.x[e]; p.y = L.ev.y[e]; p.z = L.ev.z[e]; p.occ = L.ev.occ[e]; p.nts = L.ev.nts[e];
-            p.mode = L.ev.mode[e]; p.facet = L.ev.facet[e]; pid = L.ev.pid[e];
-            const NkMode *rec = d.modetab + p.mode;
-            p.omega = rec->omega; p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
-            p.alive = true;
-            nk_events(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.bins, p, pid, step);
-        }
-        const bool alive = act && p.alive;
-        if (alive) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
-        int off, tot, o2, t2;
-        nk_prefix2(alive, false, L.wtot, parity, off, tot, o2, t2);
-        if (alive) {
-            if (w + off < d.segcap) nk_store(d, base + w + off, p.x, p.y, p.z, p.occ, p.nts, p.mode, p.facet, pid);
-            else *d.overflow = 1;
-        }
-        w += tot;
-        ev_n -= n;
-        parity ^= 1;
-        __syncthreads();              // the popped entries may be overwritten by the next pushes
-    }
-}
-
-// Hand one tile's particles over: `done` lanes are final (tally + compacted store), `ev` lanes are parked in LDS.
-__device__ __forceinline__ void nk_commit_tile(const NkDev &d, NkLds &L, bool done, bool ev, double x, double y, double z,
-                                               double occ, double nts, int mode, int facet, unsigned long long pid,
-                                               double omega, double vx, double vy, double vz, int &ev_n, int64_t base,
-                                               int &w, int &parity, uint32_t step, bool do_flux, int rep) {
-    if (done) nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, omega, vx, vy, vz, do_flux, rep);
-    int offD, totD, offE, totE;
-    nk_prefix2(done, ev, L.wtot, parity, offD, totD, offE, totE);
-    if (done) {
-        if (w + offD < d.segcap) nk_store(d, base + w + offD, x, y, z, occ, nts, mode, facet, pid);
-        else *d.overflow = 1;
-    }
-    if (ev) {
-        const int e = ev_n + offE;
-        L.ev.x[e] = x; L.ev.y[e] = y; L.ev.z[e] = z; L.ev.occ[e] = occ; L.ev.nts[e] = nts;
-        L.ev.mode[e] = mode; L.ev.facet[e] = facet; L.ev.pid[e] = pid;
-    }
-    w += totD;
-    ev_n += totE;
-    parity ^= 1;
-    __syncthreads();
-    nk_drain(d, L, ev_n, NK_WG - 1, base, w, parity, step, do_flux, rep);
 }
 
 // ========================================================================================= kernels
@@ -275,104 +218,159 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
     }
 }
 
-// The sweep: persistent workgroups, each taking segments b, b + grid, ...
-__global__ __launch_bounds__(NK_WG) void k_sweep(NkDev d, uint32_t step, int do_relax, int do_flux_i) {
+// The sweep: persistent WAVES, each taking segments w, w + n_waves, ...  A wave owns its segment and its slice of the
+// LDS event buffer, so the loop needs no workgroup barrier: the four waves of a workgroup only share the read-only
+// tables and the tally bins (LDS atomics).
+// Per segment one loop over 64-particle tiles: first the particles already there (phase A), then this segment's share
+// of the entering particles (phase B), then one empty tile that flushes the event buffer.  Every tile ends at the same
+// commit site: final particles are tallied and stored compacted at the write cursor, particles that meet a boundary
+// inside the step are parked in LDS, and whenever 64 are parked the whole wave processes them.
+#define NK_TILE 64
+#define NK_WAVE_EVCAP (NK_EVCAP / (NK_WG / 64))     // 128 parked particles per wave (< 64 pending + 64 new)
+template <int GEOM>
+__global__ __launch_bounds__(NK_WG, 3) void k_sweep(NkDev d, uint32_t step, int do_relax, int do_flux_i) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<true, true>(d, smem, L);
+    nk_lds_setup<GEOM, true>(d, smem, L);
     const bool do_flux = do_flux_i != 0;
-    const int rep = threadIdx.x & (NK_NREP - 1);
-    const int tid = threadIdx.x;
-    int parity = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rep = lane & (NK_NREP - 1);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const int eb = wave * NK_WAVE_EVCAP;                    // this wave's slice of the event buffer
     int64_t total = d.R > 0 ? (int64_t)*d.alloc_count : 0;
     if (total > d.spawn_cap) total = d.spawn_cap;
     const int64_t total_free = d.seg_free_prefix[d.nseg];
     if (total > total_free) { total = total_free; if (tid == 0) *d.overflow = 1; }
     if (tid == 0 && blockIdx.x == 0) L.bins.misc[0] = (unsigned int)total;          // "emitted" column
-    for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
+    const int nwaves = gridDim.x * (NK_WG / 64);
+    for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
+        // entering particles are dealt in proportion to the segment's free space (snapshot of the previous step):
+        // self-balancing, and the share always fits
+        const int64_t g0 = total_free > 0 ? total * d.seg_free_prefix[seg] / total_free : 0;
+        const int64_t g1 = total_free > 0 ? total * d.seg_free_prefix[seg + 1] / total_free : 0;
+        const int nA = (count + NK_TILE - 1) / NK_TILE, nB = (int)((g1 - g0 + NK_TILE - 1) / NK_TILE);
         int w = 0, ev_n = 0;
-        // ---- phase A: the particles already in the segment.  Next tile requested before this tile's arithmetic.
+        // next tile of phase A is requested before the current tile's arithmetic (the loop is latency-bound otherwise)
         int modeN = 0, facetN = 0;
         double xN = 0, yN = 0, zN = 0, occN = 0, ntsN = 0;
         unsigned long long pidN = 0;
-        if (tid < count) {
-            const int64_t i = base + tid;
+        if (lane < count) {
+            const int64_t i = base + lane;
             modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
             facetN = d.facet[i]; pidN = d.pid[i];
         }
-        for (int r = 0; r < count; r += NK_WG) {
-            const bool act = r + tid < count;
-            const int mode = modeN, facet = facetN;
-            double x = xN, y = yN, z = zN, occ = occN, nts = ntsN;
-            const unsigned long long pid = pidN;
-            const double4 *mrec = reinterpret_cast<const double4 *>(d.modetab + (act ? mode : 0));
-            const double4 ra = mrec[0], rb = mrec[1];                                // {omega, v} {tau rows}
-            if (r + NK_WG + tid < count) {
-                const int64_t i = base + r + NK_WG + tid;
-                modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
-                facetN = d.facet[i]; pidN = d.pid[i];
-            }
-            if (act) {
-                if (do_relax) occ = nk_relax(d, L, ra, rb, x, y, z, occ, mode);
-                x += ra.y * d.dt; y += ra.z * d.dt; z += ra.w * d.dt;               // drift, Population.py:793
-                nts -= 1.0;                                                         // :795
-            }
-            const bool ev = act && nts < 0.0;                                      // boundary reached inside this step
-            nk_commit_tile(d, L, act && !ev, ev, x, y, z, occ, nts, mode, facet, pid, ra.x, ra.y, ra.z, ra.w, ev_n, base, w,
-                           parity, step, do_flux, rep);
-        }
-        // ---- phase B: this segment's share of the entering particles (Mesh.sample_surface, Mesh.py:923-951; entry
-        // times Population.py:391-394 / :440-443; add_reservoir_particles :525-552)
-        // dealt in proportion to the segment's free space (snapshot of the previous step): self-balancing, and the
-        // share always fits.  128-bit-safe: total, prefix < 2^31.
-        const int64_t g0 = total_free > 0 ? total * d.seg_free_prefix[seg] / total_free : 0;
-        const int64_t g1 = total_free > 0 ? total * d.seg_free_prefix[seg + 1] / total_free : 0;
-        for (int64_t gb = g0; gb < g1; gb += NK_WG) {
-            const int64_t g = gb + tid;
-            const bool act = g < g1;
+        for (int t = 0; t <= nA + nB; ++t) {
+            bool act = false;
             double x = 0, y = 0, z = 0, occ = 0, nts = 0, omega = 0, vx = 0, vy = 0, vz = 0;
-            int m = 0, fcn = -1;
+            int mode = 0, facet = -1;
             unsigned long long pid = 0;
-            if (act) {
-                const uint64_t recd = d.spawn_list[g];
-                const int64_t rm = (int64_t)(recd >> 12);
-                const int level = (int)(recd & 0xFFFu);
-                const int r = (int)(rm / d.M);
-                m = (int)(rm - (int64_t)r * d.M);
-                pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level;
-                double uf, us, ur, ut;
-                nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
-                nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
-                const double prob = d.enter_prob[rm];
-                const double dt_in = (level == 1) ? d.dt * (1.0 - (d.res_cval[rm] / prob))
-                                                  : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
-                const int facet = d.res_facet[r];
-                const int f0 = d.facet_face_off[facet], nf = d.facet_face_off[facet + 1] - f0;
-                int a = nk_ss_right(d.facet_face_cdf + f0, nf, uf);                  // np.random.choice, Mesh.py:937
-                a = a > nf - 1 ? nf - 1 : a;
-                const double *fv = d.face_verts + 9 * (int64_t)d.facet_face_idx[f0 + a];
-                const double sq = sqrt(us);
-                const double a0 = 1.0 - sq, a1 = (1.0 - ur) * sq, a2 = ur * sq;      // Mesh.py:945-947
-                const double x0 = a0 * fv[0] + a1 * fv[3] + a2 * fv[6];
-                const double y0 = a0 * fv[1] + a1 * fv[4] + a2 * fv[7];
-                const double z0 = a0 * fv[2] + a1 * fv[5] + a2 * fv[8];
-                const NkMode *rec = d.modetab + m;
-                omega = rec->omega; vx = rec->vx; vy = rec->vy; vz = rec->vz;
-                occ = nk_occupation(d, d.res_T[r], omega);                           // Population.py:506
-                double tc;
-                nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x0, y0, z0, vx, vy, vz, tc, fcn);
-                nts = tc / d.dt - dt_in / d.dt;                                      // :535
-                x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;       // :536
+            if (t < nA) {
+                // ---- phase A: relax (deferred from the previous step), drift
+                const int r = t * NK_TILE;
+                act = r + lane < count;
+                mode = modeN; facet = facetN; x = xN; y = yN; z = zN; occ = occN; nts = ntsN; pid = pidN;
+                const double4 *mrec = reinterpret_cast<const double4 *>(d.modetab + (act ? mode : 0));
+                const double4 ra = mrec[0], rb = mrec[1];                            // {omega, v} {tau rows}
+                if (r + NK_TILE + lane < count) {
+                    const int64_t i = base + r + NK_TILE + lane;
+                    modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
+                    facetN = d.facet[i]; pidN = d.pid[i];
+                }
+                omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w;
+                if (act) {
+                    if (do_relax) occ = nk_relax(d, L, ra, rb, x, y, z, occ, mode);
+                    x += vx * d.dt; y += vy * d.dt; z += vz * d.dt;                 // drift, Population.py:793
+                    nts -= 1.0;                                                     // :795
+                }
+            } else if (t < nA + nB) {
+                // ---- phase B: an entering particle (Mesh.sample_surface, Mesh.py:923-951; entry times
+                // Population.py:391-394 / :440-443; add_reservoir_particles :525-552)
+                const int64_t g = g0 + (int64_t)(t - nA) * NK_TILE + lane;
+                act = g < g1;
+                if (act) {
+                    const uint64_t recd = d.spawn_list[g];
+                    const int64_t rm = (int64_t)(recd >> 12);
+                    const int level = (int)(recd & 0xFFFu);
+                    const int r = (int)(rm / d.M);
+                    mode = (int)(rm - (int64_t)r * d.M);
+                    pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level;
+                    double uf, us, ur, ut;
+                    nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
+                    nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
+                    const double prob = d.enter_prob[rm];
+                    const double dt_in = (level == 1) ? d.dt * (1.0 - (d.res_cval[rm] / prob))
+                                                      : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
+                    const int rf = d.res_facet[r];
+                    const int f0 = d.facet_face_off[rf], nf = d.facet_face_off[rf + 1] - f0;
+                    int a = nk_ss_right(d.facet_face_cdf + f0, nf, uf);              // np.random.choice, Mesh.py:937
+                    a = a > nf - 1 ? nf - 1 : a;
+                    const double *fv = d.face_verts + 9 * (int64_t)d.facet_face_idx[f0 + a];
+                    const double sq = sqrt(us);
+                    const double a0 = 1.0 - sq, a1 = (1.0 - ur) * sq, a2 = ur * sq;  // Mesh.py:945-947
+                    const double x0 = a0 * fv[0] + a1 * fv[3] + a2 * fv[6];
+                    const double y0 = a0 * fv[1] + a1 * fv[4] + a2 * fv[7];
+                    const double z0 = a0 * fv[2] + a1 * fv[5] + a2 * fv[8];
+                    const NkMode *rec = d.modetab + mode;
+                    omega = rec->omega; vx = rec->vx; vy = rec->vy; vz = rec->vz;
+                    occ = nk_occupation(d, d.res_T[r], omega);                       // Population.py:506
+                    double tc;
+                    nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x0, y0, z0, vx, vy, vz, tc, facet);
+                    nts = tc / d.dt - dt_in / d.dt;                                  // :535
+                    x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;   // :536
+                }
             }
+            // ---- commit: final particles -> tally + compacted store; boundary particles -> LDS buffer
             const bool ev = act && nts < 0.0;
-            nk_commit_tile(d, L, act && !ev, ev, x, y, z, occ, nts, m, fcn, pid, omega, vx, vy, vz, ev_n, base, w, parity,
-                           step, do_flux, rep);
+            const bool done = act && !ev;
+            if (done) nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, omega, vx, vy, vz, do_flux, rep);
+            const unsigned long long mD = __ballot(done), mE = __ballot(ev);
+            if (done) {
+                const int o = w + __popcll(mD & lower);
+                if (o < d.segcap) nk_store(d, base + o, x, y, z, occ, nts, mode, facet, pid);
+                else *d.overflow = 1;
+            }
+            if (ev) {
+                const int e = eb + ev_n + __popcll(mE & lower);
+                L.ev.x[e] = x; L.ev.y[e] = y; L.ev.z[e] = z; L.ev.occ[e] = occ; L.ev.nts[e] = nts;
+                L.ev.mode[e] = mode; L.ev.facet[e] = facet; L.ev.pid[e] = pid;
+            }
+            w += __popcll(mD);
+            ev_n += __popcll(mE);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS is in-order per wave; keep the compiler honest
+            // ---- drain: whenever a full batch is parked (everything on the last, empty tile) the whole wave runs the
+            // boundary event loop (Population.py:1546-1683), tallies, and appends the survivors
+            const int keep = (t == nA + nB) ? 0 : NK_TILE - 1;
+            while (ev_n > keep) {
+                const int n = ev_n >= NK_TILE ? NK_TILE : ev_n;
+                const int e = eb + ev_n - n + lane;
+                const bool eact = lane < n;
+                NkParticle p;
+                unsigned long long ppid = 0;
+                p.alive = false;
+                if (eact) {
+                    p.x = L.ev.x[e]; p.y = L.ev.y[e]; p.z = L.ev.z[e]; p.occ = L.ev.occ[e]; p.nts = L.ev.nts[e];
+                    p.mode = L.ev.mode[e]; p.facet = L.ev.facet[e]; ppid = L.ev.pid[e];
+                    const NkMode *rec = d.modetab + p.mode;
+                    p.omega = rec->omega; p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
+                    p.alive = true;
+                    nk_events(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.bins, p, ppid, step);
+                }
+                const bool alive = eact && p.alive;
+                if (alive) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
+                const unsigned long long mA = __ballot(alive);
+                if (alive) {
+                    const int o = w + __popcll(mA & lower);
+                    if (o < d.segcap) nk_store(d, base + o, p.x, p.y, p.z, p.occ, p.nts, p.mode, p.facet, ppid);
+                    else *d.overflow = 1;
+                }
+                w += __popcll(mA);
+                ev_n -= n;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            }
         }
-        // ---- phase C: whatever is still parked
-        nk_drain(d, L, ev_n, 0, base, w, parity, step, do_flux, rep);
-        if (tid == 0) d.seg_count[seg] = w < d.segcap ? w : d.segcap;
+        if (lane == 0) d.seg_count[seg] = w < d.segcap ? w : d.segcap;
     }
     nk_lds_flush(d, L, blockIdx.x);
 }
@@ -445,7 +443,7 @@ __global__ void k_update(NkDev d, const double *acc, double *hist_row, int do_fl
 __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<false, false>(d, smem, L);
+    nk_lds_setup<0, false>(d, smem, L);
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
@@ -460,10 +458,11 @@ __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d) {
 }
 
 // timesteps_to_boundary for every particle (Population.py:310-314)
+template <int GEOM>
 __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<true, false>(d, smem, L);
+    nk_lds_setup<GEOM, false>(d, smem, L);
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
@@ -479,10 +478,11 @@ __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
 }
 
 // contains_check (Population.py:1712-1722) + Mesh.sample_volume (Mesh.py:890-904)
+template <int GEOM>
 __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<true, false>(d, smem, L);
+    nk_lds_setup<GEOM, false>(d, smem, L);
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
@@ -527,11 +527,12 @@ __global__ void k_build_modetab(const double *omega, const double *vg, const dou
 }
 
 // ---- parity taps: the reference's primitives evaluated on the device
+template <int GEOM>
 __global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n, const double *x, const double *v,
                                                              double *xc, double *tc, int32_t *fc) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<true, false>(d, smem, L);
+    nk_lds_setup<GEOM, false>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
     double t; int f;
