@@ -37,6 +37,7 @@ struct nk_ctx {
     bool pending_relax = false;
     int g_sweep = 0;               // persistent grid of k_sweep = rows of `partials`
     std::vector<int32_t> h_seg_count;
+    std::vector<hipEvent_t> evpool;
     double *acc = nullptr;         // [NB]
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -179,6 +180,7 @@ void nk_destroy(nk_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
+    for (auto &e : ctx->evpool) hipEventDestroy(e);
     for (void *p : ctx->allocs) hipFree(p);
     for (void *p : ctx->pallocs) hipFree(p);
     if (ctx->acc) hipFree(ctx->acc);
@@ -591,8 +593,9 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     if (nsteps > ctx->hist_cap) {
         if (ctx->hist) hipFree(ctx->hist);
         ctx->hist = nullptr;
-        NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)nsteps * HROW * sizeof(double)));
-        ctx->hist_cap = nsteps;
+        const int rows_alloc = nsteps < 1024 ? 1024 : nsteps;   // generous: a later, longer call must not pay a realloc
+        NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)rows_alloc * HROW * sizeof(double)));
+        ctx->hist_cap = rows_alloc;
     }
     const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, true);
     const int count_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
@@ -605,12 +608,13 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         ctx->g_sweep = ctx->num_cu * per_cu;
     }
     const int g_sweep = ctx->g_sweep < d.nseg ? ctx->g_sweep : d.nseg;
-    const int nev = nsteps < 64 ? nsteps : 64;          // per-kernel timing on (up to) the first 64 steps
-    std::vector<hipEvent_t> ev((size_t)nev * 4);
-    for (auto &e : ev) NK_HIP(hipEventCreate(&e));
-    hipEvent_t t0, t1;
-    NK_HIP(hipEventCreate(&t0));
-    NK_HIP(hipEventCreate(&t1));
+    const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the call
+    if (ctx->evpool.empty()) {                           // events are created once and reused
+        ctx->evpool.resize(16 * 4 + 2);
+        for (auto &e : ctx->evpool) NK_HIP(hipEventCreate(&e));
+    }
+    hipEvent_t *ev = ctx->evpool.data();
+    hipEvent_t t0 = ctx->evpool[64], t1 = ctx->evpool[65];
     NK_HIP(hipEventRecord(t0, ctx->stream));
     for (int s = 0; s < nsteps; ++s) {
         const uint32_t step = (uint32_t)ctx->step;
@@ -646,8 +650,6 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         NK_HIP(hipEventElapsedTime(&ms, ev[4 * s + 2], ev[4 * s + 3])); vk += ms;
     }
     NK_HIP(hipEventElapsedTime(&ms, t0, t1));
-    for (auto &e : ev) hipEventDestroy(e);
-    hipEventDestroy(t0); hipEventDestroy(t1);
     ctx->timing.step_kernel_ms = sk / nev;
     ctx->timing.emit_kernel_ms = ek / nev;
     ctx->timing.events_kernel_ms = vk / nev;

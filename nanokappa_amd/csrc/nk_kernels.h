@@ -403,9 +403,20 @@ __global__ void k_update(NkDev d, const double *acc, double *hist_row, int do_fl
         if (d.norm_fixed) norm = d.active_modes / (d.particle_density * d.sv_volume[t]);
         else { norm = d.active_modes / Ns; if (isnan(norm)) norm = 0.0; }
         double E = Eraw * norm / d.QV;
-        double ref = nk_E_of_T(d, d.T_ref_local ? d.T_sv[t] : d.T_ref);
+        // E(T_old) then T(E): the tables are searched from a guess (uniform T grid; the new T is next to the old one)
+        const double Told = d.T_ref_local ? d.T_sv[t] : d.T_ref;
+        const int n = d.nE;
+        const double Ta = d.Tarr[0], Tb = d.Tarr[1];
+        int it = (int)((Told - Ta) / (Tb - Ta));
+        double ref;
+        if (Told < Ta) { ref = d.Earr[0]; it = 0; }
+        else if (Told > d.Tarr[n - 1]) { ref = d.Earr[n - 1]; it = n - 1; }
+        else ref = nk_interp_lin_hint(d.Tarr, d.Earr, n, Told, it, it);
         E += ref;
-        Tnew = nk_T_of_E(d, E);
+        int ie;
+        if (E < d.Earr[0]) Tnew = d.Tfill_lo;
+        else if (E > d.Earr[n - 1]) Tnew = d.Tfill_hi;
+        else Tnew = nk_interp_lin_hint(d.Earr, d.Tarr, n, E, it, ie);
         hist_row[NB + t] = Tnew;
         hist_row[NB + S + t] = E;
     }
