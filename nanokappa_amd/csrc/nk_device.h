@@ -366,6 +366,8 @@ struct NkParticle {
 
 // One particle's boundary events inside a timestep: Population.boundary_scattering (Population.py:1546-1683) restated
 // per particle.  On entry (x,y,z) is the end-of-step position of the free drift and nts < 0.
+// ROUGH = false compiles the rough-facet branch out (meshes without 'R' facets): fewer registers in the sweep.
+template <bool ROUGH>
 __device__ __forceinline__ void nk_events(const NkDev &d, const double *planes, const double *faces,
                                           const NkFacet *facets, const double *cen, const double *Tsv, NkBins &b,
                                           NkParticle &p, uint64_t pid, uint32_t step) {
@@ -402,7 +404,7 @@ __device__ __forceinline__ void nk_events(const NkDev &d, const double *planes, 
             if (fc.bc == 'P') {                                                      // II. periodic, :1463-1489
                 const NkFacet pf = facets[fc.partner];
                 p.x = cx + (pf.cx - fc.cx); p.y = cy + (pf.cy - fc.cy); p.z = cz + (pf.cz - fc.cz);
-            } else {                                                                 // III. rough, :1491-1544
+            } else if (ROUGH) {                                                      // III. rough, :1491-1544
                 double r0, r1;
                 nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);
                 p.x = cx; p.y = cy; p.z = cz;

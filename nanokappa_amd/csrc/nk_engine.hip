@@ -380,6 +380,7 @@ int nk_set_rough(nk_ctx *ctx, const nk_rough *r) {
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     d.Fr = r->Fr;
+    ctx->g_sweep = 0;
     if (r->Fr > 0) {
         size_t n = (size_t)r->Fr * d.M;
         NK_UP(r->specularity, n, &d.specularity);
@@ -601,8 +602,11 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     const int count_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
     if (ctx->g_sweep == 0) {                               // persistent grid = what the device keeps resident
         int per_cu = 0;
-        if (nk_geom_mode(ctx) == 1) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1>, NK_WG, lds_w));
-        else NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<2>, NK_WG, lds_w));
+        const bool rough = d.Fr > 0;
+        if (nk_geom_mode(ctx) == 1 && rough) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1, true>, NK_WG, lds_w));
+        else if (nk_geom_mode(ctx) == 1) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1, false>, NK_WG, lds_w));
+        else if (rough) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<2, true>, NK_WG, lds_w));
+        else NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<2, false>, NK_WG, lds_w));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
         ctx->g_sweep = ctx->num_cu * per_cu;
@@ -627,7 +631,14 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
         if (R > 0) k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
-        NK_GEOM_LAUNCH(k_sweep, g_sweep, lds_w, d, step, ctx->pending_relax ? 1 : 0, do_flux);
+        {
+            const int rl = ctx->pending_relax ? 1 : 0;
+            const int gm = nk_geom_mode(ctx);
+            if (gm == 1 && d.Fr > 0) k_sweep<1, true><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux);
+            else if (gm == 1) k_sweep<1, false><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux);
+            else if (d.Fr > 0) k_sweep<2, true><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux);
+            else k_sweep<2, false><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux);
+        }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
         k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d.partials, g_sweep, NB, ctx->acc);
         if (ctx->comm) {

@@ -227,7 +227,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
 // inside the step are parked in LDS, and whenever 64 are parked the whole wave processes them.
 #define NK_TILE 64
 #define NK_WAVE_EVCAP (NK_EVCAP / (NK_WG / 64))     // 128 parked particles per wave (< 64 pending + 64 new)
-template <int GEOM>
+template <int GEOM, bool ROUGH>
 __global__ __launch_bounds__(NK_WG, 3) void k_sweep(NkDev d, uint32_t step, int do_relax, int do_flux_i) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(NK_WG, 3) void k_sweep(NkDev d, uint32_t step, int 
                     const NkMode *rec = d.modetab + p.mode;
                     p.omega = rec->omega; p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
                     p.alive = true;
-                    nk_events(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.bins, p, ppid, step);
+                    nk_events<ROUGH>(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.bins, p, ppid, step);
                 }
                 const bool alive = eact && p.alive;
                 if (alive) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
