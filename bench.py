@@ -8,7 +8,8 @@
 Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): synthetic Si (31^3 q-points x 6 branches), box
 200 x 200 x 200 angstrom, 20 slices along x, BCs T T P (302 K / 298 K reservoirs on +-x, periodic sides), dt = 1 ps,
 1e7 particles PER GPU (weak scaling: the ensemble grows with N, the per-step tally is all-reduced over RCCL).
-A "step" is one Population.run_timestep: relax -> drift -> reservoir emission -> boundary events -> tally -> T update.
+A "step" is one Population.run_timestep: relax -> drift -> reservoir emission -> boundary events -> tally -> T update
+(kernels k_emit_count, k_sweep, k_reduce, k_update).
 Particles are resident in HBM before the timed region.  One JSON line is printed by rank 0.
 
 torch is used only as plumbing when WORLD_SIZE > 1 (gloo rendezvous: unique-id broadcast, barriers, max of the
@@ -172,7 +173,7 @@ def main():
         tf = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
         if os.path.exists(tf) and world == 1 and int(a.particles) == 10000000 and a.mesh_n == 31:
             try:
-                traffic = json.load(open(tf)).get('k_step_hbm_bytes_per_launch')
+                traffic = json.load(open(tf)).get('k_sweep_hbm_bytes_per_launch')
             except Exception:
                 traffic = None
         out = {
@@ -184,8 +185,9 @@ def main():
                        'particles_total': total, 'live_particles_end': tm['live'], 'parallelism': 'particle-shard x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
-                         'kernel': 'k_step', 'kernel_ms': k_ms, 'emit_kernel_ms': tm['emit_kernel_ms'],
-                         'events_kernel_ms': tm['events_kernel_ms'],
+                         'kernel': 'k_sweep', 'kernel_ms': k_ms, 'emit_count_kernel_ms': tm['emit_kernel_ms'],
+                         'reduce_update_ms': tm['events_kernel_ms'], 'stream_ms_per_step': tm['total_ms'] / a.steps,
+                         'frac_whole_step': BYTES_PER_PHONON_STEP * value / 1e9 / HBM_PEAK_GBS / max(world, 1),
                          'algorithmic_bytes_per_launch': BYTES_PER_PHONON_STEP * live_rank},
         }
         if world == 1 and not a.no_cpu_baseline:

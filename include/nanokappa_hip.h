@@ -137,11 +137,11 @@ typedef struct {
 
 /* Kernel timing of the last nk_step call, from HIP events on the library's stream. */
 typedef struct {
-    double step_kernel_ms;   /* mean duration of k_step: relax + drift + tally over every live slot */
-    double emit_kernel_ms;   /* mean duration of reservoir emission (k_emit_count + k_spawn) */
-    double events_kernel_ms; /* mean duration of k_events: boundary events of the queued particles */
+    double step_kernel_ms;   /* mean duration of k_sweep: relax + drift + boundary events + emission + tally */
+    double emit_kernel_ms;   /* mean duration of k_emit_count (reservoir counters, spawn list) */
+    double events_kernel_ms; /* mean duration of the step's tail: k_reduce (+ all-reduce) + k_update */
     double total_ms;         /* wall time of the whole call on the stream */
-    int64_t slots;           /* particle slots swept by the last step kernel */
+    int64_t slots;           /* particle capacity (nseg * segcap) */
     int64_t live;            /* live particles after the call (this rank) */
 } nk_timing;
 

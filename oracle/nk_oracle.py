@@ -135,7 +135,10 @@ def make_mesh(g):
     m.normals, m.k, m.bounds_lo, m.bounds_hi = _p(nrm, c_dp), _p(k, c_dp), _p(lo, c_dp), _p(hi, c_dp)
     m.basis, m.origins, m.face_facet, m.vertices, m.face_area = (_p(basis, c_dp), _p(org, c_dp), _p(ff, c_ip),
                                                                 _p(verts, c_dp), _p(area, c_dp))
-    bc = np.ascontiguousarray(g['bound_cond'], dtype=np.int8)
+    bc = np.asarray(g['bound_cond'])
+    if bc.dtype.kind in 'US':
+        bc = np.array([ord(str(c)[0]) for c in bc])
+    bc = np.ascontiguousarray(bc, dtype=np.int8)
     Fc = bc.shape[0]
     partner = -np.ones(Fc, dtype=np.int32)
     for a, b in np.asarray(g.get('connected_facets', np.zeros((0, 2))), dtype=int).reshape(-1, 2):

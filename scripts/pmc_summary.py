@@ -5,7 +5,8 @@ def load(d):
     f = glob.glob('%s/*/*counter_collection.csv' % d)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        agg[r['Kernel_Name'].split('(')[0]][r['Counter_Name']].append(float(r['Counter_Value']))
+        name = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]
+        agg[name][r['Counter_Name']].append(float(r['Counter_Value']))
     return {k: {c: sum(v[-5:]) / len(v[-5:]) for c, v in cs.items()} for k, cs in agg.items()}
 
 if __name__ == '__main__':

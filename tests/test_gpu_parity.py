@@ -162,3 +162,48 @@ def test_multistep_vs_oracle(case):
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
     # accumulated reservoir tallies
     assert rel_err(t['res_energy'].sum(axis=0), sim.res_energy[:2]) < 1e-8
+
+
+COMMON_ARGS = ['--poscar_file', 'POSCAR', '--hdf_file', 'synthetic', '--temp_interp', 'linear', '--timestep', '1',
+               '--energy_normal', 'mean', '--particles', 'total', '30000']
+EXTRA_CASES = {
+    # BASELINE config 3 in small: Ge-like cross-plane film, 2000 A thick, periodic sides
+    'ge_film': (['--geometry', 'box', '--dimensions', '2000', '500', '500', '--subvolumes', 'slice', '20', '0',
+                 '--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5', '--bound_cond', 'T', 'T', 'P',
+                 '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
+                 '--bound_values', '302', '298'], 'Ge'),
+    # BASELINE config 4 in small: wire with rough side facets (tables in LDS: 64 faces, 18 facets)
+    'wire16': (['--geometry', 'cylinder', '--dimensions', '500', '100', '16', '--subvolumes', 'slice', '10', '2',
+                '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+                '--bound_values', '302', '298', '5'], 'Si'),
+    # same with 72 sides: 288 faces -> the ray-casting tables stay in global memory (large-mesh code path)
+    'wire72': (['--geometry', 'cylinder', '--dimensions', '500', '100', '72', '--subvolumes', 'slice', '10', '2',
+                '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+                '--bound_values', '302', '298', '5'], 'Si'),
+}
+
+
+@pytest.mark.parametrize('name', ['ge_film', 'wire16', 'wire72'])
+def test_other_geometries_vs_oracle(name):
+    """Film with periodic sides, and wires with many rough facets (LDS and global-memory table paths): engine and
+    oracle from the same state and seed, compared step by step and particle by particle."""
+    from util import case_from_args, population_in_mesh
+    argv, species = EXTRA_CASES[name]
+    ct = case_from_args(argv + COMMON_ARGS, species)
+    pos, mode, occ, counter = population_in_mesh(ct, 30000, seed=8)
+    nsteps = 15
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=4242, cap=120000)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=4242)
+    t = eng.step(nsteps)
+    for s in range(nsteps):
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+    p = eng.download()
+    n = sim.P.N
+    assert p['pid'].shape[0] == n
+    o1, o2 = np.argsort(p['pid']), np.argsort(sim.P.pid[:n])
+    assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
+    assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
+    assert np.allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=1e-8)
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8

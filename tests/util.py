@@ -128,3 +128,52 @@ def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scal
     eng.upload(pos, mode, occ)
     eng.init_boundaries()
     return eng
+
+
+def case_from_args(argv, species='Si'):
+    """Same dict as case_tables, but assembled with this package's own Geometry / setup_tables from a Nano-kappa
+    argument list (used for geometries that have no reference golden)."""
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.phonon import Phonon
+    from nanokappa_amd import setup_tables as ST
+    from nanokappa_amd import synthetic
+    args = initialise_parser().parse_args(argv)
+    args.results_folder = ''
+    geo = Geometry(args)
+    if species == 'Si':
+        ph = golden_phonon()
+    else:
+        ph = Phonon(args, 0, material=synthetic.make_material(9, species, temperatures=np.arange(200.0, 401.0, 10.0)))
+    Q, J = ph.omega.shape
+    M = Q * J
+    n_p = float(args.particles[1])
+    density = n_p / geo.volume
+    g = geo.tables()
+    out = dict(ph=ph, J=J, M=M, mesh=g, tables=ph.tables(), centers=geo.subvol_center, volumes=geo.subvol_volume,
+               axis=geo.slice_axis, res_facets=geo.res_facets, res_T=np.asarray(geo.res_values, dtype=float),
+               enter_prob=ST.enter_probability(geo, ph, geo.res_facets, density, 1.0).reshape(-1, M),
+               particle_density=density, geo=geo)
+    if geo.rough_facets.shape[0] > 0:
+        spec0 = ST.fbz_specularity(geo, ph, geo.rough_facets, geo.rough_facets_values)
+        corr, ts = ST.specular_correspondences_velocity(geo, ph, geo.rough_facets)
+        spec = ts.astype(int) * spec0
+        sm = ST.specular_map(corr, geo, geo.rough_facets, Q, J)
+        _, roul = ST.diffuse_roulette(geo, ph, geo.rough_facets, spec, corr)
+        out['rough'] = dict(facets=geo.rough_facets, specularity=spec.reshape(-1, M), true_spec=ts.reshape(-1, M),
+                            spec_map=sm.reshape(-1, M), roulette=roul)
+    else:
+        out['rough'] = None
+    return out
+
+
+def population_in_mesh(ct, n, seed, T0=298.0):
+    """Like random_population but positions are sampled inside the mesh (non-box geometries)."""
+    rng = np.random.default_rng(seed)
+    ph = ct['ph']
+    pos = ct['geo'].mesh.sample_volume(n, rng)
+    active = np.nonzero(~ph.inactive_modes_mask.ravel())[0]
+    mode = active[rng.integers(0, active.shape[0], n)].astype(np.int32)
+    occ = ph.calculate_occupation(T0, ph.omega.ravel()[mode])
+    counter = rng.random(ct['enter_prob'].shape)
+    return pos, mode, occ, counter
