@@ -4,7 +4,7 @@
  * The reference (brunohs1993/Nanokappa) is pure Python with no FFI layer; the boundary this
  * library replaces is the body of `Population.run_timestep` (classes/Population.py:1724-1769)
  * and the helpers it calls.  Each entry point names the reference interface it stands for.
- * Python binds it with ctypes (nanokappa_amd/_lib.py); INTEGRATION.md shows the stub a
+ * Python binds it with ctypes (nanokappa_amd/engine.py); INTEGRATION.md shows the stub a
  * maintainer of the reference would add.
  *
  * Conventions: plain pointers + sizes, caller owns every host buffer (the library copies, never
