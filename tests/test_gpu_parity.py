@@ -207,3 +207,19 @@ def test_other_geometries_vs_oracle(name):
     assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
     assert np.allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=1e-8)
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+
+
+def test_rccl_path_single_rank(monkeypatch):
+    """The multi-GPU code path (dlopen'ed RCCL, in-stream all-reduce of the tally vector) with a 1-rank communicator:
+    results must equal the run without a communicator."""
+    from nanokappa_amd.engine import comm_unique_id
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 20000, seed=9)
+    ref = make_engine(ct, pos, mode, occ, counter, seed=1)
+    t0 = ref.step(6)
+    monkeypatch.setenv('NK_FORCE_COMM', '1')
+    eng = make_engine(ct, pos, mode, occ, counter, seed=1)
+    eng.comm_init(comm_unique_id(), 0, 1)
+    t1 = eng.step(6)
+    assert np.array_equal(t0['N_sv'], t1['N_sv'])
+    assert np.allclose(t0['T_sv'], t1['T_sv'], rtol=0, atol=1e-9)
