@@ -14,9 +14,10 @@
 
 #define NK_WG 256            // threads per workgroup (4 waves of 64)
 #define NK_NREP 8            // LDS replicas of the tally bins (lane & 7) to thin same-address atomics
-#define NK_PLANE_DOUBLES 5   // nx ny nz k {face_begin, face_end}
+#define NK_PLANE_DOUBLES 6   // nx ny nz k {face_begin, face_end} pad  (48 B: three aligned 16-byte reads)
 #define NK_FACE_DOUBLES 16   // lo(3) hi(3) o(3) iu(3) iw(3) {orig_face, facet}
 #define NK_LDS_FACES 256     // meshes up to this many faces keep their plane/face tables in LDS
+#define NK_LDS_RESFACES 64   // reservoir facets with up to this many faces in total keep their sampling tables in LDS
 #define NK_TAU_ROWS 4        // lifetime rows packed into each mode record
 #define NK_EVCAP 512         // entries of the per-workgroup LDS event buffer (< NK_WG pending + NK_WG new)
 
@@ -26,14 +27,15 @@
 #define NK_TAG_RESAMP 0x20000u
 #define NK_TAG_DICE 0x30000u
 
-struct NkFacet {          // 80 bytes
+struct __attribute__((aligned(16))) NkFacet {   // 96 bytes
     double cx, cy, cz;    // centroid
     double nx, ny, nz;    // outward normal
+    double tx, ty, tz;    // periodic facets: centroid(partner) - centroid(this), the translation of Population.py:1467
     int32_t bc;           // 'T','F','P','R'
     int32_t partner;      // periodic partner facet or -1
     int32_t res;          // reservoir index or -1
     int32_t rough;        // rough-facet index or -1
-    int32_t pad[4];
+    int32_t pad[2];
 };
 
 struct __attribute__((aligned(64))) NkMode {   // one gather per particle
@@ -79,11 +81,23 @@ struct NkDev {
     int32_t R, res_gen;
     const int32_t *res_facet;         // [R]
     const double *res_T;              // [R]
+    const int32_t *res_face_off;      // [R+1] faces of each reservoir facet (CSR), in Mesh.sample_surface order
+    const double *res_face_cdf;       // cumulative area fractions (np.random.choice), same CSR
+    const double *res_face_verts;     // 9 doubles per face
+    int32_t res_nf;                   // total faces of all reservoir facets
+    int32_t res_lds;                  // 1: the three tables above are staged in LDS by the sweep
     const double *enter_prob;         // [R*M]
     double *res_counter;              // [R*M]
     double *res_cval;                 // [R*M] counter / dice value used by the level-1 entry time
-    uint64_t *spawn_list;             // [spawn_cap] (rm << 12 | level) of every particle entering this step
-    int64_t spawn_cap;
+    uint64_t *spawn_list;             // [spawn_cap] (rm << 12 | level) of every particle entering this step, in
+    int64_t spawn_cap;                // mode-major order (j = m*R + r), built by k_emit_count + k_emit_fill
+    int32_t *emit_loc;                // [R*M] exclusive offset of entry j inside its 256-entry block
+    int32_t *emit_cnt;                // [R*M] particles of entry j owned by this rank
+    int32_t *emit_blk_tot;            // [nblk] particles per block; [nblk] block offsets follow in emit_blk_off
+    int32_t *emit_blk_off;            // [nblk+1]
+    uint64_t *leftover;               // [spawn_cap] records that did not fit their home segment (placed by k_sweep<SPILL>)
+    int32_t *leftover_count;
+    int32_t *spill_cursor;            // rotating segment cursor of the spill pass
     // ---- rough facets
     int32_t Fr;
     const double *specularity;        // [Fr*M]
@@ -102,7 +116,10 @@ struct NkDev {
     int32_t nseg, segcap;
     int32_t *seg_count;               // [nseg] live particles per segment (contiguous from the segment start)
     int64_t *seg_free_prefix;         // [nseg+1] exclusive prefix of the free slots per segment (after the last step):
-                                      // entering particles are dealt to segments in proportion to their free space
+                                      // win_mode 0 deals entering particles to segments in proportion to free space
+    int32_t *seg_win;                 // [nseg+1] mode windows: segment s is the home of modes [seg_win[s], seg_win[s+1])
+    int32_t win_mode;                 // 1: entering particles go to the segment that owns their mode (sorted population,
+                                      //    mode gathers become cache-resident); 0: free-space dealing (rough facets scramble modes)
     double *x, *y, *z, *occ, *nts;
     int32_t *mode, *facet;
     uint64_t *pid;
@@ -250,8 +267,16 @@ __device__ __forceinline__ int nk_classify(const NkDev &d, const double *cen, do
         double xa = a == 0 ? x : (a == 1 ? y : z);
         int s = (int)floor((xa - d.sv_lo) * d.sv_invL);
         s = s < 0 ? 0 : (s > S - 1 ? S - 1 : s);
-        while (s + 1 < S && fabs(xa - cen[3 * (s + 1) + a]) < fabs(xa - cen[3 * s + a])) ++s;
-        while (s > 0 && fabs(xa - cen[3 * (s - 1) + a]) <= fabs(xa - cen[3 * s + a])) --s;
+        // the guess and both neighbours in one round of reads; the walks below only run when the guess was off
+        const double cm = cen[3 * (s > 0 ? s - 1 : 0) + a], c0 = cen[3 * s + a], cp = cen[3 * (s + 1 < S ? s + 1 : S - 1) + a];
+        const double d0 = fabs(xa - c0);
+        if (s + 1 < S && fabs(xa - cp) < d0) {
+            ++s;
+            while (s + 1 < S && fabs(xa - cen[3 * (s + 1) + a]) < fabs(xa - cen[3 * s + a])) ++s;
+        } else if (s > 0 && fabs(xa - cm) <= d0) {
+            --s;
+            while (s > 0 && fabs(xa - cen[3 * (s - 1) + a]) <= fabs(xa - cen[3 * s + a])) --s;
+        }
         return s;
     }
     int best = 0;
@@ -273,7 +298,20 @@ __device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen,
     int g = (int)floor((xa - d.sv_lo) * d.sv_invL);
     g = g < 0 ? 0 : (g > S - 1 ? S - 1 : g);
     if (d.sv_interp == 1) {
-        int idx = g;                                  // searchsorted(centres, xa, 'left')
+        // searchsorted(centres, xa, 'left') lands on g or g+1 for slices; read both candidate brackets at once
+        {
+            const int gm = g > 0 ? g - 1 : 0, gp = g + 1 < S ? g + 1 : S - 1;
+            const double cm = cen[3 * gm + a], c0 = cen[3 * g + a], cp = cen[3 * gp + a];
+            const double Tm = Tsv[gm], T0 = Tsv[g], Tp = Tsv[gp];
+            if ((g == 0 || cm < xa) && (g + 1 >= S || !(cp < xa))) {
+                int idx = g + (c0 < xa ? 1 : 0);
+                idx = idx < 1 ? 1 : (idx > S - 1 ? S - 1 : idx);
+                const bool lower = idx == g;              // bracket (g-1, g), else (g, g+1)
+                const double xlo = lower ? cm : c0, xhi = lower ? c0 : cp, ylo = lower ? Tm : T0, yhi = lower ? T0 : Tp;
+                return (yhi - ylo) / (xhi - xlo) * (xa - xlo) + ylo;
+            }
+        }
+        int idx = g;
         while (idx < S && cen[3 * idx + a] < xa) ++idx;
         while (idx > 0 && cen[3 * (idx - 1) + a] >= xa) --idx;
         idx = idx < 1 ? 1 : (idx > S - 1 ? S - 1 : idx);
@@ -295,29 +333,39 @@ __device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen,
 // iu/iw are the first two rows of the inverse of face_basis_matrix: (u, w) = rows . (c - o) is the solve() of :840.
 __device__ __forceinline__ void nk_find_boundary(const double *planes, const double *faces, int NP, double tol, double x,
                                                  double y, double z, double vx, double vy, double vz, double &tc, int &fc) {
+    // numpy evaluates these dot products without fused multiply-adds; num cancels near a plane, so a fused evaluation
+    // moves t by many ulps.  Keep the reference's rounding here.
+#pragma clang fp contract(off)
     double tbest = __builtin_inf();
     int fbest = 0x7fffffff, facet = -1;
+    // The tables are the same for all lanes, so every read is a latency, not a bandwidth, cost: records are fetched with
+    // 16-byte reads issued together, and the next plane is requested while the current one is evaluated.
+    const double2 *P = reinterpret_cast<const double2 *>(planes);
+    double2 n0 = P[0], n1 = P[1], n2 = P[2];
     for (int pl = 0; pl < NP; ++pl) {
-        const double *p = planes + pl * NK_PLANE_DOUBLES;
-        const double num = x * p[0] + y * p[1] + z * p[2] + p[3];
-        const double den = vx * p[0] + vy * p[1] + vz * p[2];
+        const double2 p01 = n0, p23 = n1, pr = n2;
+        if (pl + 1 < NP) { n0 = P[3 * pl + 3]; n1 = P[3 * pl + 4]; n2 = P[3 * pl + 5]; }
+        const double num = x * p01.x + y * p01.y + z * p23.x + p23.y;
+        const double den = vx * p01.x + vy * p01.y + vz * p23.x;
         if (!((num < 0.0 && den > 0.0) || (num > 0.0 && den < 0.0))) continue;
         const double t = -num / den;
         if (!(t >= tol) || isinf(t) || t > tbest) continue;
         const double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
-        const int2 rng = *reinterpret_cast<const int2 *>(p + 4);
-        for (int f = rng.x; f < rng.y; ++f) {
-            const double *q = faces + f * NK_FACE_DOUBLES;
-            if (!(cx >= q[0] - tol) || !(cy >= q[1] - tol) || !(cz >= q[2] - tol) || !(cx <= q[3] + tol) ||
-                !(cy <= q[4] + tol) || !(cz <= q[5] + tol))
-                continue;
-            const double bx = cx - q[6], by = cy - q[7], bz = cz - q[8];
-            const double u = q[9] * bx + q[10] * by + q[11] * bz;
-            const double w = q[12] * bx + q[13] * by + q[14] * bz;
+        const int f_lo = __double2loint(pr.x), f_hi = __double2hiint(pr.x);
+        for (int f = f_lo; f < f_hi; ++f) {
+            const double2 *q = reinterpret_cast<const double2 *>(faces + f * NK_FACE_DOUBLES);
+            const double2 q0 = q[0], q1 = q[1], q2 = q[2];              // lo.x lo.y | lo.z hi.x | hi.y hi.z
+            const bool inside = (cx >= q0.x - tol) & (cy >= q0.y - tol) & (cz >= q1.x - tol) & (cx <= q1.y + tol) &
+                                (cy <= q2.x + tol) & (cz <= q2.y + tol);
+            if (!inside) continue;
+            const double2 q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];   // o(3) iu(3) iw(3) {face, facet}
+            const double bx = cx - q3.x, by = cy - q3.y, bz = cz - q4.x;
+            const double u = q4.y * bx + q5.x * by + q5.y * bz;
+            const double w = q6.x * bx + q6.y * by + q7.x * bz;
             const double r = 1.0 - (u + w);
             if (!(u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol)) continue;
-            const int2 id = *reinterpret_cast<const int2 *>(q + 15);
-            if (t < tbest || id.x < fbest) { tbest = t; fbest = id.x; facet = id.y; }
+            const int idf = __double2loint(q7.y), idc = __double2hiint(q7.y);
+            if (t < tbest || idf < fbest) { tbest = t; fbest = idf; facet = idc; }
         }
     }
     tc = tbest;
@@ -369,8 +417,8 @@ struct NkParticle {
 // ROUGH = false compiles the rough-facet branch out (meshes without 'R' facets): fewer registers in the sweep.
 template <bool ROUGH>
 __device__ __forceinline__ void nk_events(const NkDev &d, const double *planes, const double *faces,
-                                          const NkFacet *facets, const double *cen, const double *Tsv, NkBins &b,
-                                          NkParticle &p, uint64_t pid, uint32_t step) {
+                                          const NkFacet *facets, const double *cen, const double *Tsv,
+                                          const double *resT, NkBins &b, NkParticle &p, uint64_t pid, uint32_t step) {
     const double dt = d.dt;
     double cts = 0.0;
     uint32_t ev = 0;
@@ -382,7 +430,7 @@ __device__ __forceinline__ void nk_events(const NkDev &d, const double *planes, 
             if (fc.bc == 'T' || fc.bc == 'F') {             // I. absorbed by a reservoir, Population.py:1568-1608
                 int r = p.facet < 0 ? -1 : fc.res;
                 if (r >= 0) {
-                    double Tr = d.T_ref_local ? d.res_T[r] : d.T_ref;
+                    double Tr = d.T_ref_local ? resT[r] : d.T_ref;
                     double e = d.hbar * p.omega * (p.occ - nk_occupation(d, Tr, p.omega));
                     double vn = p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz;
                     atomicAdd(&b.nleave[r], 1u);
@@ -402,8 +450,7 @@ __device__ __forceinline__ void nk_events(const NkDev &d, const double *planes, 
             // differs from the reference's sqrt/sqrt/divide by rounding only, and saves two square roots and a divide).
             cts += (cts == 0.0) ? fabs(p.nts + 1.0) : fabs(p.nts);
             if (fc.bc == 'P') {                                                      // II. periodic, :1463-1489
-                const NkFacet pf = facets[fc.partner];
-                p.x = cx + (pf.cx - fc.cx); p.y = cy + (pf.cy - fc.cy); p.z = cz + (pf.cz - fc.cz);
+                p.x = cx + fc.tx; p.y = cy + fc.ty; p.z = cz + fc.tz;   // t = centroid(partner) - centroid(this)
             } else if (ROUGH) {                                                      // III. rough, :1491-1544
                 double r0, r1;
                 nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);

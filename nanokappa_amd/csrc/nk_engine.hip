@@ -38,6 +38,8 @@ struct nk_ctx {
     int g_sweep = 0;               // persistent grid of k_sweep = rows of `partials`
     std::vector<int32_t> h_seg_count;
     std::vector<hipEvent_t> evpool;
+    bool no_windows = false;          // NK_NO_WINDOWS=1: never route entering particles by mode window (ablation)
+    bool windows_valid = false;
     double *acc = nullptr;         // [NB]
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -46,6 +48,8 @@ struct nk_ctx {
     NkRccl rccl;
     ncclComm_t comm = nullptr;
     int num_cu = 256;
+    std::vector<int32_t> h_ffo, h_ffi;   // host copies of the mesh's facet -> faces CSR, its area cdf and the vertices
+    std::vector<double> h_fcdf, h_verts;
     std::vector<NkFacet> host_facets;   // host mirror of d.facets (patched by nk_set_reservoirs / nk_set_rough)
     const double *d_omega = nullptr, *d_vg = nullptr;   // kept to rebuild the packed mode records
     std::vector<double> h_Tgrid;
@@ -83,7 +87,8 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 static inline int nk_geom_mode(const nk_ctx *ctx) { return (ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES) ? 1 : 2; }
 static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool evbuf = false) {
     const NkDev &d = ctx->d;
-    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, geom ? nk_geom_mode(ctx) : 0, evbuf);
+    const int gm = geom ? nk_geom_mode(ctx) : 0;
+    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, evbuf, (gm == 1 && d.res_lds) ? d.res_nf : 0);
 }
 #define NK_GEOM_LAUNCH(kernel, grid, lds, ...)                                                        \
     do {                                                                                               \
@@ -159,6 +164,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.nranks = 1;
     ctx->d.tau_row0 = -1;
     { const char *dbg = getenv("NK_DEBUG"); ctx->d.dbg = dbg ? atoi(dbg) : 0; }
+    ctx->no_windows = getenv("NK_NO_WINDOWS") != nullptr;
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
     // bookkeeping words in device memory: alloc_count, overflow
@@ -275,6 +281,10 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         for (int a = f0; a < f1; ++a) cdf[a] /= cdf[f1 - 1];
     }
     NK_UP(cdf.data(), cdf.size(), &d.facet_face_cdf);
+    ctx->h_ffo.assign(m->facet_face_off, m->facet_face_off + m->Fc + 1);
+    ctx->h_ffi.assign(m->facet_face_idx, m->facet_face_idx + nidx);
+    ctx->h_fcdf = cdf;
+    ctx->h_verts.assign(m->vertices, m->vertices + (size_t)m->F * 9);
     std::vector<NkFacet> fct((size_t)m->Fc);
     for (int fc = 0; fc < m->Fc; ++fc) {
         NkFacet &q = fct[fc];
@@ -284,6 +294,10 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         q.bc = m->facet_bc[fc]; q.partner = m->facet_partner[fc]; q.res = -1; q.rough = -1;
         NK_ARG(q.bc == 'T' || q.bc == 'F' || q.bc == 'P' || q.bc == 'R', "nk_set_mesh: unknown boundary condition");
         NK_ARG(q.bc != 'P' || (q.partner >= 0 && q.partner < m->Fc), "nk_set_mesh: periodic facet without partner");
+        if (q.bc == 'P') {                          // translation of a periodic crossing, Population.py:1467
+            const int pf = q.partner;
+            q.tx = m->facet_centroid[3 * pf] - q.cx; q.ty = m->facet_centroid[3 * pf + 1] - q.cy; q.tz = m->facet_centroid[3 * pf + 2] - q.cz;
+        }
     }
     ctx->host_facets = fct;
     NK_UP(fct.data(), fct.size(), &d.facets);
@@ -351,6 +365,7 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     d.R = r->R; d.res_gen = r->gen;
+    d.res_nf = 0; d.res_lds = 0;
     NK_ARG((int64_t)d.R * d.M < (1ll << 28), "nk_set_reservoirs: R*Q*J too large for the particle id layout");
     if (r->R > 0) {
         NK_UP(r->facet, (size_t)r->R, &d.res_facet);
@@ -368,6 +383,24 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
             NK_ARG(r->facet[i] >= 0 && r->facet[i] < d.Fc, "nk_set_reservoirs: facet index");
             ctx->host_facets[r->facet[i]].res = i;
         }
+        // sampling tables of the reservoir facets, gathered per reservoir (faces in Mesh.sample_surface order)
+        std::vector<int32_t> off((size_t)r->R + 1, 0);
+        std::vector<double> rcdf, rverts;
+        for (int i = 0; i < r->R; ++i) {
+            const int f0 = ctx->h_ffo[r->facet[i]], f1 = ctx->h_ffo[r->facet[i] + 1];
+            NK_ARG(f1 > f0, "nk_set_reservoirs: reservoir facet without faces");
+            for (int a = f0; a < f1; ++a) {
+                rcdf.push_back(ctx->h_fcdf[a]);
+                const double *v = &ctx->h_verts[(size_t)ctx->h_ffi[a] * 9];
+                rverts.insert(rverts.end(), v, v + 9);
+            }
+            off[(size_t)i + 1] = (int32_t)rcdf.size();
+        }
+        NK_UP(off.data(), off.size(), &d.res_face_off);
+        NK_UP(rcdf.data(), rcdf.size(), &d.res_face_cdf);
+        NK_UP(rverts.data(), rverts.size(), &d.res_face_verts);
+        d.res_nf = (int32_t)rcdf.size();
+        d.res_lds = d.res_nf <= NK_LDS_RESFACES ? 1 : 0;
         int rc = nk_patch_facets(ctx);
         if (rc) return rc;
     }
@@ -460,25 +493,61 @@ static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
     return NK_OK;
 }
 
-// Lay N particles out over the segments (equal shares, contiguous index ranges).
+// Lay N particles out over the segments, sorted by mode (stable): the particles of one 64-wide tile then share a few
+// mode records and the sweep's gathers stay in cache.  Segment s becomes the home of the modes
+// [seg_win[s], seg_win[s+1]) -- equal-population windows; when the population cannot be balanced that way (fewer modes
+// than segments, a few modes holding most particles) the split is by count and win_mode is 0.
 static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, const double *z, const int32_t *mode,
                       const double *occ, const double *n_ts, const int32_t *facet, const uint64_t *pid, uint64_t pid_offset) {
     NkDev &d = ctx->d;
-    std::vector<int32_t> cnt((size_t)d.nseg);
-    std::vector<int64_t> start((size_t)d.nseg + 1, 0);
-    for (int sgm = 0; sgm < d.nseg; ++sgm) {
-        int64_t lo = (N * sgm) / d.nseg, hi = (N * (sgm + 1)) / d.nseg;
-        cnt[sgm] = (int32_t)(hi - lo);
-        start[sgm] = lo;
-        NK_ARG(cnt[sgm] <= d.segcap, "nk_upload_particles: segment capacity too small");
+    const int M = d.M;
+    for (int64_t i = 0; i < N; ++i) NK_ARG(mode[i] >= 0 && mode[i] < M, "nk_upload_particles: mode index out of range");
+    std::vector<int64_t> mstart((size_t)M + 1, 0);               // counting sort by mode
+    for (int64_t i = 0; i < N; ++i) mstart[(size_t)mode[i] + 1] += 1;
+    for (int m = 0; m < M; ++m) mstart[(size_t)m + 1] += mstart[(size_t)m];
+    std::vector<int64_t> order((size_t)N);
+    {
+        std::vector<int64_t> cur(mstart.begin(), mstart.end() - 1);
+        for (int64_t i = 0; i < N; ++i) order[(size_t)cur[(size_t)mode[i]]++] = i;
     }
+    std::vector<int32_t> win((size_t)d.nseg + 1, 0);
+    std::vector<int64_t> start((size_t)d.nseg + 1, 0);
+    bool windows = !ctx->no_windows;
+    {
+        int m = 0;
+        for (int sgm = 0; sgm < d.nseg; ++sgm) {
+            const int64_t target = (N * (sgm + 1)) / d.nseg;
+            while (m < M && mstart[(size_t)m] < target) ++m;
+            if (sgm == d.nseg - 1) m = M;
+            win[(size_t)sgm + 1] = m;
+            start[(size_t)sgm + 1] = mstart[(size_t)m];
+            if (start[(size_t)sgm + 1] - start[(size_t)sgm] > (int64_t)(0.8 * d.segcap)) windows = false;
+        }
+    }
+    if (!windows)
+        for (int sgm = 0; sgm <= d.nseg; ++sgm) start[(size_t)sgm] = (N * sgm) / d.nseg;
+    std::vector<int32_t> cnt((size_t)d.nseg);
+    for (int sgm = 0; sgm < d.nseg; ++sgm) {
+        cnt[(size_t)sgm] = (int32_t)(start[(size_t)sgm + 1] - start[(size_t)sgm]);
+        NK_ARG(cnt[(size_t)sgm] <= d.segcap, "nk_upload_particles: segment capacity too small");
+    }
+    d.win_mode = (windows && d.Fr == 0) ? 1 : 0;
+    ctx->windows_valid = windows;
     std::vector<double> bd((size_t)d.cap);
     auto put = [&](const void *src, size_t esz, void *dst) -> int {
         if (!src) return NK_OK;
-        char *o = (char *)bd.data();
-        const char *in = (const char *)src;
-        for (int sgm = 0; sgm < d.nseg; ++sgm)
-            memcpy(o + (size_t)sgm * d.segcap * esz, in + (size_t)start[sgm] * esz, (size_t)cnt[sgm] * esz);
+        for (int sgm = 0; sgm < d.nseg; ++sgm) {
+            const int64_t lo = start[(size_t)sgm], n = cnt[(size_t)sgm];
+            if (esz == 8) {
+                uint64_t *o = (uint64_t *)bd.data() + (size_t)sgm * d.segcap;
+                const uint64_t *in = (const uint64_t *)src;
+                for (int64_t k = 0; k < n; ++k) o[k] = in[order[(size_t)(lo + k)]];
+            } else {
+                uint32_t *o = (uint32_t *)bd.data() + (size_t)sgm * d.segcap;
+                const uint32_t *in = (const uint32_t *)src;
+                for (int64_t k = 0; k < n; ++k) o[k] = in[order[(size_t)(lo + k)]];
+            }
+        }
         NK_HIP(hipMemcpy(dst, bd.data(), (size_t)d.cap * esz, hipMemcpyHostToDevice));
         return NK_OK;
     };
@@ -493,6 +562,7 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
         if ((rc = put(ids.data(), 8, d.pid))) return rc;
     }
     NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(d.seg_win, win.data(), win.size() * 4, hipMemcpyHostToDevice));
     std::vector<int64_t> fp((size_t)d.nseg + 1, 0);
     for (int sgm = 0; sgm < d.nseg; ++sgm) fp[sgm + 1] = fp[sgm] + (d.segcap - cnt[sgm]);
     NK_HIP(hipMemcpy(d.seg_free_prefix, fp.data(), fp.size() * 8, hipMemcpyHostToDevice));
@@ -521,6 +591,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
     NK_PALLOC(uint64_t, pid, pu, d.cap);
     NK_PALLOC(uint64_t, spawn_list, pu, d.spawn_cap);
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
+    NK_PALLOC(int32_t, seg_win, pi, d.nseg + 1);
     { const int64_t *pl; int rc_ = nk_upload<int64_t>(ctx, nullptr, (size_t)d.nseg + 1, &pl, true); if (rc_) return rc_; d.seg_free_prefix = (int64_t *)pl; }
 #undef NK_PALLOC
     return NK_OK;
@@ -609,6 +680,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         else NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<2, false>, NK_WG, lds_w));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
+        if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
         ctx->g_sweep = ctx->num_cu * per_cu;
     }
     const int g_sweep = ctx->g_sweep < d.nseg ? ctx->g_sweep : d.nseg;

@@ -42,36 +42,42 @@ struct NkLds {
     NkBins bins;
     const double *planes, *faces;
     const NkFacet *facets;
+    const double *resT;                  // [R] reservoir temperatures
+    const int *rf_off;                   // reservoir face tables (CSR), LDS copies when d.res_lds
+    const double *rf_cdf, *rf_verts;
     NkEvBuf ev;
-    int *wtot;            // [2][8] per-wave counts of the block prefix sums (double-buffered)
 };
 
 // geom: 0 = no ray-casting tables, 1 = planes/faces/facets staged in LDS, 2 = read from global memory (large meshes)
-__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, bool evbuf) {
+// nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged)
+__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, bool evbuf, int nrf) {
     int Fl = geom == 1 ? F : 0;
     int Pl = Fl ? NP : 0;
     int Fcl = geom == 1 ? Fc : 0;
     size_t nd = (size_t)S + 3 * S + NK_NREP * S + NK_NREP * 3 * S + 4 * R + (size_t)Fl * NK_FACE_DOUBLES +
-                (size_t)Pl * NK_PLANE_DOUBLES + (evbuf ? 6 * NK_EVCAP : 0);
-    size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) + (size_t)(NK_NREP * S + R + 1 + 16 + (evbuf ? 2 * NK_EVCAP : 0)) * 4;
+                (size_t)Pl * NK_PLANE_DOUBLES + (evbuf ? 6 * NK_EVCAP : 0) + (size_t)R + 10 * (size_t)nrf + 2;
+    size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) +
+                   (size_t)(NK_NREP * S + R + 1 + (R + 1) + (evbuf ? 2 * NK_EVCAP : 0)) * 4 + 16;
     return (bytes + 15) & ~(size_t)15;
 }
 
 // Cooperative fill of the read-only tables and zeroing of the bins; ends with a barrier.  GEOM as in nk_lds_bytes (a
 // compile-time choice, so that the table pointers are provably LDS and are read with ds_read, not flat loads);
-// EVBUF = carve the event buffer.
+// EVBUF = carve the event buffer.  Plane, face and facet tables start on 16-byte boundaries (they are read 16 bytes
+// at a time).
 template <int GEOM, bool EVBUF>
 __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem, NkLds &L) {
     const int S = d.S, R = d.R;
     const int Fl = GEOM == 1 ? d.F : 0;
     const int Pl = Fl ? d.NP : 0;
     const int Fcl = GEOM == 1 ? d.Fc : 0;
+    const int nrf = (GEOM == 1 && d.res_lds) ? d.res_nf : 0;
     double *p = (double *)smem;
     L.Tsv = p; p += S;
     L.cen = p; p += 3 * S;
     L.bins.E = p; p += NK_NREP * S;
     L.bins.flux = p; p += NK_NREP * 3 * S;
-    L.bins.resb = p; p += 4 * R;
+    L.bins.resb = p; p += 4 * R;                       // 36 S + 4 R doubles so far: even
     double *faces = p; p += (size_t)Fl * NK_FACE_DOUBLES;
     double *planes = p; p += (size_t)Pl * NK_PLANE_DOUBLES;
     if (EVBUF) {
@@ -79,12 +85,16 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
         L.ev.occ = p; p += NK_EVCAP; L.ev.nts = p; p += NK_EVCAP;
         L.ev.pid = (unsigned long long *)p; p += NK_EVCAP;
     }
+    double *resT = p; p += R;
+    double *rf_cdf = p; p += nrf;
+    double *rf_verts = p; p += 9 * (size_t)nrf;
+    p += ((size_t)R + 10 * (size_t)nrf) & 1;           // keep the facet table 16-byte aligned
     NkFacet *facets = (NkFacet *)p;
     unsigned int *u = (unsigned int *)(facets + Fcl);
     L.bins.N = u; u += NK_NREP * S;
     L.bins.nleave = u; u += R;
     L.bins.misc = u; u += 1;
-    L.wtot = (int *)u; u += 16;
+    int *rf_off = (int *)u; u += R + 1;
     if (EVBUF) { L.ev.mode = (int *)u; u += NK_EVCAP; L.ev.facet = (int *)u; u += NK_EVCAP; }
     const int t = threadIdx.x;
     for (int i = t; i < S; i += NK_WG) L.Tsv[i] = d.T_sv[i];
@@ -92,10 +102,15 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     for (int i = t; i < NK_NREP * S; i += NK_WG) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
     for (int i = t; i < NK_NREP * 3 * S; i += NK_WG) L.bins.flux[i] = 0.0;
     for (int i = t; i < 4 * R; i += NK_WG) L.bins.resb[i] = 0.0;
-    for (int i = t; i < R; i += NK_WG) L.bins.nleave[i] = 0u;
+    for (int i = t; i < R; i += NK_WG) { L.bins.nleave[i] = 0u; resT[i] = d.res_T[i]; }
     if (t == 0) L.bins.misc[0] = 0u;
     for (int i = t; i < Fl * NK_FACE_DOUBLES; i += NK_WG) faces[i] = d.faces[i];
     for (int i = t; i < Pl * NK_PLANE_DOUBLES; i += NK_WG) planes[i] = d.planes[i];
+    if (nrf > 0) {
+        for (int i = t; i <= R; i += NK_WG) rf_off[i] = d.res_face_off[i];
+        for (int i = t; i < nrf; i += NK_WG) rf_cdf[i] = d.res_face_cdf[i];
+        for (int i = t; i < 9 * nrf; i += NK_WG) rf_verts[i] = d.res_face_verts[i];
+    }
     {
         const int nw = Fcl * (int)(sizeof(NkFacet) / 4);
         const int32_t *src = (const int32_t *)d.facets;
@@ -104,6 +119,8 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     }
     if (GEOM == 1) { L.faces = faces; L.planes = planes; L.facets = facets; }
     else { L.faces = d.faces; L.planes = d.planes; L.facets = d.facets; }
+    L.resT = resT;
+    L.rf_off = rf_off; L.rf_cdf = rf_cdf; L.rf_verts = rf_verts;
     __syncthreads();
 }
 
@@ -125,26 +142,6 @@ __device__ __forceinline__ void nk_lds_flush(const NkDev &d, const NkLds &L, int
     }
 }
 
-// Exclusive prefix over the workgroup of two predicates at once (ballot + per-wave totals in LDS, one barrier).
-// `parity` alternates between calls so that the per-wave totals of consecutive calls never alias.
-__device__ __forceinline__ void nk_prefix2(bool a, bool b, int *wtot, int parity, int &offA, int &totA, int &offB,
-                                           int &totB) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const unsigned long long ma = __ballot(a), mb = __ballot(b);
-    const unsigned long long lower = (1ull << lane) - 1ull;
-    offA = __popcll(ma & lower);
-    offB = __popcll(mb & lower);
-    if (lane == 0) { wtot[parity * 8 + wave] = __popcll(ma); wtot[parity * 8 + 4 + wave] = __popcll(mb); }
-    __syncthreads();
-    totA = 0; totB = 0;
-#pragma unroll
-    for (int w = 0; w < NK_WG / 64; ++w) {
-        const int ca = wtot[parity * 8 + w], cb = wtot[parity * 8 + 4 + w];
-        if (w < wave) { offA += ca; offB += cb; }
-        totA += ca; totB += cb;
-    }
-}
-
 // Deferred lifetime_scattering (Population.py:1701-1710) for one particle.
 // The mode record is passed as two 32-byte halves {omega, vx, vy, vz} {tau0..tau3} (two dwordx4 pairs, no struct copy).
 __device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const double4 &ra, const double4 &rb, double x,
@@ -159,6 +156,21 @@ __device__ __forceinline__ void nk_store(const NkDev &d, int64_t i, double x, do
                                          int mode, int facet, unsigned long long pid) {
     d.x[i] = x; d.y[i] = y; d.z[i] = z; d.occ[i] = occ; d.nts[i] = nts;
     d.mode[i] = mode; d.facet[i] = facet; d.pid[i] = pid;
+}
+
+// Mesh.sample_surface on one reservoir facet (Mesh.py:923-951): face by area (np.random.choice, :937), then a uniform
+// point of the triangle (:945-947).  `off/cdf/verts` are the reservoir face tables (LDS or global).
+__device__ __forceinline__ void nk_sample_res_face(const int *off, const double *cdf, const double *verts, int r, double uf,
+                                                   double us, double ur, double &x0, double &y0, double &z0) {
+    const int f0 = off[r], nf = off[r + 1] - f0;
+    int a = nk_ss_right(cdf + f0, nf, uf);
+    a = a > nf - 1 ? nf - 1 : a;
+    const double *fv = verts + 9 * (f0 + a);
+    const double sq = sqrt(us);
+    const double a0 = 1.0 - sq, a1 = (1.0 - ur) * sq, a2 = ur * sq;
+    x0 = a0 * fv[0] + a1 * fv[3] + a2 * fv[6];
+    y0 = a0 * fv[1] + a1 * fv[4] + a2 * fv[7];
+    z0 = a0 * fv[2] + a1 * fv[5] + a2 * fv[8];
 }
 
 // ========================================================================================= kernels
@@ -226,9 +238,20 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
 // commit site: final particles are tallied and stored compacted at the write cursor, particles that meet a boundary
 // inside the step are parked in LDS, and whenever 64 are parked the whole wave processes them.
 #define NK_TILE 64
+#ifndef NK_SWEEP_OCC
+#define NK_SWEEP_OCC 3          // workgroups per CU the sweep is compiled for (3 x 4 waves = 3 waves per SIMD)
+#endif
+// Developer ablation build (make ablate -> libnanokappa_hip_ablate.so, env NK_DEBUG = mask): skip one part of the sweep
+// to see what bounds it.  1 no particle stores, 2 no tally, 4 no relaxation, 8 no boundary events, 16 no entering
+// particles.  The production library compiles NK_ABL(b) to false.
+#ifdef NK_ABLATE
+#define NK_ABL(b) ((d.dbg & (b)) != 0)
+#else
+#define NK_ABL(b) false
+#endif
 #define NK_WAVE_EVCAP (NK_EVCAP / (NK_WG / 64))     // 128 parked particles per wave (< 64 pending + 64 new)
 template <int GEOM, bool ROUGH>
-__global__ __launch_bounds__(NK_WG, 3) void k_sweep(NkDev d, uint32_t step, int do_relax, int do_flux_i) {
+__global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t step, int do_relax, int do_flux_i) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
     nk_lds_setup<GEOM, true>(d, smem, L);
@@ -241,6 +264,8 @@ __global__ __launch_bounds__(NK_WG, 3) void k_sweep(NkDev d, uint32_t step, int 
     if (total > d.spawn_cap) total = d.spawn_cap;
     const int64_t total_free = d.seg_free_prefix[d.nseg];
     if (total > total_free) { total = total_free; if (tid == 0) *d.overflow = 1; }
+    if (NK_ABL(16)) total = 0;
+    if (NK_ABL(4)) do_relax = 0;
     if (tid == 0 && blockIdx.x == 0) L.bins.misc[0] = (unsigned int)total;          // "emitted" column
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
@@ -295,53 +320,55 @@ __global__ __launch_bounds__(NK_WG, 3) void k_sweep(NkDev d, uint32_t step, int 
                     const int level = (int)(recd & 0xFFFu);
                     const int r = (int)(rm / d.M);
                     mode = (int)(rm - (int64_t)r * d.M);
+                    // everything that hangs off the record is requested at once; the Philox rounds cover the latency
+                    const double prob = d.enter_prob[rm];
+                    const double cval = d.res_cval[rm];
+                    const double4 ra = *reinterpret_cast<const double4 *>(d.modetab + mode);
                     pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level;
                     double uf, us, ur, ut;
                     nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
                     nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
-                    const double prob = d.enter_prob[rm];
-                    const double dt_in = (level == 1) ? d.dt * (1.0 - (d.res_cval[rm] / prob))
+                    const double dt_in = (level == 1) ? d.dt * (1.0 - (cval / prob))
                                                       : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
-                    const int rf = d.res_facet[r];
-                    const int f0 = d.facet_face_off[rf], nf = d.facet_face_off[rf + 1] - f0;
-                    int a = nk_ss_right(d.facet_face_cdf + f0, nf, uf);              // np.random.choice, Mesh.py:937
-                    a = a > nf - 1 ? nf - 1 : a;
-                    const double *fv = d.face_verts + 9 * (int64_t)d.facet_face_idx[f0 + a];
-                    const double sq = sqrt(us);
-                    const double a0 = 1.0 - sq, a1 = (1.0 - ur) * sq, a2 = ur * sq;  // Mesh.py:945-947
-                    const double x0 = a0 * fv[0] + a1 * fv[3] + a2 * fv[6];
-                    const double y0 = a0 * fv[1] + a1 * fv[4] + a2 * fv[7];
-                    const double z0 = a0 * fv[2] + a1 * fv[5] + a2 * fv[8];
-                    const NkMode *rec = d.modetab + mode;
-                    omega = rec->omega; vx = rec->vx; vy = rec->vy; vz = rec->vz;
-                    occ = nk_occupation(d, d.res_T[r], omega);                       // Population.py:506
+                    double x0, y0, z0;
+                    if (GEOM == 1 && d.res_lds) nk_sample_res_face(L.rf_off, L.rf_cdf, L.rf_verts, r, uf, us, ur, x0, y0, z0);
+                    else nk_sample_res_face(d.res_face_off, d.res_face_cdf, d.res_face_verts, r, uf, us, ur, x0, y0, z0);
+                    omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w;
+                    occ = nk_occupation(d, L.resT[r], omega);                        // Population.py:506
                     double tc;
                     nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x0, y0, z0, vx, vy, vz, tc, facet);
                     nts = tc / d.dt - dt_in / d.dt;                                  // :535
                     x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;   // :536
                 }
             }
-            // ---- commit: final particles -> tally + compacted store; boundary particles -> LDS buffer
-            const bool ev = act && nts < 0.0;
+            // ---- commit: boundary particles -> LDS buffer; final particles -> tally + compacted store
+            const bool ev = act && nts < 0.0 && !NK_ABL(8);
             const bool done = act && !ev;
-            if (done) nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, omega, vx, vy, vz, do_flux, rep);
             const unsigned long long mD = __ballot(done), mE = __ballot(ev);
-            if (done) {
-                const int o = w + __popcll(mD & lower);
-                if (o < d.segcap) nk_store(d, base + o, x, y, z, occ, nts, mode, facet, pid);
-                else *d.overflow = 1;
-            }
             if (ev) {
                 const int e = eb + ev_n + __popcll(mE & lower);
                 L.ev.x[e] = x; L.ev.y[e] = y; L.ev.z[e] = z; L.ev.occ[e] = occ; L.ev.nts[e] = nts;
                 L.ev.mode[e] = mode; L.ev.facet[e] = facet; L.ev.pid[e] = pid;
             }
-            w += __popcll(mD);
             ev_n += __popcll(mE);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS is in-order per wave; keep the compiler honest
-            // ---- drain: whenever a full batch is parked (everything on the last, empty tile) the whole wave runs the
-            // boundary event loop (Population.py:1546-1683), tallies, and appends the survivors
+            // whenever a full batch is parked (everything on the last, empty tile) the whole wave runs the boundary
+            // event loop below; the batch's mode records are requested now, under the tally and the stores
             const int keep = (t == nA + nB) ? 0 : NK_TILE - 1;
+            double4 pre = make_double4(0, 0, 0, 0);
+            if (ev_n > keep) {
+                const int n = ev_n >= NK_TILE ? NK_TILE : ev_n;
+                if (lane < n) pre = *reinterpret_cast<const double4 *>(d.modetab + L.ev.mode[eb + ev_n - n + lane]);
+            }
+            if (done && !NK_ABL(2)) nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, omega, vx, vy, vz, do_flux, rep);
+            if (done) {
+                const int o = w + __popcll(mD & lower);
+                if (o < d.segcap) { if (!NK_ABL(1)) nk_store(d, base + o, x, y, z, occ, nts, mode, facet, pid); }
+                else *d.overflow = 1;
+            }
+            w += __popcll(mD);
+            // ---- drain (Population.py:1546-1683), tally, append the survivors
+            bool first = true;
             while (ev_n > keep) {
                 const int n = ev_n >= NK_TILE ? NK_TILE : ev_n;
                 const int e = eb + ev_n - n + lane;
@@ -352,17 +379,18 @@ __global__ __launch_bounds__(NK_WG, 3) void k_sweep(NkDev d, uint32_t step, int 
                 if (eact) {
                     p.x = L.ev.x[e]; p.y = L.ev.y[e]; p.z = L.ev.z[e]; p.occ = L.ev.occ[e]; p.nts = L.ev.nts[e];
                     p.mode = L.ev.mode[e]; p.facet = L.ev.facet[e]; ppid = L.ev.pid[e];
-                    const NkMode *rec = d.modetab + p.mode;
-                    p.omega = rec->omega; p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
+                    const double4 ra = first ? pre : *reinterpret_cast<const double4 *>(d.modetab + p.mode);
+                    p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                     p.alive = true;
-                    nk_events<ROUGH>(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.bins, p, ppid, step);
+                    nk_events<ROUGH>(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, ppid, step);
                 }
+                first = false;
                 const bool alive = eact && p.alive;
-                if (alive) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
+                if (alive && !NK_ABL(2)) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
                 const unsigned long long mA = __ballot(alive);
                 if (alive) {
                     const int o = w + __popcll(mA & lower);
-                    if (o < d.segcap) nk_store(d, base + o, p.x, p.y, p.z, p.occ, p.nts, p.mode, p.facet, ppid);
+                    if (o < d.segcap) { if (!NK_ABL(1)) nk_store(d, base + o, p.x, p.y, p.z, p.occ, p.nts, p.mode, p.facet, ppid); }
                     else *d.overflow = 1;
                 }
                 w += __popcll(mA);
@@ -370,7 +398,7 @@ __global__ __launch_bounds__(NK_WG, 3) void k_sweep(NkDev d, uint32_t step, int 
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
         }
-        if (lane == 0) d.seg_count[seg] = w < d.segcap ? w : d.segcap;
+        if (lane == 0 && !NK_ABL(1)) d.seg_count[seg] = w < d.segcap ? w : d.segcap;
     }
     nk_lds_flush(d, L, blockIdx.x);
 }
@@ -422,7 +450,7 @@ __global__ void k_update(NkDev d, const double *acc, double *hist_row, int do_fl
     }
     for (int b = t; b < NB; b += blockDim.x) hist_row[b] = acc[b];
     __syncthreads();
-    if (t < S) d.T_sv[t] = Tnew;
+    if (t < S && !NK_ABL(2)) d.T_sv[t] = Tnew;
     // free-space prefix over the segments for the next step's spawn distribution
     {
         __shared__ long long part[512];

@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libnanokappa_hip.so')
+LIB_PATH = os.path.join(_HERE, os.environ.get('NK_LIBNAME', 'libnanokappa_hip.so'))   # NK_LIBNAME: developer builds
 
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
