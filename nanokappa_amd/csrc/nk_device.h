@@ -88,16 +88,10 @@ struct NkDev {
     int32_t res_lds;                  // 1: the three tables above are staged in LDS by the sweep
     const double *enter_prob;         // [R*M]
     double *res_counter;              // [R*M]
-    double *res_cval;                 // [R*M] counter / dice value used by the level-1 entry time
-    uint64_t *spawn_list;             // [spawn_cap] (rm << 12 | level) of every particle entering this step, in
-    int64_t spawn_cap;                // mode-major order (j = m*R + r), built by k_emit_count + k_emit_fill
-    int32_t *emit_loc;                // [R*M] exclusive offset of entry j inside its 256-entry block
-    int32_t *emit_cnt;                // [R*M] particles of entry j owned by this rank
-    int32_t *emit_blk_tot;            // [nblk] particles per block; [nblk] block offsets follow in emit_blk_off
-    int32_t *emit_blk_off;            // [nblk+1]
-    uint64_t *leftover;               // [spawn_cap] records that did not fit their home segment (placed by k_sweep<SPILL>)
-    int32_t *leftover_count;
-    int32_t *spill_cursor;            // rotating segment cursor of the spill pass
+    double *res_cval[2];              // [R*M] counter / dice value used by the level-1 entry time (buffer = step & 1)
+    uint64_t *spawn_list[2];          // [spawn_cap] (rm << 12 | level) of every particle entering at step k: buffer k & 1.
+    int64_t spawn_cap;                //   The sweep of step k consumes buffer k & 1 and, in its tail, fills buffer
+                                      //   (k+1) & 1 for the next step (k_emit_count primes the first step).
     // ---- rough facets
     int32_t Fr;
     const double *specularity;        // [Fr*M]
@@ -116,15 +110,13 @@ struct NkDev {
     int32_t nseg, segcap;
     int32_t *seg_count;               // [nseg] live particles per segment (contiguous from the segment start)
     int64_t *seg_free_prefix;         // [nseg+1] exclusive prefix of the free slots per segment (after the last step):
-                                      // win_mode 0 deals entering particles to segments in proportion to free space
-    int32_t *seg_win;                 // [nseg+1] mode windows: segment s is the home of modes [seg_win[s], seg_win[s+1])
-    int32_t win_mode;                 // 1: entering particles go to the segment that owns their mode (sorted population,
-                                      //    mode gathers become cache-resident); 0: free-space dealing (rough facets scramble modes)
+                                      // entering particles are dealt to segments in proportion to their free space
     double *x, *y, *z, *occ, *nts;
     int32_t *mode, *facet;
     uint64_t *pid;
     // ---- bookkeeping words in device memory
-    int32_t *alloc_count;             // particles entering this step (this rank) = length of spawn_list
+    int32_t *alloc_count;             // [2] particles entering at step k (this rank) = length of spawn_list[k & 1]
+    int32_t *ticket;                  // arrival counter of k_reduce's workgroups (the last one runs the update)
     int32_t *overflow;                // set when a particle had to be dropped for lack of capacity
     double *partials;                 // [rows][NB] per-workgroup tally rows
     int32_t NB;                       // bins per row = 5*S + 5*R + 1

@@ -38,8 +38,7 @@ struct nk_ctx {
     int g_sweep = 0;               // persistent grid of k_sweep = rows of `partials`
     std::vector<int32_t> h_seg_count;
     std::vector<hipEvent_t> evpool;
-    bool no_windows = false;          // NK_NO_WINDOWS=1: never route entering particles by mode window (ablation)
-    bool windows_valid = false;
+    bool spawn_ready = false;         // spawn_list[step & 1] already holds the particles entering at the next step
     double *acc = nullptr;         // [NB]
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -164,19 +163,19 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.nranks = 1;
     ctx->d.tau_row0 = -1;
     { const char *dbg = getenv("NK_DEBUG"); ctx->d.dbg = dbg ? atoi(dbg) : 0; }
-    ctx->no_windows = getenv("NK_NO_WINDOWS") != nullptr;
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
-    // bookkeeping words in device memory: alloc_count, overflow
+    // bookkeeping words in device memory: alloc_count[2], overflow, ticket
     const int32_t *p32 = nullptr;
     int rc;
-    if ((rc = nk_upload<int32_t>(ctx, nullptr, 4, &p32))) {
+    if ((rc = nk_upload<int32_t>(ctx, nullptr, 8, &p32))) {
         g_create_error = ctx->err;
         delete ctx;
         return rc;
     }
     ctx->d.alloc_count = (int32_t *)p32;
-    ctx->d.overflow = (int32_t *)p32 + 1;
+    ctx->d.overflow = (int32_t *)p32 + 2;
+    ctx->d.ticket = (int32_t *)p32 + 3;
     *out = ctx;
     return NK_OK;
 }
@@ -365,6 +364,7 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     d.R = r->R; d.res_gen = r->gen;
+    ctx->spawn_ready = false;
     d.res_nf = 0; d.res_lds = 0;
     NK_ARG((int64_t)d.R * d.M < (1ll << 28), "nk_set_reservoirs: R*Q*J too large for the particle id layout");
     if (r->R > 0) {
@@ -375,9 +375,21 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
         NK_UP(r->counter, (size_t)r->R * d.M, &c);
         d.res_counter = (double *)c;
         NK_UP((const double *)nullptr, (size_t)r->R * d.M, &c);
-        d.res_cval = (double *)c;
+        d.res_cval[0] = (double *)c;
+        NK_UP((const double *)nullptr, (size_t)r->R * d.M, &c);
+        d.res_cval[1] = (double *)c;
         double pmax = 0.0;
-        for (size_t i = 0; i < (size_t)r->R * d.M; ++i) pmax = std::max(pmax, r->enter_prob[i]);
+        int64_t most = 0;                               // upper bound of the particles entering in one step
+        for (size_t i = 0; i < (size_t)r->R * d.M; ++i) {
+            pmax = std::max(pmax, r->enter_prob[i]);
+            most += (int64_t)floor(r->enter_prob[i]) + 1;
+        }
+        d.spawn_cap = most;
+        const uint64_t *pu;
+        NK_UP((const uint64_t *)nullptr, (size_t)most, &pu);
+        d.spawn_list[0] = (uint64_t *)pu;
+        NK_UP((const uint64_t *)nullptr, (size_t)most, &pu);
+        d.spawn_list[1] = (uint64_t *)pu;
         NK_ARG(pmax < 4094.0, "nk_set_reservoirs: more than 4094 particles of one mode per step (id layout)");
         for (int i = 0; i < r->R; ++i) {
             NK_ARG(r->facet[i] >= 0 && r->facet[i] < d.Fc, "nk_set_reservoirs: facet index");
@@ -493,10 +505,8 @@ static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
     return NK_OK;
 }
 
-// Lay N particles out over the segments, sorted by mode (stable): the particles of one 64-wide tile then share a few
-// mode records and the sweep's gathers stay in cache.  Segment s becomes the home of the modes
-// [seg_win[s], seg_win[s+1]) -- equal-population windows; when the population cannot be balanced that way (fewer modes
-// than segments, a few modes holding most particles) the split is by count and win_mode is 0.
+// Lay N particles out over the segments (equal shares), sorted by mode (stable): the particles of a 64-wide tile then
+// share a few mode records.  Later arrivals are appended in (reservoir, mode) runs, so segments stay piecewise sorted.
 static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, const double *z, const int32_t *mode,
                       const double *occ, const double *n_ts, const int32_t *facet, const uint64_t *pid, uint64_t pid_offset) {
     NkDev &d = ctx->d;
@@ -510,29 +520,13 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
         std::vector<int64_t> cur(mstart.begin(), mstart.end() - 1);
         for (int64_t i = 0; i < N; ++i) order[(size_t)cur[(size_t)mode[i]]++] = i;
     }
-    std::vector<int32_t> win((size_t)d.nseg + 1, 0);
     std::vector<int64_t> start((size_t)d.nseg + 1, 0);
-    bool windows = !ctx->no_windows;
-    {
-        int m = 0;
-        for (int sgm = 0; sgm < d.nseg; ++sgm) {
-            const int64_t target = (N * (sgm + 1)) / d.nseg;
-            while (m < M && mstart[(size_t)m] < target) ++m;
-            if (sgm == d.nseg - 1) m = M;
-            win[(size_t)sgm + 1] = m;
-            start[(size_t)sgm + 1] = mstart[(size_t)m];
-            if (start[(size_t)sgm + 1] - start[(size_t)sgm] > (int64_t)(0.8 * d.segcap)) windows = false;
-        }
-    }
-    if (!windows)
-        for (int sgm = 0; sgm <= d.nseg; ++sgm) start[(size_t)sgm] = (N * sgm) / d.nseg;
+    for (int sgm = 0; sgm <= d.nseg; ++sgm) start[(size_t)sgm] = (N * sgm) / d.nseg;
     std::vector<int32_t> cnt((size_t)d.nseg);
     for (int sgm = 0; sgm < d.nseg; ++sgm) {
         cnt[(size_t)sgm] = (int32_t)(start[(size_t)sgm + 1] - start[(size_t)sgm]);
         NK_ARG(cnt[(size_t)sgm] <= d.segcap, "nk_upload_particles: segment capacity too small");
     }
-    d.win_mode = (windows && d.Fr == 0) ? 1 : 0;
-    ctx->windows_valid = windows;
     std::vector<double> bd((size_t)d.cap);
     auto put = [&](const void *src, size_t esz, void *dst) -> int {
         if (!src) return NK_OK;
@@ -562,7 +556,6 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
         if ((rc = put(ids.data(), 8, d.pid))) return rc;
     }
     NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
-    NK_HIP(hipMemcpy(d.seg_win, win.data(), win.size() * 4, hipMemcpyHostToDevice));
     std::vector<int64_t> fp((size_t)d.nseg + 1, 0);
     for (int sgm = 0; sgm < d.nseg; ++sgm) fp[sgm + 1] = fp[sgm] + (d.segcap - cnt[sgm]);
     NK_HIP(hipMemcpy(d.seg_free_prefix, fp.data(), fp.size() * 8, hipMemcpyHostToDevice));
@@ -581,7 +574,6 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
     d.nseg = (int32_t)nseg;
     d.segcap = (int32_t)segcap;
     d.cap = nseg * segcap;
-    d.spawn_cap = d.cap;
     const double *pd; const int32_t *pi; const uint64_t *pu;
 #define NK_PALLOC(T, field, ptr, count)                                                                \
     do { int rc_ = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (rc_) return rc_; d.field = (T *)ptr; } while (0)
@@ -589,9 +581,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
     NK_PALLOC(double, occ, pd, d.cap); NK_PALLOC(double, nts, pd, d.cap);
     NK_PALLOC(int32_t, mode, pi, d.cap); NK_PALLOC(int32_t, facet, pi, d.cap);
     NK_PALLOC(uint64_t, pid, pu, d.cap);
-    NK_PALLOC(uint64_t, spawn_list, pu, d.spawn_cap);
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
-    NK_PALLOC(int32_t, seg_win, pi, d.nseg + 1);
     { const int64_t *pl; int rc_ = nk_upload<int64_t>(ctx, nullptr, (size_t)d.nseg + 1, &pl, true); if (rc_) return rc_; d.seg_free_prefix = (int64_t *)pl; }
 #undef NK_PALLOC
     return NK_OK;
@@ -619,6 +609,7 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
                         uint64_t pid_offset) {
     NK_ARG(ctx && N >= 0, "nk_upload_particles: bad arguments");
     NK_ARG(N == 0 || (x && y && z && mode && occ), "nk_upload_particles: x, y, z, mode, occ are required");
+    NK_ARG(ctx->have_material, "nk_upload_particles: call nk_set_material first");
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     NK_HIP(hipStreamSynchronize(ctx->stream));
@@ -628,8 +619,8 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     }
     int rc = nk_scatter(ctx, N, x, y, z, mode, occ, n_ts, facet, pid, pid_offset);
     if (rc) return rc;
-    int32_t zero32[4] = {0, 0, 0, 0};
-    NK_HIP(hipMemcpy(d.alloc_count, zero32, 16, hipMemcpyHostToDevice));
+    int32_t zero32 = 0;
+    NK_HIP(hipMemcpy(d.overflow, &zero32, 4, hipMemcpyHostToDevice));
     ctx->pending_relax = false;
     return NK_OK;
 }
@@ -701,23 +692,34 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         const int fe = ctx->params.flux_every;
         const int do_flux = (fe > 0 && ((ctx->step + 1) % fe) == 0) ? 1 : 0;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
-        if (R > 0) k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
+        const int buf = (int)(step & 1u);
+        if (R > 0 && !ctx->spawn_ready) {                // prime: nobody has prepared this step's entering particles
+            NK_HIP(hipMemsetAsync(d.alloc_count, 0, 8, ctx->stream));
+            k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
+        }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
+        // the sweep's tail prepares step + 1 when each workgroup's slice of the (reservoir, mode) table is small
+        const bool emit_next = R > 0 && ((int64_t)R * d.M + g_sweep - 1) / g_sweep <= (int64_t)NK_EMIT_KMAX * NK_WG;
         {
             const int rl = ctx->pending_relax ? 1 : 0;
             const int gm = nk_geom_mode(ctx);
-            if (gm == 1 && d.Fr > 0) k_sweep<1, true><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux);
-            else if (gm == 1) k_sweep<1, false><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux);
-            else if (d.Fr > 0) k_sweep<2, true><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux);
-            else k_sweep<2, false><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux);
+            const int flags = do_flux | (emit_next ? 2 : 0);
+            if (gm == 1 && d.Fr > 0) k_sweep<1, true><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags);
+            else if (gm == 1) k_sweep<1, false><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags);
+            else if (d.Fr > 0) k_sweep<2, true><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags);
+            else k_sweep<2, false><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags);
         }
+        ctx->spawn_ready = emit_next;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
-        k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d.partials, g_sweep, NB, ctx->acc);
+        double *hrow = ctx->hist + (size_t)s * HROW;
         if (ctx->comm) {
+            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, buf, 0);
             ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB, ncclDouble, ncclSum, ctx->comm, ctx->stream);
             if (nrc != ncclSuccess) { ctx->err = "ncclAllReduce failed"; return NK_ERR_COMM; }
+            k_update<<<1, NK_WG, 0, ctx->stream>>>(d, ctx->acc, hrow, do_flux, buf);
+        } else {
+            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, buf, 1);
         }
-        k_update<<<1, 512, 0, ctx->stream>>>(d, ctx->acc, ctx->hist + (size_t)s * HROW, do_flux);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
         ctx->pending_relax = true;
         ctx->step += 1;
@@ -848,6 +850,7 @@ int nk_comm_unique_id(void *id128) {
 }
 int nk_comm_init(nk_ctx *ctx, const void *id128, int rank, int nranks) {
     NK_ARG(ctx && id128 && nranks >= 1 && rank >= 0 && rank < nranks, "nk_comm_init: bad arguments");
+    NK_ARG(!ctx->spawn_ready, "nk_comm_init: must be called before the first nk_step (emission ownership is per rank)");
     NK_HIP(hipSetDevice(ctx->device));
     ctx->d.rank = rank;
     ctx->d.nranks = nranks;

@@ -174,60 +174,84 @@ __device__ __forceinline__ void nk_sample_res_face(const int *off, const double 
 }
 
 // ========================================================================================= kernels
-// Which modes enter at each reservoir this step, and how many particles of each:
-// fill_reservoirs 'constant' (Population.py:358-370) / 'fixed_rate' (:408-420).  One lane per (reservoir, mode);
-// every entering particle gets one 64-bit record (rm << 12 | level) in spawn_list, in (reservoir, mode) order within a
-// workgroup's chunk.
-__global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
-    const int64_t RM = (int64_t)d.R * d.M;
-    const int64_t rm = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    int c = 0, c_mine = 0;
-    if (rm < RM) {
-        const double prob = d.enter_prob[rm];
-        const double fixed = floor(prob);
-        int mask;
-        double cv;
-        if (d.res_gen == 0) {
-            cv = d.res_counter[rm] + (prob - fixed);
-            mask = cv >= 1.0;
-            cv -= (double)mask;
-            d.res_counter[rm] = cv;
-        } else {
-            double d1;
-            nk_uniform2_dev(d.seed, (uint64_t)rm | 0xFFFFFFFF00000000ull, step, NK_TAG_DICE, cv, d1);
-            mask = cv <= (prob - fixed);
-        }
-        c = (int)fixed + mask;
-        if (c > 0) d.res_cval[rm] = cv;
-        if (d.nranks == 1) c_mine = c;
-        else for (int level = c; level >= 1; --level) c_mine += (((rm + level + (int64_t)step) % d.nranks) == d.rank);
+// Which modes enter at each reservoir at `step`, and how many particles of each: fill_reservoirs 'constant'
+// (Population.py:358-370) / 'fixed_rate' (:408-420) for one (reservoir, mode) entry.  c = particles entering,
+// c_mine = those this rank owns (emission_owner: (rm + level + step) % nranks).
+__device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int buf, int64_t rm, int &c, int &c_mine) {
+    const double prob = d.enter_prob[rm];
+    const double fixed = floor(prob);
+    int mask;
+    double cv;
+    if (d.res_gen == 0) {
+        cv = d.res_counter[rm] + (prob - fixed);
+        mask = cv >= 1.0;
+        cv -= (double)mask;
+        d.res_counter[rm] = cv;
+    } else {
+        double d1;
+        nk_uniform2_dev(d.seed, (uint64_t)rm | 0xFFFFFFFF00000000ull, step, NK_TAG_DICE, cv, d1);
+        mask = cv <= (prob - fixed);
     }
-    // allocation in spawn_list: wave scan, then ONE global atomic per workgroup (a hot counter serves ~90 atomics/us)
-    int incl = c_mine;
+    c = (int)fixed + mask;
+    if (c > 0) d.res_cval[buf][rm] = cv;
+    c_mine = 0;
+    if (d.nranks == 1) c_mine = c;
+    else for (int level = c; level >= 1; --level) c_mine += (((rm + level + (int64_t)step) % d.nranks) == d.rank);
+}
+
+// The entries [e0, e1) (at most KMAX * NK_WG of them) handled by one workgroup: every entering particle gets one
+// 64-bit record (rm << 12 | level) in spawn_list[buf].  Space is claimed with ONE global atomic per workgroup (a hot
+// counter serves ~90 atomics/us).  Must be called by all threads of the workgroup.
+template <int KMAX>
+__device__ __forceinline__ void nk_emit_block(const NkDev &d, uint32_t step, int buf, int64_t e0, int64_t e1, int *wsum,
+                                              int *bbase) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int c[KMAX], cm[KMAX];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int64_t rm = e0 + (int64_t)k * NK_WG + tid;
+        c[k] = 0; cm[k] = 0;
+        if (rm < e1) nk_emit_entry(d, step, buf, rm, c[k], cm[k]);
+        mine += cm[k];
+    }
+    int incl = mine;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
     const int total = __shfl(incl, 63, 64);
-    __shared__ int wsum[NK_WG / 64];
-    __shared__ int bbase;
-    const int wave = threadIdx.x >> 6;
     if (lane == 63) wsum[wave] = total;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         int t = 0;
         for (int w = 0; w < NK_WG / 64; ++w) t += wsum[w];
-        bbase = t > 0 ? atomicAdd(d.alloc_count, t) : 0;
+        *bbase = t > 0 ? atomicAdd(d.alloc_count + buf, t) : 0;
     }
     __syncthreads();
-    int base = bbase;
+    int base = *bbase;
     for (int w = 0; w < wave; ++w) base += wsum[w];
-    int64_t g = (int64_t)base + incl - c_mine;
-    for (int level = c; level >= 1 && c_mine > 0; --level) {
-        if (d.nranks > 1 && (((rm + level + (int64_t)step) % d.nranks) != d.rank)) continue;
-        if (g < d.spawn_cap) d.spawn_list[g] = ((uint64_t)rm << 12) | (uint64_t)level;
-        else *d.overflow = 1;
-        ++g;
+    int64_t g = (int64_t)base + incl - mine;
+    uint64_t *list = d.spawn_list[buf];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int64_t rm = e0 + (int64_t)k * NK_WG + tid;
+        for (int level = c[k]; level >= 1 && cm[k] > 0; --level) {
+            if (d.nranks > 1 && (((rm + level + (int64_t)step) % d.nranks) != d.rank)) continue;
+            if (g < d.spawn_cap) list[g] = ((uint64_t)rm << 12) | (uint64_t)level;
+            else *d.overflow = 1;
+            ++g;
+        }
     }
+}
+#define NK_EMIT_KMAX 4          // entries per thread the sweep's tail may take (else k_emit_count runs every step)
+
+// Stand-alone emission pass: primes the first step after (re)configuration, and serves every step when the
+// (reservoir, mode) table is too large for the sweep's tail.
+__global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
+    __shared__ int wsum[NK_WG / 64];
+    __shared__ int bbase;
+    const int64_t RM = (int64_t)d.R * d.M;
+    const int64_t e0 = (int64_t)blockIdx.x * NK_WG;
+    nk_emit_block<1>(d, step, (int)(step & 1u), e0, e0 + NK_WG < RM ? e0 + NK_WG : RM, wsum, &bbase);
 }
 
 // The sweep: persistent WAVES, each taking segments w, w + n_waves, ...  A wave owns its segment and its slice of the
@@ -251,16 +275,19 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
 #endif
 #define NK_WAVE_EVCAP (NK_EVCAP / (NK_WG / 64))     // 128 parked particles per wave (< 64 pending + 64 new)
 template <int GEOM, bool ROUGH>
-__global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t step, int do_relax, int do_flux_i) {
+__global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
     nk_lds_setup<GEOM, true>(d, smem, L);
-    const bool do_flux = do_flux_i != 0;
+    const bool do_flux = (flags & 1) != 0;          // flags: 1 = heat-flux step, 2 = emit the next step's particles
+    const int buf = (int)(step & 1u);
+    __shared__ int emit_wsum[NK_WG / 64];
+    __shared__ int emit_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rep = lane & (NK_NREP - 1);
     const unsigned long long lower = (1ull << lane) - 1ull;
     const int eb = wave * NK_WAVE_EVCAP;                    // this wave's slice of the event buffer
-    int64_t total = d.R > 0 ? (int64_t)*d.alloc_count : 0;
+    int64_t total = d.R > 0 ? (int64_t)d.alloc_count[buf] : 0;
     if (total > d.spawn_cap) total = d.spawn_cap;
     const int64_t total_free = d.seg_free_prefix[d.nseg];
     if (total > total_free) { total = total_free; if (tid == 0) *d.overflow = 1; }
@@ -315,14 +342,14 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 const int64_t g = g0 + (int64_t)(t - nA) * NK_TILE + lane;
                 act = g < g1;
                 if (act) {
-                    const uint64_t recd = d.spawn_list[g];
+                    const uint64_t recd = d.spawn_list[buf][g];
                     const int64_t rm = (int64_t)(recd >> 12);
                     const int level = (int)(recd & 0xFFFu);
                     const int r = (int)(rm / d.M);
                     mode = (int)(rm - (int64_t)r * d.M);
                     // everything that hangs off the record is requested at once; the Philox rounds cover the latency
                     const double prob = d.enter_prob[rm];
-                    const double cval = d.res_cval[rm];
+                    const double cval = d.res_cval[buf][rm];
                     const double4 ra = *reinterpret_cast<const double4 *>(d.modetab + mode);
                     pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level;
                     double uf, us, ur, ut;
@@ -400,15 +427,116 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
         }
         if (lane == 0 && !NK_ABL(1)) d.seg_count[seg] = w < d.segcap ? w : d.segcap;
     }
+    // tail: this workgroup's slice of the (reservoir, mode) table for the NEXT step (fill_reservoirs does not look at
+    // the particles), into the other spawn buffer -- no separate launch, and it fills the sweep's ragged end
+    if (flags & 2) {
+        const int64_t RM = (int64_t)d.R * d.M;
+        const int64_t per = (RM + gridDim.x - 1) / gridDim.x;
+        const int64_t e0 = (int64_t)blockIdx.x * per;
+        nk_emit_block<NK_EMIT_KMAX>(d, step + 1u, buf ^ 1, e0 < RM ? e0 : RM, e0 + per < RM ? e0 + per : RM, emit_wsum, &emit_base);
+    }
     nk_lds_flush(d, L, blockIdx.x);
 }
 
-// Column sums of the tally rows, fixed order -> bitwise reproducible for a given grid.
-__global__ __launch_bounds__(NK_WG) void k_reduce(const double *partials, int rows, int NB, double *acc) {
+// Normalise, invert E(T), publish the new subvolume temperatures, history row: calculate_energy (Population.py:719-728)
+// + refresh_temperatures (:692), run by ONE workgroup.
+// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, 0, 0, overflow
+__device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc, double *hist_row, int do_flux, int buf,
+                                               long long *part) {
+    // One workgroup, so everything here is a chain of memory latencies: all first-round loads are issued together, the
+    // E(T) / T(E) tables are read as one 4-point window around the old temperature (T moves by a small fraction of
+    // the 0.1 K table step per timestep; the general search is the fallback), and the segment counts stay in registers.
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int S = d.S, NB = d.NB, n = d.nE;
+    constexpr int KMAX = 32;                                   // nseg <= 8192, nth = 256
+    const int lane = tid & 63, wave = tid >> 6, nw = (nth + 63) >> 6;
+    const int per = (d.nseg + nth - 1) / nth;                  // <= KMAX contiguous segments per thread
+    int fr[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {                           // all loads in flight at once
+        const int sgm = tid * per + k;
+        fr[k] = (k < per && sgm < d.nseg) ? d.segcap - d.seg_count[sgm] : 0;
+    }
+    const double Ta = d.Tarr[0], Tb = d.Tarr[1], Tz = d.Tarr[n - 1], Ea = d.Earr[0], Ez = d.Earr[n - 1];
+    for (int t = tid; t < S; t += nth) {
+        const double Eraw = acc[t], Ns = acc[S + t];
+        const double Told = d.T_ref_local ? d.T_sv[t] : d.T_ref;
+        double norm;
+        if (d.norm_fixed) norm = d.active_modes / (d.particle_density * d.sv_volume[t]);
+        else { norm = d.active_modes / Ns; if (isnan(norm)) norm = 0.0; }
+        double E = Eraw * norm / d.QV;
+        int it = (int)((Told - Ta) / (Tb - Ta));               // uniform-grid guess of searchsorted(Tarr, Told)
+        it = it < 0 ? 0 : (it > n - 1 ? n - 1 : it);
+        int base = it - 1;
+        base = base < 0 ? 0 : (base > n - 4 ? n - 4 : base);
+        double wT[4], wE[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const int q = n >= 4 ? base + j : 0; wT[j] = d.Tarr[q]; wE[j] = d.Earr[q]; }
+        // E(T_old), crystal_energy_function
+        double ref;
+        if (Told < Ta) ref = Ea;
+        else if (Told > Tz) ref = Ez;
+        else if (n >= 4 && wT[0] < Told && !(wT[3] < Told)) {
+            const int c = (wT[1] < Told) + (wT[2] < Told);     // searchsorted-left = base + 1 + c
+            const double xlo = c == 0 ? wT[0] : (c == 1 ? wT[1] : wT[2]), xhi = c == 0 ? wT[1] : (c == 1 ? wT[2] : wT[3]);
+            const double ylo = c == 0 ? wE[0] : (c == 1 ? wE[1] : wE[2]), yhi = c == 0 ? wE[1] : (c == 1 ? wE[2] : wE[3]);
+            ref = (yhi - ylo) / (xhi - xlo) * (Told - xlo) + ylo;
+        } else { int io; ref = nk_interp_lin_hint(d.Tarr, d.Earr, n, Told, it, io); }
+        E += ref;
+        // T(E), temperature_function
+        double Tnew;
+        if (E < Ea) Tnew = d.Tfill_lo;
+        else if (E > Ez) Tnew = d.Tfill_hi;
+        else if (n >= 4 && wE[0] < E && !(wE[3] < E)) {
+            const int c = (wE[1] < E) + (wE[2] < E);
+            const double xlo = c == 0 ? wE[0] : (c == 1 ? wE[1] : wE[2]), xhi = c == 0 ? wE[1] : (c == 1 ? wE[2] : wE[3]);
+            const double ylo = c == 0 ? wT[0] : (c == 1 ? wT[1] : wT[2]), yhi = c == 0 ? wT[1] : (c == 1 ? wT[2] : wT[3]);
+            Tnew = (yhi - ylo) / (xhi - xlo) * (E - xlo) + ylo;
+        } else { int io; Tnew = nk_interp_lin_hint(d.Earr, d.Tarr, n, E, it, io); }
+        hist_row[NB + t] = Tnew;
+        hist_row[NB + S + t] = E;
+        if (!NK_ABL(2)) d.T_sv[t] = Tnew;
+    }
+    for (int b = tid; b < NB; b += nth) hist_row[b] = acc[b];
+    // free-space prefix over the segments for the next step's spawn distribution: thread t owns the contiguous
+    // segments [t*per, (t+1)*per); one workgroup scan of the per-thread sums
+    long long mine = 0;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) mine += fr[k];
+    long long incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { long long v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    if (lane == 63) part[wave] = incl;
+    __syncthreads();
+    long long wbase = 0, run = 0;
+    for (int w = 0; w < nw; ++w) { const long long v = part[w]; if (w < wave) wbase += v; run += v; }
+    long long pre = wbase + incl - mine;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int sgm = tid * per + k;
+        if (k < per && sgm < d.nseg) d.seg_free_prefix[sgm] = pre;
+        pre += fr[k];
+    }
+    if (tid == 0) {
+        d.seg_free_prefix[d.nseg] = run;
+        d.alloc_count[buf] = 0;                      // consumed by this step's sweep; refilled two steps on
+        hist_row[NB + 2 * S + 0] = (double)do_flux;
+        hist_row[NB + 2 * S + 1] = 0.0;
+        hist_row[NB + 2 * S + 2] = 0.0;
+        hist_row[NB + 2 * S + 3] = (double)*d.overflow;
+    }
+}
+
+// Column sums of the tally rows, fixed order -> bitwise reproducible for a given grid.  One workgroup per column.
+// fuse != 0 (single rank): the workgroup that finishes last also runs the update, saving a launch.
+__global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc, double *hist_row, int do_flux, int buf,
+                                                  int fuse) {
     __shared__ double sh[NK_WG];
-    const int b = blockIdx.x;
+    __shared__ long long part[NK_WG];
+    __shared__ int last;
+    const int b = blockIdx.x, NB = d.NB;
     double v = 0.0;
-    for (int r = threadIdx.x; r < rows; r += NK_WG) v += partials[(int64_t)r * NB + b];
+    for (int r = threadIdx.x; r < rows; r += NK_WG) v += d.partials[(int64_t)r * NB + b];
     sh[threadIdx.x] = v;
     __syncthreads();
     for (int o = NK_WG / 2; o > 0; o >>= 1) {
@@ -416,66 +544,22 @@ __global__ __launch_bounds__(NK_WG) void k_reduce(const double *partials, int ro
         __syncthreads();
     }
     if (threadIdx.x == 0) acc[b] = sh[0];
+    if (!fuse) return;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = (atomicAdd(d.ticket, 1) == (int)gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) *d.ticket = 0;
+    __threadfence();
+    nk_update_body(d, acc, hist_row, do_flux, buf, part);
 }
 
-// Normalise, invert E(T), publish the new subvolume temperatures, history row.
-// calculate_energy (Population.py:719-728) + refresh_temperatures (:692).
-// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, live (this rank), 0, overflow
-__global__ void k_update(NkDev d, const double *acc, double *hist_row, int do_flux) {
-    const int t = threadIdx.x;
-    const int S = d.S, NB = d.NB;
-    double Tnew = 0.0;
-    if (t < S) {
-        double Eraw = acc[t], Ns = acc[S + t];
-        double norm;
-        if (d.norm_fixed) norm = d.active_modes / (d.particle_density * d.sv_volume[t]);
-        else { norm = d.active_modes / Ns; if (isnan(norm)) norm = 0.0; }
-        double E = Eraw * norm / d.QV;
-        // E(T_old) then T(E): the tables are searched from a guess (uniform T grid; the new T is next to the old one)
-        const double Told = d.T_ref_local ? d.T_sv[t] : d.T_ref;
-        const int n = d.nE;
-        const double Ta = d.Tarr[0], Tb = d.Tarr[1];
-        int it = (int)((Told - Ta) / (Tb - Ta));
-        double ref;
-        if (Told < Ta) { ref = d.Earr[0]; it = 0; }
-        else if (Told > d.Tarr[n - 1]) { ref = d.Earr[n - 1]; it = n - 1; }
-        else ref = nk_interp_lin_hint(d.Tarr, d.Earr, n, Told, it, it);
-        E += ref;
-        int ie;
-        if (E < d.Earr[0]) Tnew = d.Tfill_lo;
-        else if (E > d.Earr[n - 1]) Tnew = d.Tfill_hi;
-        else Tnew = nk_interp_lin_hint(d.Earr, d.Tarr, n, E, it, ie);
-        hist_row[NB + t] = Tnew;
-        hist_row[NB + S + t] = E;
-    }
-    for (int b = t; b < NB; b += blockDim.x) hist_row[b] = acc[b];
-    __syncthreads();
-    if (t < S && !NK_ABL(2)) d.T_sv[t] = Tnew;
-    // free-space prefix over the segments for the next step's spawn distribution
-    {
-        __shared__ long long part[512];
-        const int per = (d.nseg + (int)blockDim.x - 1) / (int)blockDim.x;
-        const int lo = t * per, hi = (lo + per < d.nseg) ? lo + per : d.nseg;
-        long long sum = 0;
-        for (int k = lo; k < hi; ++k) sum += d.segcap - d.seg_count[k];
-        part[t] = sum;
-        __syncthreads();
-        if (t == 0) {
-            long long run = 0;
-            for (int k = 0; k < (int)blockDim.x; ++k) { long long v = part[k]; part[k] = run; run += v; }
-            d.seg_free_prefix[d.nseg] = run;
-        }
-        __syncthreads();
-        long long run = part[t];
-        for (int k = lo; k < hi; ++k) { d.seg_free_prefix[k] = run; run += d.segcap - d.seg_count[k]; }
-    }
-    if (t == 0) {
-        *d.alloc_count = 0;
-        hist_row[NB + 2 * S + 0] = (double)do_flux;
-        hist_row[NB + 2 * S + 1] = 0.0;
-        hist_row[NB + 2 * S + 2] = 0.0;
-        hist_row[NB + 2 * S + 3] = (double)*d.overflow;
-    }
+// The update as its own launch (after the RCCL all-reduce when nranks > 1).
+__global__ __launch_bounds__(NK_WG) void k_update(NkDev d, const double *acc, double *hist_row, int do_flux, int buf) {
+    __shared__ long long part[NK_WG];
+    nk_update_body(d, acc, hist_row, do_flux, buf, part);
 }
 
 // Stand-alone lifetime_scattering (flushes the deferred relaxation).
