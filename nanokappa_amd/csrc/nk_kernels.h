@@ -196,7 +196,8 @@ __device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int
     if (c > 0) d.res_cval[buf][rm] = cv;
     c_mine = 0;
     if (d.nranks == 1) c_mine = c;
-    else for (int level = c; level >= 1; --level) c_mine += (((rm + level + (int64_t)step) % d.nranks) == d.rank);
+    else for (int level = c; level >= 1; --level)                  // rm < 2^28, so 32-bit arithmetic is exact
+        c_mine += (((uint32_t)rm + (uint32_t)level + step) % (uint32_t)d.nranks) == (uint32_t)d.rank;
 }
 
 // The entries [e0, e1) (at most KMAX * NK_WG of them) handled by one workgroup: every entering particle gets one
@@ -205,15 +206,18 @@ __device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int
 template <int KMAX>
 __device__ __forceinline__ void nk_emit_block(const NkDev &d, uint32_t step, int buf, int64_t e0, int64_t e1, int *wsum,
                                               int *bbase) {
+    static_assert(KMAX <= 4, "counts are packed 16 bits per entry");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int c[KMAX], cm[KMAX];
-    int mine = 0;
-#pragma unroll
+    uint64_t pc = 0, pm = 0;                       // (c, c_mine) of this thread's entries, 16 bits each (c <= 4095);
+    int mine = 0;                                  // rolled loops: this sits in the sweep's tail, keep the code small
+#pragma unroll 1
     for (int k = 0; k < KMAX; ++k) {
         const int64_t rm = e0 + (int64_t)k * NK_WG + tid;
-        c[k] = 0; cm[k] = 0;
-        if (rm < e1) nk_emit_entry(d, step, buf, rm, c[k], cm[k]);
-        mine += cm[k];
+        int c = 0, cm = 0;
+        if (rm < e1) nk_emit_entry(d, step, buf, rm, c, cm);
+        pc |= (uint64_t)c << (16 * k);
+        pm |= (uint64_t)cm << (16 * k);
+        mine += cm;
     }
     int incl = mine;
 #pragma unroll
@@ -231,11 +235,12 @@ __device__ __forceinline__ void nk_emit_block(const NkDev &d, uint32_t step, int
     for (int w = 0; w < wave; ++w) base += wsum[w];
     int64_t g = (int64_t)base + incl - mine;
     uint64_t *list = d.spawn_list[buf];
-#pragma unroll
+#pragma unroll 1
     for (int k = 0; k < KMAX; ++k) {
         const int64_t rm = e0 + (int64_t)k * NK_WG + tid;
-        for (int level = c[k]; level >= 1 && cm[k] > 0; --level) {
-            if (d.nranks > 1 && (((rm + level + (int64_t)step) % d.nranks) != d.rank)) continue;
+        const int c = (int)((pc >> (16 * k)) & 0xFFFFu), cm = (int)((pm >> (16 * k)) & 0xFFFFu);
+        for (int level = c; level >= 1 && cm > 0; --level) {
+            if (d.nranks > 1 && (((uint32_t)rm + (uint32_t)level + step) % (uint32_t)d.nranks) != (uint32_t)d.rank) continue;
             if (g < d.spawn_cap) list[g] = ((uint64_t)rm << 12) | (uint64_t)level;
             else *d.overflow = 1;
             ++g;
