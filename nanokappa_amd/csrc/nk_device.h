@@ -404,66 +404,81 @@ struct NkParticle {
     bool alive;
 };
 
-// One particle's boundary events inside a timestep: Population.boundary_scattering (Population.py:1546-1683) restated
-// per particle.  On entry (x,y,z) is the end-of-step position of the free drift and nts < 0.
+// Boundary events inside a timestep: Population.boundary_scattering (Population.py:1546-1683) restated per particle.
+// On entry (x,y,z) is the end-of-step position of the free drift and nts < 0 (first call: cts = 0, ev = 0).
+// ONE event per call: the reference loops "while any particle still has time left"; here a particle that needs another
+// event goes back to the event buffer and joins the next batch, so every pass of the wave runs 64 particles with
+// exactly one event each (a while-loop per lane would idle most lanes: few particles cross more than one wall).
+// Returns NK_EV_DONE (remainder drifted, particle final), NK_EV_DEAD (absorbed) or NK_EV_MORE (another event pending;
+// cts / ev carry the consumed fraction of the step and the event count, which also numbers the RNG draws).
 // ROUGH = false compiles the rough-facet branch out (meshes without 'R' facets): fewer registers in the sweep.
+#define NK_EV_DONE 0
+#define NK_EV_DEAD 1
+#define NK_EV_MORE 2
 template <bool ROUGH>
-__device__ __forceinline__ void nk_events(const NkDev &d, const double *planes, const double *faces,
-                                          const NkFacet *facets, const double *cen, const double *Tsv,
-                                          const double *resT, NkBins &b, NkParticle &p, uint64_t pid, uint32_t step) {
+__device__ __forceinline__ int nk_event_one(const NkDev &d, const double *planes, const double *faces,
+                                            const NkFacet *facets, const double *cen, const double *Tsv,
+                                            const double *resT, NkBins &b, NkParticle &p, double &cts, uint32_t &ev,
+                                            uint64_t pid, uint32_t step) {
     const double dt = d.dt;
-    double cts = 0.0;
-    uint32_t ev = 0;
-    while (cts < 1.0) {
-        double rem = 1.0 - cts;
-        if (rem > p.nts) {
-            int fi = p.facet < 0 ? d.Fc - 1 : p.facet;      // a miss indexes the last facet
-            const NkFacet fc = facets[fi];
-            if (fc.bc == 'T' || fc.bc == 'F') {             // I. absorbed by a reservoir, Population.py:1568-1608
-                int r = p.facet < 0 ? -1 : fc.res;
-                if (r >= 0) {
-                    double Tr = d.T_ref_local ? resT[r] : d.T_ref;
-                    double e = d.hbar * p.omega * (p.occ - nk_occupation(d, Tr, p.omega));
-                    double vn = p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz;
-                    atomicAdd(&b.nleave[r], 1u);
-                    atomicAdd(&b.resb[4 * r + 0], -e);
-                    atomicAdd(&b.resb[4 * r + 1], e * p.vx / vn);
-                    atomicAdd(&b.resb[4 * r + 2], e * p.vy / vn);
-                    atomicAdd(&b.resb[4 * r + 3], e * p.vz / vn);
+    {
+        int fi = p.facet < 0 ? d.Fc - 1 : p.facet;          // a miss indexes the last facet
+        const NkFacet fc = facets[fi];
+        if (fc.bc == 'T' || fc.bc == 'F') {                 // I. absorbed by a reservoir, Population.py:1568-1608
+            int r = p.facet < 0 ? -1 : fc.res;
+            if (r >= 0) {
+                double Tr = d.T_ref_local ? resT[r] : d.T_ref;
+                double e = d.hbar * p.omega * (p.occ - nk_occupation(d, Tr, p.omega));
+                double vn = p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz;
+#ifdef NK_ABLATE
+                if (!(d.dbg & 64))
+#endif
+                {
+                atomicAdd(&b.nleave[r], 1u);
+                atomicAdd(&b.resb[4 * r + 0], -e);
+                atomicAdd(&b.resb[4 * r + 1], e * p.vx / vn);
+                atomicAdd(&b.resb[4 * r + 2], e * p.vy / vn);
+                atomicAdd(&b.resb[4 * r + 3], e * p.vz / vn);
                 }
-                p.alive = false;
-                return;
             }
-            double tcol = p.nts * dt;
-            double cx = p.x + p.vx * tcol, cy = p.y + p.vy * tcol, cz = p.z + p.vz * tcol;
-            // consumed fraction of the step, Population.py:1482 / :1514: |x_col - x_prev| / |v dt| with x_prev = the
-            // start-of-step position for a first event (:1472-1474), else the current position.  Both points lie on
-            // the ray x + s v, so the quotient is |nts + 1| resp. |nts| exactly; evaluated in that closed form (it
-            // differs from the reference's sqrt/sqrt/divide by rounding only, and saves two square roots and a divide).
-            cts += (cts == 0.0) ? fabs(p.nts + 1.0) : fabs(p.nts);
-            if (fc.bc == 'P') {                                                      // II. periodic, :1463-1489
-                p.x = cx + fc.tx; p.y = cy + fc.ty; p.z = cz + fc.tz;   // t = centroid(partner) - centroid(this)
-            } else if (ROUGH) {                                                      // III. rough, :1491-1544
-                double r0, r1;
-                nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);
-                p.x = cx; p.y = cy; p.z = cz;
-                int mo; double no, oo;
-                nk_reflect(d, cen, Tsv, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, r0, r1, r1, mo, no, oo);
-                p.mode = mo; p.occ = no; p.omega = oo;
-                const NkMode *rec = d.modetab + mo;
-                p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
-            }
-            double tc; int fcn;
-            nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
-            p.nts = tc / dt;
-            p.facet = fcn;
-            if (++ev > 4096u) cts = 1.0;                     // the reference would spin
-        } else {                                             // IV. drift the remainder, :1673-1681
-            p.x += p.vx * dt * rem; p.y += p.vy * dt * rem; p.z += p.vz * dt * rem;
-            p.nts -= rem;
-            cts = 1.0;
+            p.alive = false;
+            return NK_EV_DEAD;
         }
+        double tcol = p.nts * dt;
+        double cx = p.x + p.vx * tcol, cy = p.y + p.vy * tcol, cz = p.z + p.vz * tcol;
+        // consumed fraction of the step, Population.py:1482 / :1514: |x_col - x_prev| / |v dt| with x_prev = the
+        // start-of-step position for a first event (:1472-1474), else the current position.  Both points lie on
+        // the ray x + s v, so the quotient is |nts + 1| resp. |nts| exactly; evaluated in that closed form (it
+        // differs from the reference's sqrt/sqrt/divide by rounding only, and saves two square roots and a divide).
+        cts += (cts == 0.0) ? fabs(p.nts + 1.0) : fabs(p.nts);
+        if (fc.bc == 'P') {                                                      // II. periodic, :1463-1489
+            p.x = cx + fc.tx; p.y = cy + fc.ty; p.z = cz + fc.tz;   // t = centroid(partner) - centroid(this)
+        } else if (ROUGH) {                                                      // III. rough, :1491-1544
+            double r0, r1;
+            nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);
+            p.x = cx; p.y = cy; p.z = cz;
+            int mo; double no, oo;
+            nk_reflect(d, cen, Tsv, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, r0, r1, r1, mo, no, oo);
+            p.mode = mo; p.occ = no; p.omega = oo;
+            const NkMode *rec = d.modetab + mo;
+            p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
+        }
+        double tc; int fcn;
+#ifdef NK_ABLATE
+        if (d.dbg & 32) { tc = 3.0 * dt; fcn = p.facet; } else
+#endif
+        nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
+        p.nts = tc / dt;
+        p.facet = fcn;
+        if (++ev > 4096u) cts = 1.0;                         // the reference would spin
     }
+    if (cts < 1.0) {
+        const double rem = 1.0 - cts;
+        if (rem > p.nts) return NK_EV_MORE;                  // the next wall is inside this step as well
+        p.x += p.vx * dt * rem; p.y += p.vy * dt * rem; p.z += p.vz * dt * rem;      // IV. drift the remainder, :1673-1681
+        p.nts -= rem;
+    }
+    return NK_EV_DONE;
 }
 
 // Population.calculate_energy's per-particle part (Population.py:704-717) + the heat-flux sum (:734-736).

@@ -557,7 +557,10 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
     }
     NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
     std::vector<int64_t> fp((size_t)d.nseg + 1, 0);
-    for (int sgm = 0; sgm < d.nseg; ++sgm) fp[sgm + 1] = fp[sgm] + (d.segcap - cnt[sgm]);
+    for (int sgm = 0; sgm < d.nseg; ++sgm) {              // same rule as nk_update_body
+        const int fs = d.segcap - cnt[sgm];
+        fp[sgm + 1] = fp[sgm] + ((d.segcap < NK_QUANT_SEGCAP || fs >= NK_MIN_FREE) ? fs : 0);
+    }
     NK_HIP(hipMemcpy(d.seg_free_prefix, fp.data(), fp.size() * 8, hipMemcpyHostToDevice));
     return NK_OK;
 }

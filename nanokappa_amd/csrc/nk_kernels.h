@@ -33,9 +33,9 @@
 
 // =================================================================================== LDS carve-up
 struct NkEvBuf {          // parked boundary-event particles of the workgroup
-    double *x, *y, *z, *occ, *nts;
+    double *x, *y, *z, *occ, *nts, *cts;     // cts: fraction of the step already consumed by earlier events
     unsigned long long *pid;
-    int *mode, *facet;
+    int *mode, *facet, *evc;                 // evc: events so far in this step (numbers the RNG draws)
 };
 struct NkLds {
     double *Tsv, *cen;
@@ -55,9 +55,9 @@ __host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int 
     int Pl = Fl ? NP : 0;
     int Fcl = geom == 1 ? Fc : 0;
     size_t nd = (size_t)S + 3 * S + NK_NREP * S + NK_NREP * 3 * S + 4 * R + (size_t)Fl * NK_FACE_DOUBLES +
-                (size_t)Pl * NK_PLANE_DOUBLES + (evbuf ? 6 * NK_EVCAP : 0) + (size_t)R + 10 * (size_t)nrf + 2;
+                (size_t)Pl * NK_PLANE_DOUBLES + (evbuf ? 7 * NK_EVCAP : 0) + (size_t)R + 10 * (size_t)nrf + 2;
     size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) +
-                   (size_t)(NK_NREP * S + R + 1 + (R + 1) + (evbuf ? 2 * NK_EVCAP : 0)) * 4 + 16;
+                   (size_t)(NK_NREP * S + R + 1 + (R + 1) + (evbuf ? 3 * NK_EVCAP : 0)) * 4 + 16;
     return (bytes + 15) & ~(size_t)15;
 }
 
@@ -84,6 +84,7 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
         L.ev.x = p; p += NK_EVCAP; L.ev.y = p; p += NK_EVCAP; L.ev.z = p; p += NK_EVCAP;
         L.ev.occ = p; p += NK_EVCAP; L.ev.nts = p; p += NK_EVCAP;
         L.ev.pid = (unsigned long long *)p; p += NK_EVCAP;
+        L.ev.cts = p; p += NK_EVCAP;
     }
     double *resT = p; p += R;
     double *rf_cdf = p; p += nrf;
@@ -95,7 +96,7 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     L.bins.nleave = u; u += R;
     L.bins.misc = u; u += 1;
     int *rf_off = (int *)u; u += R + 1;
-    if (EVBUF) { L.ev.mode = (int *)u; u += NK_EVCAP; L.ev.facet = (int *)u; u += NK_EVCAP; }
+    if (EVBUF) { L.ev.mode = (int *)u; u += NK_EVCAP; L.ev.facet = (int *)u; u += NK_EVCAP; L.ev.evc = (int *)u; u += NK_EVCAP; }
     const int t = threadIdx.x;
     for (int i = t; i < S; i += NK_WG) L.Tsv[i] = d.T_sv[i];
     for (int i = t; i < 3 * S; i += NK_WG) L.cen[i] = d.centers[i];
@@ -267,12 +268,15 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
 // commit site: final particles are tallied and stored compacted at the write cursor, particles that meet a boundary
 // inside the step are parked in LDS, and whenever 64 are parked the whole wave processes them.
 #define NK_TILE 64
+#define NK_MIN_FREE 128         // segments with fewer free slots take no entering particles this step ...
+#define NK_QUANT_SEGCAP 512     // ... when segments are at least this large (tiny test populations deal exactly)
 #ifndef NK_SWEEP_OCC
 #define NK_SWEEP_OCC 3          // workgroups per CU the sweep is compiled for (3 x 4 waves = 3 waves per SIMD)
 #endif
 // Developer ablation build (make ablate -> libnanokappa_hip_ablate.so, env NK_DEBUG = mask): skip one part of the sweep
 // to see what bounds it.  1 no particle stores, 2 no tally, 4 no relaxation, 8 no boundary events, 16 no entering
-// particles.  The production library compiles NK_ABL(b) to false.
+// particles, 32 no ray casting after an event, 64 no reservoir tally, 128 no tally of event particles.
+// The production library compiles NK_ABL(b) to false.
 #ifdef NK_ABLATE
 #define NK_ABL(b) ((d.dbg & (b)) != 0)
 #else
@@ -305,8 +309,15 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
         const int count = d.seg_count[seg];
         // entering particles are dealt in proportion to the segment's free space (snapshot of the previous step):
         // self-balancing, and the share always fits
-        const int64_t g0 = total_free > 0 ? total * d.seg_free_prefix[seg] / total_free : 0;
-        const int64_t g1 = total_free > 0 ? total * d.seg_free_prefix[seg + 1] / total_free : 0;
+        int64_t g0 = total_free > 0 ? total * d.seg_free_prefix[seg] / total_free : 0;
+        int64_t g1 = total_free > 0 ? total * d.seg_free_prefix[seg + 1] / total_free : 0;
+        // whole tiles: share boundaries rounded down to multiples of 64 (a 9-lane tile costs as much as a full one).
+        // The prefix only counts segments with >= NK_MIN_FREE free slots, so a share grown by up to 63 still fits
+        // whenever the entering particles fill at most half of that space.
+        if (d.segcap >= NK_QUANT_SEGCAP && total * 2 <= total_free) {
+            g0 &= ~(int64_t)63;
+            g1 = (seg + 1 == d.nseg) ? total : (g1 & ~(int64_t)63);
+        }
         const int nA = (count + NK_TILE - 1) / NK_TILE, nB = (int)((g1 - g0 + NK_TILE - 1) / NK_TILE);
         int w = 0, ev_n = 0;
         // next tile of phase A is requested before the current tile's arithmetic (the loop is latency-bound otherwise)
@@ -381,6 +392,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 const int e = eb + ev_n + __popcll(mE & lower);
                 L.ev.x[e] = x; L.ev.y[e] = y; L.ev.z[e] = z; L.ev.occ[e] = occ; L.ev.nts[e] = nts;
                 L.ev.mode[e] = mode; L.ev.facet[e] = facet; L.ev.pid[e] = pid;
+                L.ev.cts[e] = 0.0; L.ev.evc[e] = 0;
             }
             ev_n += __popcll(mE);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS is in-order per wave; keep the compiler honest
@@ -399,7 +411,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 else *d.overflow = 1;
             }
             w += __popcll(mD);
-            // ---- drain (Population.py:1546-1683), tally, append the survivors
+            // ---- drain (Population.py:1546-1683): one boundary event per particle and pass; finished particles are
+            // tallied and appended, absorbed ones vanish, the few that meet another wall go back to the buffer
             bool first = true;
             while (ev_n > keep) {
                 const int n = ev_n >= NK_TILE ? NK_TILE : ev_n;
@@ -407,19 +420,23 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 const bool eact = lane < n;
                 NkParticle p;
                 unsigned long long ppid = 0;
+                double cts = 0.0;
+                uint32_t evc = 0;
+                int st = NK_EV_DEAD;
                 p.alive = false;
                 if (eact) {
                     p.x = L.ev.x[e]; p.y = L.ev.y[e]; p.z = L.ev.z[e]; p.occ = L.ev.occ[e]; p.nts = L.ev.nts[e];
                     p.mode = L.ev.mode[e]; p.facet = L.ev.facet[e]; ppid = L.ev.pid[e];
+                    cts = L.ev.cts[e]; evc = (uint32_t)L.ev.evc[e];
                     const double4 ra = first ? pre : *reinterpret_cast<const double4 *>(d.modetab + p.mode);
                     p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                     p.alive = true;
-                    nk_events<ROUGH>(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, ppid, step);
+                    st = nk_event_one<ROUGH>(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, cts, evc, ppid, step);
                 }
                 first = false;
-                const bool alive = eact && p.alive;
-                if (alive && !NK_ABL(2)) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
-                const unsigned long long mA = __ballot(alive);
+                const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
+                if (alive && !NK_ABL(2) && !NK_ABL(128)) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
+                const unsigned long long mA = __ballot(alive), mM = __ballot(more);
                 if (alive) {
                     const int o = w + __popcll(mA & lower);
                     if (o < d.segcap) { if (!NK_ABL(1)) nk_store(d, base + o, p.x, p.y, p.z, p.occ, p.nts, p.mode, p.facet, ppid); }
@@ -427,6 +444,14 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 }
                 w += __popcll(mA);
                 ev_n -= n;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // all lanes have read their entries
+                if (more) {
+                    const int q = eb + ev_n + __popcll(mM & lower);
+                    L.ev.x[q] = p.x; L.ev.y[q] = p.y; L.ev.z[q] = p.z; L.ev.occ[q] = p.occ; L.ev.nts[q] = p.nts;
+                    L.ev.mode[q] = p.mode; L.ev.facet[q] = p.facet; L.ev.pid[q] = ppid;
+                    L.ev.cts[q] = cts; L.ev.evc[q] = (int)evc;
+                }
+                ev_n += __popcll(mM);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
         }
@@ -460,7 +485,8 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {                           // all loads in flight at once
         const int sgm = tid * per + k;
-        fr[k] = (k < per && sgm < d.nseg) ? d.segcap - d.seg_count[sgm] : 0;
+        const int fs = (k < per && sgm < d.nseg) ? d.segcap - d.seg_count[sgm] : 0;
+        fr[k] = (d.segcap < NK_QUANT_SEGCAP || fs >= NK_MIN_FREE) ? fs : 0;
     }
     const double Ta = d.Tarr[0], Tb = d.Tarr[1], Tz = d.Tarr[n - 1], Ea = d.Earr[0], Ez = d.Earr[n - 1];
     for (int t = tid; t < S; t += nth) {
