@@ -1,11 +1,11 @@
-# Memory-latency counters of k_sweep (developer probe): separate --pmc passes, kernel-trace only
+# Memory-latency counters of k_sweep (developer probe): separate --pmc passes, kernel-trace only.
+# (A TCC_EA0_*_LEVEL pass was tried once and never returned; it is not run here.)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 B="python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline"
 rocprofv3 --kernel-trace --pmc SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES SQ_BUSY_CYCLES -d $R/gpurun_out/lat1 -o p --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_WAIT_INST_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_ANY -d $R/gpurun_out/lat2 -o p --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc TCP_TCC_READ_REQ_LATENCY_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum -d $R/gpurun_out/lat3 -o p --output-format csv -- $B > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_sum -d $R/gpurun_out/lat4 -o p --output-format csv -- $B > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM -d $R/gpurun_out/lat5 -o p --output-format csv -- $B > /dev/null 2>&1
 cd $R && python3 - <<'PY'
 import csv, glob, collections

@@ -2,7 +2,7 @@
 import csv, glob, collections, json, sys
 
 def load(d):
-    f = glob.glob('%s/*/*counter_collection.csv' % d)[0]
+    f = glob.glob('%s/**/*counter_collection.csv' % d, recursive=True)[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
         name = r['Kernel_Name'].split('(')[0].replace('void ', '').split('<')[0]

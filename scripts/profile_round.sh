@@ -1,0 +1,22 @@
+# Round profile of the bench workload: kernel-trace stats + calibrated HBM traffic of k_sweep (separate --pmc passes).
+#   gpurun -- 'bash scripts/profile_round.sh v4'   ->  gpurun_out/prof_<tag>/...  (copy the summaries into profiles/)
+TAG=${1:-vX}
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/prof_$TAG
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+B="python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --calibrate"
+rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/kt.log
+echo "kernel trace done"
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/sq -o p --output-format csv -- $B > /dev/null 2> $O/sq.log
+echo "sq pass done"
+rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fe -o p --output-format csv -- $B > /dev/null 2> $O/fe.log
+echo "fetch pass done"
+rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/wr -o p --output-format csv -- $B > /dev/null 2> $O/wr.log
+echo "write pass done"
+cd $R
+CAL=$(grep -h "calibration:" $O/fe.log | tail -1 | sed 's/.*reads \([0-9]*\) B and writes \([0-9]*\) B.*/\1 \2/')
+python3 scripts/pmc_summary.py $O/sq $O/fe $O/wr $CAL > $O/pmc.json && python3 -c "
+import json; j=json.load(open('$O/pmc.json')); k=j['k_sweep']; print('k_sweep read %.3f GB write %.3f GB' % (k['read_bytes']/1e9, k['write_bytes']/1e9)); print(j['calibration'])"
+cp $O/kt/kt_kernel_stats.csv $O/kernel_stats.csv
+python3 bench.py --steps 50 --warmup 10 > $O/bench.json 2> $O/bench.err; tail -c 1200 $O/bench.json
