@@ -94,7 +94,10 @@ typedef struct {
     const double *T;           /* [R] imposed temperature */
     const double *enter_prob;  /* [R*Q*J] */
     const double *counter;     /* [R*Q*J] initial res_counter (Population.py:343) */
-    int32_t gen;               /* 0 'constant', 1 'fixed_rate' (Population.py:358-455) */
+    int32_t gen;               /* 0 'constant', 1 'fixed_rate', 2 'one_to_one' (Population.py:358-489) */
+    const int64_t *n_leaving;  /* [R] 'one_to_one' only: particles to emit at the first step (Population.py:344:
+                                * round(sum of enter_prob)), all ranks together; afterwards the engine emits what
+                                * left through each reservoir at the previous step (:466, :1585).  NULL otherwise */
 } nk_reservoirs;
 
 /* Rough facets, reference Population.py:852-877 (specularity), :1042-1461 (specular map),

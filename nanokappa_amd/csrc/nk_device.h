@@ -88,6 +88,8 @@ struct NkDev {
     int32_t res_lds;                  // 1: the three tables above are staged in LDS by the sweep
     const double *enter_prob;         // [R*M]
     double *res_counter;              // [R*M]
+    const double *res_roulette;       // [R*M] 'one_to_one': cumulative enter_prob per reservoir, last = 1 (Population.py:467-468)
+    int32_t *nleave_prev;             // [R] 'one_to_one': particles that left at the previous step, all ranks (Population.py:466)
     double *res_cval[2];              // [R*M] counter / dice value used by the level-1 entry time (buffer = step & 1)
     uint64_t *spawn_list[2];          // [spawn_cap] (rm << 12 | level) of every particle entering at step k: buffer k & 1.
     int64_t spawn_cap;                //   The sweep of step k consumes buffer k & 1 and, in its tail, fills buffer

@@ -384,6 +384,29 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
             pmax = std::max(pmax, r->enter_prob[i]);
             most += (int64_t)floor(r->enter_prob[i]) + 1;
         }
+        NK_ARG(r->gen >= 0 && r->gen <= 2, "nk_set_reservoirs: gen must be 0 (constant), 1 (fixed_rate) or 2 (one_to_one)");
+        if (r->gen == 2) {
+            // one_to_one: cumulative enter_prob per reservoir (np.cumsum, then / max: Population.py:467-468) and the
+            // first step's emission; the list must hold whatever leaves in one step
+            NK_ARG(r->n_leaving, "nk_set_reservoirs: one_to_one needs n_leaving");
+            std::vector<double> roul((size_t)r->R * d.M);
+            std::vector<int32_t> nl((size_t)r->R);
+            int64_t first = 0;
+            for (int i = 0; i < r->R; ++i) {
+                double run = 0.0, mx = 0.0;
+                for (int m = 0; m < d.M; ++m) { run += r->enter_prob[(size_t)i * d.M + m]; roul[(size_t)i * d.M + m] = run; mx = std::max(mx, run); }
+                NK_ARG(mx > 0.0, "nk_set_reservoirs: one_to_one reservoir with zero entry probability");
+                for (int m = 0; m < d.M; ++m) roul[(size_t)i * d.M + m] /= mx;
+                NK_ARG(r->n_leaving[i] >= 0 && r->n_leaving[i] < (1ll << 24), "nk_set_reservoirs: n_leaving out of range");
+                nl[(size_t)i] = (int32_t)r->n_leaving[i];
+                first += r->n_leaving[i];
+            }
+            NK_UP(roul.data(), roul.size(), &d.res_roulette);
+            const int32_t *pn;
+            NK_UP(nl.data(), nl.size(), &pn);
+            d.nleave_prev = (int32_t *)pn;
+            most = std::max<int64_t>(4 * std::max(first, most) + 65536, most);
+        }
         d.spawn_cap = most;
         const uint64_t *pu;
         NK_UP((const uint64_t *)nullptr, (size_t)most, &pu);
@@ -696,13 +719,16 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         const int do_flux = (fe > 0 && ((ctx->step + 1) % fe) == 0) ? 1 : 0;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
         const int buf = (int)(step & 1u);
-        if (R > 0 && !ctx->spawn_ready) {                // prime: nobody has prepared this step's entering particles
+        if (R > 0 && d.res_gen == 2) {                   // one_to_one: needs the reduced N_leaving of the previous step
+            NK_HIP(hipMemsetAsync(d.alloc_count, 0, 8, ctx->stream));
+            k_emit_one_to_one<<<ctx->num_cu * 4, NK_WG, 0, ctx->stream>>>(d, step);
+        } else if (R > 0 && !ctx->spawn_ready) {         // prime: nobody has prepared this step's entering particles
             NK_HIP(hipMemsetAsync(d.alloc_count, 0, 8, ctx->stream));
             k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
         }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
         // the sweep's tail prepares step + 1 when each workgroup's slice of the (reservoir, mode) table is small
-        const bool emit_next = R > 0 && ((int64_t)R * d.M + g_sweep - 1) / g_sweep <= (int64_t)NK_EMIT_KMAX * NK_WG;
+        const bool emit_next = R > 0 && d.res_gen != 2 && ((int64_t)R * d.M + g_sweep - 1) / g_sweep <= (int64_t)NK_EMIT_KMAX * NK_WG;
         {
             const int rl = ctx->pending_relax ? 1 : 0;
             const int gm = nk_geom_mode(ctx);

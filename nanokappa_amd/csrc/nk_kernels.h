@@ -250,6 +250,55 @@ __device__ __forceinline__ void nk_emit_block(const NkDev &d, uint32_t step, int
 }
 #define NK_EMIT_KMAX 4          // entries per thread the sweep's tail may take (else k_emit_count runs every step)
 
+// fill_reservoirs 'one_to_one' (Population.py:457-489): one particle in for every particle that left through the
+// reservoir at the previous step (all ranks; nleave_prev is written by the update after the all-reduce).  One thread
+// per candidate: owner test, mode from the cumulative enter_prob (np.searchsorted :472), record
+// (i << 40 | rm << 12 | 0) -- level 0 marks "entry time uniform in the step" for the sweep's phase B.
+__global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t step) {
+    __shared__ int wsum[NK_WG / 64];
+    __shared__ int bbase;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int buf = (int)(step & 1u);
+    int64_t total = 0;
+    for (int r = 0; r < d.R; ++r) total += d.nleave_prev[r];
+    uint64_t *list = d.spawn_list[buf];
+    for (int64_t c0 = (int64_t)blockIdx.x * NK_WG; c0 < total; c0 += (int64_t)gridDim.x * NK_WG) {
+        const int64_t c = c0 + tid;
+        uint64_t rec = 0;
+        int mine = 0;
+        if (c < total) {
+            int r = 0;
+            int64_t i = c;
+            while (r < d.R - 1 && i >= d.nleave_prev[r]) { i -= d.nleave_prev[r]; ++r; }
+            if (((uint32_t)((uint64_t)i + step) % (uint32_t)d.nranks) == (uint32_t)d.rank) {
+                const uint64_t pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | (uint64_t)i;
+                double um, u1;
+                nk_uniform2_dev(d.seed, pid, step, NK_TAG_DICE, um, u1);
+                int m = nk_ss_left(d.res_roulette + (int64_t)r * d.M, d.M, um);
+                m = m > d.M - 1 ? d.M - 1 : m;
+                if (i < (1ll << 24)) { rec = ((uint64_t)i << 40) | ((uint64_t)((int64_t)r * d.M + m) << 12); mine = 1; }
+                else *d.overflow = 1;
+            }
+        }
+        int incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        if (tid == 0) {
+            int t = 0;
+            for (int w = 0; w < NK_WG / 64; ++w) t += wsum[w];
+            bbase = t > 0 ? atomicAdd(d.alloc_count + buf, t) : 0;
+        }
+        __syncthreads();
+        int base = bbase;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        const int64_t g = (int64_t)base + incl - mine;
+        if (mine) { if (g < d.spawn_cap) list[g] = rec; else *d.overflow = 1; }
+        __syncthreads();
+    }
+}
+
 // Stand-alone emission pass: primes the first step after (re)configuration, and serves every step when the
 // (reservoir, mode) table is too large for the sweep's tail.
 __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
@@ -359,19 +408,21 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 act = g < g1;
                 if (act) {
                     const uint64_t recd = d.spawn_list[buf][g];
-                    const int64_t rm = (int64_t)(recd >> 12);
-                    const int level = (int)(recd & 0xFFFu);
+                    const int64_t rm = (int64_t)((recd >> 12) & 0xFFFFFFFull);
+                    const int level = (int)(recd & 0xFFFu);      // 0: 'one_to_one' record (index in bits 40..63)
                     const int r = (int)(rm / d.M);
                     mode = (int)(rm - (int64_t)r * d.M);
                     // everything that hangs off the record is requested at once; the Philox rounds cover the latency
                     const double prob = d.enter_prob[rm];
                     const double cval = d.res_cval[buf][rm];
                     const double4 ra = *reinterpret_cast<const double4 *>(d.modetab + mode);
-                    pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level;
+                    pid = level > 0 ? ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level
+                                    : ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | (recd >> 40);
                     double uf, us, ur, ut;
                     nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
                     nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
-                    const double dt_in = (level == 1) ? d.dt * (1.0 - (cval / prob))
+                    const double dt_in = (level == 0) ? d.dt * ut                               // one_to_one :482
+                                       : (level == 1) ? d.dt * (1.0 - (cval / prob))
                                                       : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
                     double x0, y0, z0;
                     if (GEOM == 1 && d.res_lds) nk_sample_res_face(L.rf_off, L.rf_cdf, L.rf_verts, r, uf, us, ur, x0, y0, z0);
@@ -548,6 +599,7 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
         if (k < per && sgm < d.nseg) d.seg_free_prefix[sgm] = pre;
         pre += fr[k];
     }
+    if (d.res_gen == 2) for (int r = tid; r < d.R; r += nth) d.nleave_prev[r] = (int32_t)acc[5 * S + r];
     if (tid == 0) {
         d.seg_free_prefix[d.nseg] = run;
         d.alloc_count[buf] = 0;                      // consumed by this step's sweep; refilled two steps on

@@ -46,7 +46,7 @@ class nk_subvols(C.Structure):
 
 class nk_reservoirs(C.Structure):
     _fields_ = [('R', C.c_int32), ('facet', c_ip), ('T', c_dp), ('enter_prob', c_dp), ('counter', c_dp),
-                ('gen', C.c_int32)]
+                ('gen', C.c_int32), ('n_leaving', C.POINTER(C.c_int64))]
 
 
 class nk_rough(C.Structure):
@@ -245,12 +245,15 @@ class Engine(object):
         self._ck(self.L.nk_set_subvolumes(self.h, C.byref(s), _p(t)), 'nk_set_subvolumes')
         self.S = int(s.S)
 
-    def set_reservoirs(self, facets, T, enter_prob, counter, gen=0):
+    def set_reservoirs(self, facets, T, enter_prob, counter, gen=0, n_leaving=None):
+        """gen: 0 'constant', 1 'fixed_rate', 2 'one_to_one' (needs n_leaving[R], the first step's emission)."""
         r = nk_reservoirs()
         f, t, ep, cn = _i(facets), _d(T), _d(enter_prob), _d(counter)
         r.R = f.shape[0]
         r.facet, r.T, r.enter_prob, r.counter = _p(f, c_ip), _p(t), _p(ep), _p(cn)
         r.gen = int(gen)
+        nl = None if n_leaving is None else np.ascontiguousarray(n_leaving, dtype=np.int64)
+        r.n_leaving = None if nl is None else nl.ctypes.data_as(C.POINTER(C.c_int64))
         self._ck(self.L.nk_set_reservoirs(self.h, C.byref(r)), 'nk_set_reservoirs')
         self.R = int(r.R)
 

@@ -91,8 +91,8 @@ class Population(Constants):
         self.subvol_volume = geometry.subvol_volume
         self.bound_cond = geometry.bound_cond
         self.res_gen = args.reservoir_gen[0]
-        if self.res_gen not in ('constant', 'fixed_rate'):
-            raise NotImplementedError("--reservoir_gen %s: 'constant' and 'fixed_rate' are built" % self.res_gen)
+        if self.res_gen not in ('constant', 'fixed_rate', 'one_to_one'):
+            raise Exception('Invalid --reservoir_gen')
         self.rough_facets = np.asarray(geometry.rough_facets)
         self.rough_facets_values = np.asarray(geometry.rough_facets_values)
         self.connected_facets = geometry.connected_facets
@@ -317,7 +317,9 @@ class Population(Constants):
         Q, J = phonon.omega.shape
         if self.n_of_reservoirs > 0:
             eng.set_reservoirs(self.res_facet, self.res_facet_temperature, self.enter_prob.reshape(-1, Q * J),
-                               self.res_counter.reshape(-1, Q * J), gen={'constant': 0, 'fixed_rate': 1}[self.res_gen])
+                               self.res_counter.reshape(-1, Q * J),
+                               gen={'constant': 0, 'fixed_rate': 1, 'one_to_one': 2}[self.res_gen],
+                               n_leaving=(self.N_leaving if self.res_gen == 'one_to_one' else None))
         if self.rough_facets.shape[0] > 0:
             eng.set_rough(self.rough_facets, self.specularity.reshape(-1, Q * J), self.true_specular.reshape(-1, Q * J),
                           self.spec_map.reshape(-1, Q * J), self.creation_roulette)

@@ -282,6 +282,55 @@ int64_t nko_emit(const nko_material *mat, const nko_mesh *mesh, nko_reservoirs *
         for (int32_t a = 0; a < nf; ++a) tot += mesh->face_area[mesh->facet_face_idx[f0 + a]];
         for (int32_t a = 0; a < nf; ++a) { acc += mesh->face_area[mesh->facet_face_idx[f0 + a]] / tot; cd[a] = acc; }
         for (int32_t a = 0; a < nf; ++a) cd[a] /= cd[nf - 1];
+        if (res->gen == 2) {                                       /* one_to_one :457-489 */
+            /* one particle in for every particle that left through this facet at the previous step: mode drawn
+             * from the cumulative enter_prob (:467-472), entry time uniform in the step (:482) */
+            double *roul = (double *)malloc(sizeof(double) * (size_t)M);
+            double run = 0.0, mx = 0.0;
+            for (int64_t m = 0; m < M; ++m) { run += res->enter_prob[(int64_t)r * M + m]; roul[m] = run; if (run > mx) mx = run; }
+            for (int64_t m = 0; m < M; ++m) roul[m] /= mx;
+            int64_t n = res->n_leaving ? res->n_leaving[r] : 0;
+            for (int64_t i = 0; i < n; ++i) {
+                if (((i + step) % nranks) != rank) continue;
+                uint64_t pid = ((uint64_t)((step + 1) & 0xFFFFFF) << 40) | ((uint64_t)r << 32) | (uint64_t)i;
+                double um, u_unused, uf, us, ur, ut;
+                nko_uniform2(p->seed, pid, (uint32_t)step, TAG_DICE, &um, &u_unused);
+                nko_uniform2(p->seed, pid, (uint32_t)step, TAG_EMIT, &uf, &us);
+                nko_uniform2(p->seed, pid, (uint32_t)step, TAG_EMIT + 1, &ur, &ut);
+                int64_t m = ss_left(roul, (int32_t)M, um);                                /* np.searchsorted :472 */
+                if (m > M - 1) m = M - 1;
+                double dt_in = p->dt * ut;                                               /* :482 */
+                int32_t a = ss_right(cd, nf, uf);
+                if (a > nf - 1) a = nf - 1;
+                const double *vx = mesh->vertices + 9 * (int64_t)mesh->facet_face_idx[f0 + a];
+                double sq = sqrt(us);
+                double a0 = 1.0 - sq, a1 = (1.0 - ur) * sq, a2 = ur * sq;
+                double x[3];
+                for (int d = 0; d < 3; ++d) x[d] = (a0 * vx[d] + a1 * vx[3 + d]) + a2 * vx[6 + d];
+                if (P->N >= P->cap) { free(roul); if (cd != cdf) free(cd); return -1; }
+                int64_t k = P->N++;
+                const double *v = mat->group_vel + 3 * m;
+                double xc[3], tc; int32_t fc;
+                find_boundary_one(mesh, x, v, xc, &tc, &fc);
+                P->n_ts[k] = tc / p->dt - dt_in / p->dt;
+                for (int d = 0; d < 3; ++d) P->pos[3 * k + d] = x[d] + v[d] * dt_in;
+                if (res->dbg_dt_in) res->dbg_dt_in[k] = dt_in;
+                if (res->dbg_x0) { res->dbg_x0[3 * k] = x[0]; res->dbg_x0[3 * k + 1] = x[1]; res->dbg_x0[3 * k + 2] = x[2]; }
+                if (res->dbg_level) res->dbg_level[k] = 0;
+                if (res->dbg_res) res->dbg_res[k] = r;
+                P->facet[k] = fc;
+                P->mode[k] = (int32_t)m;
+                P->occ[k] = occupation(mat, res->T[r], mat->omega[m]);
+                P->pid[k] = pid;
+                P->energy[k] = 0.0;
+                P->temp[k] = res->T[r];
+                P->sv[k] = -1;
+                ++emitted;
+            }
+            free(roul);
+            if (cd != cdf) free(cd);
+            continue;
+        }
         for (int64_t m = 0; m < M; ++m) {
             int64_t rm = (int64_t)r * M + m;
             double prob = res->enter_prob[rm];

@@ -74,12 +74,14 @@ typedef struct {
     const double *T;         /* [R] */
     const double *enter_prob;/* [R*Q*J] Population.py:146-161 */
     double *counter;         /* [R*Q*J] state, Population.py:343, :361-365 */
-    int32_t gen;             /* 0 constant, 1 fixed_rate */
+    int32_t gen;             /* 0 constant, 1 fixed_rate, 2 one_to_one (Population.py:457-489) */
     /* optional test taps (NULL = off), indexed by the slot the new particle is appended to */
     double *dbg_dt_in;       /* [cap]   entry-time offset, Population.py:391-394 */
     double *dbg_x0;          /* [cap*3] sampled position on the facet, Mesh.py:949 */
     int32_t *dbg_level;      /* [cap]   which of the mode's particles (1 = deterministic time) */
     int32_t *dbg_res;        /* [cap]   reservoir index */
+    const int64_t *n_leaving;/* [R] one_to_one: particles to emit at this step = those that left through the facet at
+                              * the previous step, all ranks together (Population.py:344, :466, :1585) */
 } nko_reservoirs;
 
 typedef struct {

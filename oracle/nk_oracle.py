@@ -45,7 +45,8 @@ class Subvols(C.Structure):
 
 class Reservoirs(C.Structure):
     _fields_ = [('R', C.c_int32), ('facet', c_ip), ('T', c_dp), ('enter_prob', c_dp), ('counter', c_dp),
-                ('gen', C.c_int32), ('dbg_dt_in', c_dp), ('dbg_x0', c_dp), ('dbg_level', c_ip), ('dbg_res', c_ip)]
+                ('gen', C.c_int32), ('dbg_dt_in', c_dp), ('dbg_x0', c_dp), ('dbg_level', c_ip), ('dbg_res', c_ip),
+                ('n_leaving', c_lp)]
 
 
 class Rough(C.Structure):
@@ -177,14 +178,19 @@ def make_subvols(centers, volumes, kind, axis, interp):
     return s
 
 
-def make_reservoirs(facets, T, enter_prob, counter, gen=0):
+def make_reservoirs(facets, T, enter_prob, counter, gen=0, n_leaving=None):
+    """gen: 0 'constant', 1 'fixed_rate', 2 'one_to_one' (then n_leaving[R] = particles to emit at the first step,
+    Population.py:344; OracleSim keeps it up to date afterwards)."""
     r = Reservoirs()
     f = _i(facets); t = _d(T); ep = _d(enter_prob); cn = _d(counter)
     r.R = f.shape[0]
     r.facet, r.T, r.enter_prob, r.counter = _p(f, c_ip), _p(t, c_dp), _p(ep, c_dp), _p(cn, c_dp)
     r.gen = gen
-    _keep(r, f, t, ep, cn)
+    nl = np.ascontiguousarray(np.zeros(f.shape[0]) if n_leaving is None else n_leaving, dtype=np.int64)
+    r.n_leaving = _p(nl, c_lp)
+    _keep(r, f, t, ep, cn, nl)
     r.counter_array = cn
+    r.n_leaving_array = nl
     return r
 
 
@@ -309,10 +315,12 @@ class OracleSim(object):
                                   _p(self.res_flux, c_dp))
         L.nko_tally(self.ref(self.mat), self.ref(self.sv), self.ref(self.p), self.ref(self.P.s), _p(self.T_sv, c_dp),
                     _p(self.N_sv, c_lp), _p(self.E_raw, c_dp))
-        vec = np.concatenate((self.E_raw, self.N_sv.astype(np.float64)))
+        vec = np.concatenate((self.E_raw, self.N_sv.astype(np.float64), self.N_leaving[:self.R].astype(np.float64)))
         allreduce(vec)
         self.E_raw[:] = vec[:self.S]
-        self.N_sv[:] = np.rint(vec[self.S:]).astype(np.int64)
+        self.N_sv[:] = np.rint(vec[self.S:2 * self.S]).astype(np.int64)
+        if self.R > 0 and self.res.gen == 2:             # one_to_one: next step emits what left on ALL ranks
+            self.res.n_leaving_array[:] = np.rint(vec[2 * self.S:]).astype(np.int64)
         L.nko_update_T(self.ref(self.mat), self.ref(self.sv), self.ref(self.p), _p(self.N_sv, c_lp), _p(self.E_raw, c_dp),
                        _p(self.T_sv, c_dp), _p(self.E_sv, c_dp))
         L.nko_assign_T(self.ref(self.sv), _p(self.T_sv, c_dp), self.ref(self.P.s))
@@ -334,6 +342,8 @@ class OracleSim(object):
                                   self.ref(self.rough), self.ref(self.p), _p(self.T_sv, c_dp), C.c_int64(self.step),
                                   self.ref(self.P.s), _p(self.N_leaving, c_lp), _p(self.res_energy, c_dp),
                                   _p(self.res_flux, c_dp))
+        if self.R > 0 and self.res.gen == 2:             # one_to_one: next step emits what left now (Population.py:1749)
+            self.res.n_leaving_array[:] = self.N_leaving[:self.R]
         L.nko_refresh_temperatures(self.ref(self.mat), self.ref(self.sv), self.ref(self.p), self.ref(self.P.s),
                                    _p(self.T_sv, c_dp), _p(self.E_sv, c_dp), _p(self.N_sv, c_lp), _p(self.E_raw, c_dp))
         L.nko_lifetime_scattering(self.ref(self.mat), self.ref(self.p), self.ref(self.P.s))

@@ -428,8 +428,13 @@ def run_stats(case, seed, particles=100000, steps=1000, extra=()):
     return np.array(rows), wall, nsum
 
 
+# statistical cases that are a base BC set + extra reference flags
+CASE_EXTRA = {'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one'])}
+
+
 def gen_stats_one(case, seed):
-    rows, wall, nsum = run_stats(case, seed)
+    base, extra = CASE_EXTRA.get(case, (case, []))
+    rows, wall, nsum = run_stats(base, seed, extra=extra)
     np.savez_compressed(os.path.join(HERE, '_stats_%s_%d.npz' % (case, seed)),
                         rows=rows, wall=np.array(wall), phonon_steps=np.array(nsum))
     print(case, seed, 'wall', wall, 'phonon-steps/s', nsum / wall)
@@ -437,8 +442,8 @@ def gen_stats_one(case, seed):
 
 def gen_stats_merge():
     import glob
-    for case in ('ttp', 'ttrrp'):
-        files = sorted(glob.glob(os.path.join(HERE, '_stats_%s_*.npz' % case)))
+    for case in ('ttp', 'ttrrp', 'ttp_o2o'):
+        files = sorted(glob.glob(os.path.join(HERE, '_stats_%s_[0-9]*.npz' % case)))
         if not files:
             continue
         rows = np.array([np.load(f)['rows'] for f in files])        # (seeds, 100, cols)

@@ -164,6 +164,36 @@ def test_multistep_vs_oracle(case):
     assert rel_err(t['res_energy'].sum(axis=0), sim.res_energy[:2]) < 1e-8
 
 
+@pytest.mark.parametrize('gen', [1, 2])
+def test_multistep_other_generators(gen):
+    """fill_reservoirs 'fixed_rate' (Population.py:408-455) and 'one_to_one' (:457-489): same decisions as the oracle.
+    one_to_one emits what left through each reservoir at the previous step, so the counts chain from step to step."""
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 30000, seed=6)
+    nsteps = 20
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=43, gen=gen)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=43, gen=gen)
+    t = eng.step(nsteps)
+    emitted_prev = None
+    for s in range(nsteps):
+        n_before = sim.P.N
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.array_equal(t['N_leaving'][s], sim.N_leaving[:2]), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+        if gen == 2 and s > 0:
+            assert t['N_emitted'][s] == t['N_leaving'][s - 1].sum()
+    p = eng.download()
+    n = sim.P.N
+    assert p['pid'].shape[0] == n
+    o1 = np.argsort(p['pid'])
+    o2 = np.argsort(sim.P.pid[:n])
+    assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
+    assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
+    assert np.allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=1e-8)
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+
+
 COMMON_ARGS = ['--poscar_file', 'POSCAR', '--hdf_file', 'synthetic', '--temp_interp', 'linear', '--timestep', '1',
                '--energy_normal', 'mean', '--particles', 'total', '30000']
 EXTRA_CASES = {

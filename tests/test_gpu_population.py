@@ -38,7 +38,11 @@ def window_stats(rows, lo=50):
     return T, phi, kap, Np
 
 
-@pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
+STAT_CASES = {'ttp': ('ttp', []), 'ttrrp': ('ttrrp', []),
+              'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one'])}      # same table as make_golden.CASE_EXTRA
+
+
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp', 'ttp_o2o'])
 def test_statistical_parity_with_reference(case, tmp_path):
     """Same configuration as the reference goldens (C1a / C1b of SURVEY 8d, 729 x 6 synthetic Si): per-subvolume
     temperature, heat flux, kappa and particle count, averaged over steps 500-1000, must lie within the
@@ -48,7 +52,8 @@ def test_statistical_parity_with_reference(case, tmp_path):
     seeds = [101, 102, 103, 104]
     rows = []
     for s in seeds:
-        pop, geo, ph = build_population(case, 100000, s, tmp_path / ('run%d' % s) if False else None)
+        base, extra = STAT_CASES[case]
+        pop, geo, ph = build_population(base, 100000, s, None, extra=extra)
         rec = []
         for _ in range(100):
             pop.run(10, geo, ph)

@@ -258,3 +258,38 @@ def test_emission(scale):
     assert np.allclose(xr + vr * g['res_dt_in'][:, None], g['new_positions'], rtol=1e-13, atol=1e-11)
     occ = ph.calculate_occupation(np.array([302.0, 298.0])[res.tap_res[:n]], ph.omega.ravel()[store.mode[:n]])
     assert rel_err(store.occ[:n], occ) < 1e-13
+
+
+def test_one_to_one_generator_counts_and_modes():
+    """fill_reservoirs 'one_to_one' (Population.py:457-489) in the oracle: the first step emits round(sum enter_prob)
+    per reservoir (:344), every later step what left through the facet at the previous one (:466); the drawn modes
+    follow the cumulative enter_prob (:467-472): only modes that can enter, frequencies ~ probabilities."""
+    from util import case_tables, random_population, make_oracle_sim, first_n_leaving
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 20000, seed=3)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=9, gen=2)
+    first = first_n_leaving(ct['enter_prob'])
+    left_prev = first.copy()
+    M = ct['enter_prob'].reshape(2, -1).shape[1]
+    seen = np.zeros((2, M))
+    for s in range(12):
+        n0 = sim.P.N
+        sim.run_timestep()
+        new = sim.P.pid[:sim.P.N] >> 40 == ((s + 1) & 0xFFFFFF)
+        # emitted particles of this step that are still alive + those absorbed again cannot exceed what was due
+        assert new.sum() <= left_prev.sum()
+        pid = sim.P.pid[:sim.P.N][new]
+        r = (pid >> 32) & 0xFF
+        np.add.at(seen, (r.astype(int), sim.P.mode[:sim.P.N][new]), 1)
+        left_prev = sim.N_leaving[:2].copy()
+        assert np.array_equal(sim.res.n_leaving_array, left_prev)
+    ep = ct['enter_prob'].reshape(2, -1)
+    assert seen[ep == 0].sum() == 0                       # a mode that cannot enter is never drawn
+    # chi-square-ish: group modes into 20 probability-ordered bins per reservoir
+    for r in range(2):
+        order = np.argsort(ep[r])
+        bins = np.array_split(order, 20)
+        obs = np.array([seen[r, b].sum() for b in bins])
+        exp = np.array([ep[r, b].sum() for b in bins]) / ep[r].sum() * obs.sum()
+        ok = exp > 20
+        assert np.all(np.abs(obs[ok] - exp[ok]) < 6 * np.sqrt(exp[ok]) + 0.12 * exp[ok])

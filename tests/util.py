@@ -90,14 +90,16 @@ def random_population(ct, n, seed, T0=298.0):
     return pos, mode, occ, counter
 
 
-def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=298.0, emit_scale=1.0):
+def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=298.0, emit_scale=1.0, gen=0):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
     import nk_oracle as O
     mat = O.make_material(ct['tables'])
     mesh = O.make_mesh(ct['mesh'])
     sv = O.make_subvols(ct['centers'], ct['volumes'], 0, ct['axis'], interp)
-    res = O.make_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'] * emit_scale, counter.copy())
+    ep = ct['enter_prob'] * emit_scale
+    res = O.make_reservoirs(ct['res_facets'], ct['res_T'], ep, counter.copy(), gen=gen,
+                            n_leaving=(first_n_leaving(ep) if gen == 2 else None))
     if ct['rough'] is not None:
         r = ct['rough']
         rough = O.make_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'])
@@ -113,14 +115,22 @@ def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=29
     return sim
 
 
+def first_n_leaving(enter_prob):
+    """Population.py:344: the first step of 'one_to_one' emits round(sum of enter_prob) particles per reservoir."""
+    ep = np.asarray(enter_prob)
+    return np.sum(ep.reshape(ep.shape[0], -1), axis=1).round().astype(np.int64)
+
+
 def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scale=1.0, flux_every=10,
-                contains_every=100, device=0):
+                contains_every=100, device=0, gen=0):
     from nanokappa_amd.engine import Engine
     eng = Engine(device, seed)
     eng.set_material(ct['tables'])
     eng.set_mesh(ct['mesh'])
     eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], interp, np.full(ct['centers'].shape[0], T0))
-    eng.set_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'] * emit_scale, counter)
+    ep = ct['enter_prob'] * emit_scale
+    eng.set_reservoirs(ct['res_facets'], ct['res_T'], ep, counter, gen=gen,
+                       n_leaving=(first_n_leaving(ep) if gen == 2 else None))
     if ct['rough'] is not None:
         r = ct['rough']
         eng.set_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'])
