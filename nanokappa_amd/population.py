@@ -177,10 +177,14 @@ class Population(Constants):
             self.creation_roulette = np.zeros((0, Q * J))
             self.degeneracies, self.degen_index = ST.find_degeneracies(phonon)
             return
-        if self.scat_model not in ('v', 'vel', 'velocity', 'groupvel', 'group_vel'):
-            raise NotImplementedError("--bound_scat %s: only the 'velocity' reflection model is built so far" % self.scat_model)
         spec0 = ST.fbz_specularity(geometry, phonon, self.rough_facets, self.rough_facets_values)
-        self.correspondent_modes, self.true_specular = ST.specular_correspondences_velocity(geometry, phonon, self.rough_facets)
+        self.k_model = self.scat_model in ('k', 'wavevector', 'wave_vector')
+        if self.k_model:
+            self.correspondent_modes, self.true_specular = ST.specular_correspondences_k(geometry, phonon, self.rough_facets)
+        elif self.scat_model in ('v', 'vel', 'velocity', 'groupvel', 'group_vel'):
+            self.correspondent_modes, self.true_specular = ST.specular_correspondences_velocity(geometry, phonon, self.rough_facets)
+        else:
+            raise Exception('Invalid --bound_scat')
         self.specularity = self.true_specular.astype(int) * spec0                  # Population.py:1459
         self.spec_map = ST.specular_map(self.correspondent_modes, geometry, self.rough_facets, Q, J)
         self.degeneracies, self.degen_index = ST.find_degeneracies(phonon)
@@ -321,8 +325,16 @@ class Population(Constants):
                                gen={'constant': 0, 'fixed_rate': 1, 'one_to_one': 2}[self.res_gen],
                                n_leaving=(self.N_leaving if self.res_gen == 'one_to_one' else None))
         if self.rough_facets.shape[0] > 0:
+            degen_j2 = None
+            if getattr(self, 'k_model', False):
+                # 'k' model: a specular out-mode with a degenerate partner lands on the pair's second branch with
+                # probability 1/2 (Population.py:963-969)
+                degen_j2 = -np.ones((Q, J), dtype=np.int32)
+                di = self.degen_index.astype(int)
+                has = di > -1
+                degen_j2[has] = self.degeneracies[di[has], 2]
             eng.set_rough(self.rough_facets, self.specularity.reshape(-1, Q * J), self.true_specular.reshape(-1, Q * J),
-                          self.spec_map.reshape(-1, Q * J), self.creation_roulette)
+                          self.spec_map.reshape(-1, Q * J), self.creation_roulette, degen_j2=degen_j2)
         eng.set_params(dt=self.dt, norm_fixed=(self.norm == 'fixed'), particle_density=self.particle_density,
                        T_ref=(None if self.T_reference == 'local' else self.T_reference),
                        flux_every=self.n_dt_to_conv, contains_every=100)

@@ -125,6 +125,74 @@ def specular_correspondences_velocity(geometry, phonon, rough_facets, crit=1e-3,
     return corr, true_spec
 
 
+def specular_correspondences_k(geometry, phonon, rough_facets):
+    """'k' / 'wavevector' reflection model (Population.py:1056-1240): an in-mode (q, j) is specular when the mirrored
+    wavevector k - 2 n (k.n) stays in the first Brillouin zone (a normal process), lands on a grid point within half
+    a grid step, and that q-point has an outgoing branch whose frequency interval overlaps; of the overlapping
+    branches the one with the smallest relative frequency difference is taken.
+
+    Returns (correspondent_modes (K,7): n(3) q_in j_in q_out j_out, true_spec (Fr,Q,J) bool).
+    """
+    from scipy.interpolate import NearestNDInterpolator
+    normals = -np.round(geometry.facets_normal[rough_facets, :], decimals=10)
+    normals, inv_normals = np.unique(normals, axis=0, return_inverse=True)
+    inv_normals = np.asarray(inv_normals).ravel()
+    k = phonon.wavevectors
+    v = phonon.group_vel
+    Q, J = phonon.omega.shape
+    true_spec = np.zeros((len(rough_facets), Q, J), dtype=bool)
+    tol = phonon.q_to_k(np.absolute(1 / (2 * phonon.data_mesh)))
+    near_k = NearestNDInterpolator(k, np.arange(Q))
+    rows = []
+
+    def mirror(active):
+        return k[active, :] - 2 * n * np.sum(k[active, :] * n, axis=1, keepdims=True)
+
+    for i_n, n in enumerate(normals):
+        vdn = np.sum(v * n, axis=2)
+        s_in, s_out = vdn < 0, vdn > 0
+        active = np.any(s_in, axis=1)
+        _, disp = phonon.find_min_k(mirror(active), return_disp=True)
+        active[active] = np.all(disp == 0, axis=1)                       # normal processes only
+        k_try = mirror(active)
+        q_near = near_k(k_try).astype(int)
+        k_dist = np.absolute(k_try - k[q_near, :])
+        active[active] = np.logical_and(np.any(s_out[q_near, :], axis=1), np.all(k_dist < tol, axis=1))
+        out_q = near_k(mirror(active)).astype(int)
+        in_q = np.arange(Q)[active]
+        valid_v = np.logical_and(s_in[in_q, :], np.transpose(s_out[out_q, :][None], (2, 1, 0)))     # (Jout, Qa, Jin)
+        keep = np.any(valid_v, axis=(0, 2))
+        active[active] = keep
+        valid_v = valid_v[:, keep, :]
+        out_q = near_k(mirror(active)).astype(int)
+        in_q = np.arange(Q)[active]
+        in_delta = np.sum(np.absolute(v[in_q, :, :]) * tol[None, None, :], axis=2)                  # (Qa, J)
+        out_delta = np.sum(np.absolute(v[out_q, :, :]) * tol[None, None, :], axis=2)
+        in_om, out_om = phonon.omega[in_q, :], phonon.omega[out_q, :]
+        in_up, in_dn = in_om + in_delta, in_om - in_delta
+        out_up = np.transpose((out_om + out_delta)[None], (2, 1, 0))                                # (J, Qa, 1)
+        out_dn = np.transpose((out_om - out_delta)[None], (2, 1, 0))
+        overlap = (np.where(in_up < out_up, in_up, out_up) - np.where(in_dn > out_dn, in_dn, out_dn)) > 0
+        with np.errstate(divide='ignore', invalid='ignore'):
+            om_diff = np.absolute((in_om - np.transpose(out_om[None], (2, 1, 0))) / in_om)          # (Jout, Qa, Jin)
+        om_diff = np.where(overlap, om_diff, np.inf)
+        valid = np.logical_and(overlap, valid_v)
+        vk = np.any(valid, axis=(0, 2))
+        active[active] = vk
+        valid = valid[:, vk, :]
+        om_diff = np.where(valid, om_diff[:, vk, :], np.inf)
+        min_diff = np.amin(om_diff, axis=0)                                                         # (Qa, Jin)
+        branch = np.where(np.any(valid, axis=0), np.argmax(om_diff == min_diff, axis=0), -1).astype(int)
+        in_q = np.arange(Q)[active]
+        out_q = near_k(mirror(active)).astype(int)
+        for f in np.nonzero(inv_normals == i_n)[0]:
+            true_spec[f][in_q, :] = branch != -1
+        iq, j_in = np.nonzero(branch != -1)
+        rows.append(np.vstack((np.ones(iq.shape[0]) * n.reshape(-1, 1), in_q[iq], j_in, out_q[iq], branch[iq, j_in])).T)
+    corr = np.vstack(rows) if rows else np.zeros((0, 7))
+    return corr, true_spec
+
+
 def specular_map(corr, geometry, rough_facets, Q, J):
     """Flat out-mode per (rough facet, q, j), -1 where the mode has no specular partner.  When an in-mode has
     several partners the reference's nearest-neighbour lookup (Population.py:1457) returns one of them; here the

@@ -10,6 +10,8 @@ from util import golden, sub, golden_phonon, rel_err, case_tables, random_popula
 
 pytestmark = pytest.mark.gpu
 
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+
 
 def base_engine(name, interp=1, seed=1):
     from nanokappa_amd.engine import Engine
@@ -236,6 +238,31 @@ def test_other_geometries_vs_oracle(name):
     assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
     assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
     assert np.allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=1e-8)
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+
+
+def test_k_reflection_model_vs_oracle():
+    """--bound_scat k: wavevector-mirror specular pairs plus the degenerate-branch coin flip (Population.py:963-969);
+    tables from setup_tables.specular_correspondences_k (equal to the reference's, test_host_geometry), engine and
+    oracle stepped from the same state."""
+    import ref_harness_args as A
+    from util import case_from_args
+    ct = case_from_args(A.argv_for('ttrrp', 30000), 'Si', scat_model='k')
+    assert (ct['rough']['degen_j2'] > -1).sum() > 0
+    pos, mode, occ, counter = random_population(ct, 30000, seed=12)
+    nsteps = 20
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=77)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=77)
+    t = eng.step(nsteps)
+    for s in range(nsteps):
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+    p = eng.download()
+    n = sim.P.N
+    o1, o2 = np.argsort(p['pid']), np.argsort(sim.P.pid[:n])
+    assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
+    assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 

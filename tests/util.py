@@ -102,7 +102,8 @@ def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=29
                             n_leaving=(first_n_leaving(ep) if gen == 2 else None))
     if ct['rough'] is not None:
         r = ct['rough']
-        rough = O.make_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'])
+        rough = O.make_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'],
+                             degen_j2=r.get('degen_j2'))
     else:
         z = np.zeros(0)
         rough = O.make_rough(np.zeros(0, dtype=np.int32), z, np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32), z)
@@ -133,14 +134,14 @@ def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scal
                        n_leaving=(first_n_leaving(ep) if gen == 2 else None))
     if ct['rough'] is not None:
         r = ct['rough']
-        eng.set_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'])
+        eng.set_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'], degen_j2=r.get('degen_j2'))
     eng.set_params(dt=1.0, particle_density=ct['particle_density'], flux_every=flux_every, contains_every=contains_every)
     eng.upload(pos, mode, occ)
     eng.init_boundaries()
     return eng
 
 
-def case_from_args(argv, species='Si'):
+def case_from_args(argv, species='Si', scat_model='velocity'):
     """Same dict as case_tables, but assembled with this package's own Geometry / setup_tables from a Nano-kappa
     argument list (used for geometries that have no reference golden)."""
     from nanokappa_amd.argument_parser import initialise_parser
@@ -166,12 +167,22 @@ def case_from_args(argv, species='Si'):
                particle_density=density, geo=geo)
     if geo.rough_facets.shape[0] > 0:
         spec0 = ST.fbz_specularity(geo, ph, geo.rough_facets, geo.rough_facets_values)
-        corr, ts = ST.specular_correspondences_velocity(geo, ph, geo.rough_facets)
+        degen_j2 = None
+        if scat_model == 'k':
+            corr, ts = ST.specular_correspondences_k(geo, ph, geo.rough_facets)
+            deg, idx = ST.find_degeneracies(ph)
+            degen_j2 = -np.ones((Q, J), dtype=np.int32)
+            has = idx.astype(int) > -1
+            degen_j2[has] = deg[idx.astype(int)[has], 2]
+            degen_j2 = degen_j2.ravel()
+        else:
+            corr, ts = ST.specular_correspondences_velocity(geo, ph, geo.rough_facets)
+            deg = None
         spec = ts.astype(int) * spec0
         sm = ST.specular_map(corr, geo, geo.rough_facets, Q, J)
-        _, roul = ST.diffuse_roulette(geo, ph, geo.rough_facets, spec, corr)
+        _, roul = ST.diffuse_roulette(geo, ph, geo.rough_facets, spec, corr, scat_model=scat_model, degeneracies=deg)
         out['rough'] = dict(facets=geo.rough_facets, specularity=spec.reshape(-1, M), true_spec=ts.reshape(-1, M),
-                            spec_map=sm.reshape(-1, M), roulette=roul)
+                            spec_map=sm.reshape(-1, M), roulette=roul, degen_j2=degen_j2)
     else:
         out['rough'] = None
     return out
