@@ -175,8 +175,12 @@ class Geometry(object):
                 ax = int(np.nonzero(grid != 1)[0][0])
                 self.args.subvolumes = ['slice', int(grid[ax]), ax]
                 self.subvol_type = 'slice'
+        if self.subvol_type == 'grid':
+            self._set_grid_subvolumes(grid)
+            return
         if self.subvol_type != 'slice':
-            raise NotImplementedError("subvolume type %r: only 'slice' is built so far (SURVEY 8f row 4)" % self.subvol_type)
+            raise NotImplementedError("subvolume type %r: 'slice' and 'grid' are built (voronoi needs the reference's "
+                                      "random point relaxation, SURVEY 8f row 4)" % self.subvol_type)
         self.n_of_subvols = int(self.args.subvolumes[1])                                # Geometry.py:449-471
         self.slice_axis = int(self.args.subvolumes[2])
         ext = self.bounds[1] - self.bounds[0]
@@ -194,9 +198,71 @@ class Geometry(object):
         self.n_of_subvol_con = con.shape[0]
         self.subvol_con_vectors = self.subvol_center[con[:, 1]] - self.subvol_center[con[:, 0]]
 
+    def _set_grid_subvolumes(self, grid):
+        """nx x ny x nz cell centres over the bounding box (Geometry.py:508-538), those on the surface dropped, sorted
+        lexicographically; neighbours from get_subvol_connections; 3-D nearest-centre classifier."""
+        self.grid = grid
+        nx, ny, nz = (int(g) for g in grid)
+        xx = np.linspace(0.5 / nx, 1 - 0.5 / nx, nx)
+        yy = np.linspace(0.5 / ny, 1 - 0.5 / ny, ny)
+        zz = np.linspace(0.5 / nz, 1 - 0.5 / nz, nz)
+        g = np.meshgrid(xx, yy, zz)
+        ext = self.bounds[1] - self.bounds[0]
+        c = np.vstack(list(map(np.ravel, g))).T * ext + self.bounds[0, :]
+        _, dist, _ = self.mesh.closest_face(c)
+        c = c[dist > 0, :]                                                             # closest_point(...)[1] > 0
+        self.subvol_center = c[np.lexsort((c[:, 2], c[:, 1], c[:, 0]))]
+        self.n_of_subvols = self.subvol_center.shape[0]
+        self.get_subvol_connections()
+        self.subvol_classifier = SubvolClassifier(self.n_of_subvols, self.subvol_center)
+        self.subvol_volume = self.calculate_subvol_volume()
+
+    def get_subvol_connections(self):
+        """Which subvolumes are neighbours (Geometry.py:961-1052): candidate pairs whose midpoint is inside the solid and
+        whose connecting segment does not leave it, confirmed nearest first; a pair is dropped when its midpoint lies
+        beyond the interface plane of an already confirmed neighbour of either end."""
+        sc = self.subvol_center
+        S = self.n_of_subvols
+        o = (sc + sc[:, None, :]) / 2                                     # o[i, j] midpoint
+        n = sc - sc[:, None, :]                                           # n[i, j] = c_j - c_i
+        c_d = np.linalg.norm(n, axis=-1)
+        iu = np.triu_indices(S, k=1)
+        sv_con = np.vstack(iu).T                                          # sorted unique pairs (i < j), lexicographic
+        sv_con = sv_con[self.mesh.contains(o[sv_con[:, 0], sv_con[:, 1], :])]
+        _, d, _ = self.mesh.find_boundary(sc[sv_con[:, 0], :], n[sv_con[:, 0], sv_con[:, 1], :])
+        sv_con = sv_con[d > 1, :]
+        confirmed = np.zeros(sv_con.shape[0], dtype=bool)
+        remove = np.zeros(sv_con.shape[0], dtype=bool)
+        order = np.argsort(c_d[sv_con[:, 0], sv_con[:, 1]])
+        for index, con in enumerate(sv_con[order, :]):
+            k = order[index]
+            if confirmed[k]:
+                continue
+            i_sv, j_sv = con
+            for end in (i_sv, j_sv):
+                if remove[k]:
+                    break
+                e_con = np.nonzero(np.any(sv_con == end, axis=1))[0]
+                e_conf = e_con[confirmed[e_con]]
+                for k_sv in sv_con[e_conf, :][sv_con[e_conf, :] != end]:
+                    if np.sum((o[i_sv, j_sv, :] - o[end, k_sv, :]) * n[end, k_sv, :]) >= 0:
+                        remove[k] = True
+            if not remove[k]:
+                confirmed[k] = True
+        sv_con = sv_con[~remove, :]
+        u_sv = np.unique(sv_con)                                          # only connected subvolumes survive
+        self.subvol_center = sc[u_sv, :]
+        new = np.zeros(sv_con.shape, dtype=int)
+        for i, sv in enumerate(u_sv):
+            new = np.where(sv_con == sv, i, new)
+        self.subvol_connections = new
+        self.n_of_subvols = self.subvol_center.shape[0]
+        self.n_of_subvol_con = new.shape[0]
+        self.subvol_con_vectors = self.subvol_center[new[:, 1], :] - self.subvol_center[new[:, 0], :]
+
     def calculate_subvol_volume(self, tol=1e-4, seed=20231003):
         """Exact V/S for boxes (Geometry.py:551-552); Monte-Carlo cover otherwise (:605-639), seeded."""
-        if self.shape in ('cuboid', 'box'):
+        if self.subvol_type in ('slice', 'grid') and self.shape in ('cuboid', 'box'):
             return self.volume * np.ones(self.n_of_subvols) / self.n_of_subvols
         rng = np.random.default_rng(seed)
         cover = np.zeros(self.n_of_subvols)

@@ -48,6 +48,10 @@ class _Stats(object):
                 self.mean_sv_k, self.std_sv_k = np.nanmean(k, axis=0), np.nanstd(k, axis=0)
             kk = np.array([r['kappa'] for r in rows])
             self.mean_k, self.std_k = np.nanmean(kk), np.nanstd(kk)
+        else:                                                   # per-connection conductivities, Visualisation.py:196-199
+            ck = np.array([r['con_k'] for r in rows])
+            with np.errstate(invalid='ignore'):
+                self.mean_con_k, self.std_con_k = np.nanmean(ck, axis=0), np.nanstd(ck, axis=0)
 
 
 class Population(Constants):
@@ -499,7 +503,8 @@ class Population(Constants):
                 new_mean = np.concatenate((v.mean_T, v.mean_sv_phi[sel], v.mean_en_res, v.mean_sv_k))
                 new_std = np.concatenate((v.std_T, v.std_sv_phi[sel], v.std_en_res, v.std_sv_k))
             else:
-                raise NotImplementedError('residue for non-slice subvolumes')
+                new_mean = np.concatenate((v.mean_T, v.mean_sv_phi, v.mean_en_res, v.mean_con_k))
+                new_std = np.concatenate((v.std_T, v.std_sv_phi, v.std_en_res, v.std_con_k))
             residue_mean = np.absolute((new_mean - self.old_mean_large) / self.old_mean_large)
         self.residue_all = np.where(new_std > np.absolute(new_mean), 0, residue_mean)
         self.max_residue = np.nanmax(self.residue_all)
@@ -538,7 +543,8 @@ class Population(Constants):
     def _record_convergence(self, geometry):
         row = dict(step=self.current_timestep, T=np.array(self.subvol_temperature), phi=np.array(self.subvol_heat_flux),
                    en_res=np.array(self.res_energy_balance), N_p=self.N_p, sv_Np=np.array(self.subvol_N_p),
-                   kappa=getattr(self, 'kappa', np.nan), sv_k=np.array(getattr(self, 'subvol_kappa', np.zeros(0))))
+                   kappa=getattr(self, 'kappa', np.nan), sv_k=np.array(getattr(self, 'subvol_kappa', np.zeros(0))),
+                   con_k=np.array(getattr(self, 'svcon_kappa', np.zeros(0))))
         self.conv_rows.append(row)
         if len(self.conv_rows) > max(self.n_mean, 1000):
             del self.conv_rows[:-max(self.n_mean, 1000)]

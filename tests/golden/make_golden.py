@@ -111,6 +111,45 @@ def gen_mesh():
     np.savez_compressed(os.path.join(HERE, 'mesh.npz'), **out)
 
 
+GRID_ARGS = {   # 'grid' subvolumes (Geometry.py:473-539, :961-1052): box and cylinder, nearest-centre temperatures
+    'box_grid332': ['--geometry', 'box', '--dimensions', '200', '200', '200', '--subvolumes', 'grid', '3', '3', '2',
+                    '--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5', '--bound_cond', 'T', 'T', 'P',
+                    '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
+                    '--bound_values', '302', '298'],
+    'box_grid441': ['--geometry', 'box', '--dimensions', '400', '300', '100', '--subvolumes', 'grid', '4', '4', '1',
+                    '--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5', '--bound_cond', 'T', 'T', 'P',
+                    '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
+                    '--bound_values', '302', '298'],
+}
+
+
+def grid_argv(name, particles=1000, iterations=1000):
+    common = [a for a in H.COMMON]
+    i = common.index('--temp_interp')
+    common[i + 1] = 'nearest'
+    return GRID_ARGS[name] + common + ['--particles', 'total', str(particles), '--iterations', str(iterations)]
+
+
+def gen_grid():
+    out = {}
+    rng = np.random.default_rng(11)
+    for name in GRID_ARGS:
+        args = H.make_args(ref, grid_argv(name))
+        geo = ref.Geometry(args)
+        p = name + '__'
+        out[p + 'subvol_center'] = geo.subvol_center
+        out[p + 'subvol_volume'] = geo.subvol_volume
+        out[p + 'subvol_connections'] = geo.subvol_connections
+        out[p + 'subvol_con_vectors'] = geo.subvol_con_vectors
+        out[p + 'n_of_subvols'] = np.array(geo.n_of_subvols)
+        b = geo.mesh.bounds
+        x = b[0] - 10 + rng.random((3000, 3)) * (b[1] - b[0] + 20)
+        out[p + 'cls_x'] = x
+        out[p + 'cls_id'] = geo.subvol_classifier.predict(x)
+        print(name, geo.n_of_subvols, 'subvolumes', geo.subvol_connections.shape[0], 'connections')
+    np.savez_compressed(os.path.join(HERE, 'grid.npz'), **out)
+
+
 def material_small():
     return make_material(9, 'Si', temperatures=T_GRID)
 
@@ -412,8 +451,21 @@ def gen_emission():
     np.savez_compressed(os.path.join(HERE, 'emission.npz'), **out)
 
 
+def build_case_argv(argv, seed):
+    mat = material_small()
+    args = H.make_args(ref, argv)
+    geo = ref.Geometry(args)
+    ph = H.make_phonon(ref, args, mat)
+    np.random.seed(seed)
+    pop = ref.Population(args, geo, ph)
+    return args, geo, ph, pop, mat
+
+
 def run_stats(case, seed, particles=100000, steps=1000, extra=()):
-    args, geo, ph, pop, mat = build_case(case, particles, seed, extra=extra, iterations=steps)
+    if case in GRID_ARGS:
+        args, geo, ph, pop, mat = build_case_argv(grid_argv(case, particles, steps), seed)
+    else:
+        args, geo, ph, pop, mat = build_case(case, particles, seed, extra=extra, iterations=steps)
     rows = []
     t0 = time.time()
     nsum = 0
@@ -421,9 +473,13 @@ def run_stats(case, seed, particles=100000, steps=1000, extra=()):
         pop.run_timestep(geo, ph)
         nsum += pop.N_p
         if pop.current_timestep % 10 == 0:
-            rows.append(np.concatenate(([pop.current_timestep, pop.N_p, pop.kappa],
-                                        pop.subvol_temperature, pop.subvol_heat_flux[:, 0],
-                                        pop.subvol_N_p, pop.subvol_kappa)))
+            if geo.subvol_type == 'slice':
+                rows.append(np.concatenate(([pop.current_timestep, pop.N_p, pop.kappa],
+                                            pop.subvol_temperature, pop.subvol_heat_flux[:, 0],
+                                            pop.subvol_N_p, pop.subvol_kappa)))
+            else:       # step, N_p, T[S], phi[S*3], Np[S], connection kappas[C]
+                rows.append(np.concatenate(([pop.current_timestep, pop.N_p], pop.subvol_temperature,
+                                            pop.subvol_heat_flux.ravel(), pop.subvol_N_p, pop.svcon_kappa)))
     wall = time.time() - t0
     return np.array(rows), wall, nsum
 
@@ -442,7 +498,7 @@ def gen_stats_one(case, seed):
 
 def gen_stats_merge():
     import glob
-    for case in ('ttp', 'ttrrp', 'ttp_o2o'):
+    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332'):
         files = sorted(glob.glob(os.path.join(HERE, '_stats_%s_[0-9]*.npz' % case)))
         if not files:
             continue
@@ -450,6 +506,10 @@ def gen_stats_merge():
         walls = np.array([float(np.load(f)['wall']) for f in files])
         ps = np.array([float(np.load(f)['phonon_steps']) for f in files])
         seeds = np.array([int(os.path.basename(f).split('_')[-1].split('.')[0]) for f in files])
+        if case in GRID_ARGS:
+            np.savez_compressed(os.path.join(HERE, 'stats_%s.npz' % case), rows=rows, wall=walls, phonon_steps=ps, seeds=seeds)
+            print(case, rows.shape, 'mean throughput', (ps / walls).mean())
+            continue
         np.savez_compressed(os.path.join(HERE, 'stats_%s.npz' % case), rows=rows, wall=walls,
                             phonon_steps=ps, seeds=seeds,
                             columns=np.array(['step', 'N_p', 'kappa'] + ['T%d' % i for i in range(20)]

@@ -241,6 +241,33 @@ def test_other_geometries_vs_oracle(name):
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
+def test_grid_subvolumes_vs_oracle():
+    """'grid' subvolumes: 3-D nearest-centre classification and nearest-centre particle temperatures on the device
+    (nk_classify general branch) against the oracle, step by step."""
+    from util import case_from_args
+    argv = ['--geometry', 'box', '--dimensions', '200', '200', '200', '--subvolumes', 'grid', '3', '3', '2',
+            '--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5', '--bound_cond', 'T', 'T', 'P',
+            '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
+            '--bound_values', '302', '298', '--poscar_file', 'POSCAR', '--hdf_file', 'synthetic', '--temp_interp', 'nearest',
+            '--timestep', '1', '--energy_normal', 'mean', '--particles', 'total', '30000']
+    ct = case_from_args(argv, 'Si')
+    assert ct['kind'] == 1 and ct['centers'].shape[0] == 18
+    pos, mode, occ, counter = random_population(ct, 30000, seed=21)
+    nsteps = 20
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=5)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=5)
+    t = eng.step(nsteps)
+    for s in range(nsteps):
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+    p = eng.download()
+    n = sim.P.N
+    o1, o2 = np.argsort(p['pid']), np.argsort(sim.P.pid[:n])
+    assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+
+
 def test_k_reflection_model_vs_oracle():
     """--bound_scat k: wavevector-mirror specular pairs plus the degenerate-branch coin flip (Population.py:963-969);
     tables from setup_tables.specular_correspondences_k (equal to the reference's, test_host_geometry), engine and

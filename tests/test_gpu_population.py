@@ -89,3 +89,63 @@ def test_outputs_written(tmp_path):
     pd = np.loadtxt(tmp_path / 'particle_data.txt', delimiter=',', comments='#')
     assert pd.shape[1] == 6 and abs(pd.shape[0] - 20000) < 2000
     assert os.path.exists(tmp_path / 'residue.txt')
+
+
+GRID_ARGV = ['--geometry', 'box', '--dimensions', '200', '200', '200', '--subvolumes', 'grid', '3', '3', '2',
+             '--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5', '--bound_cond', 'T', 'T', 'P',
+             '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
+             '--bound_values', '302', '298']
+
+
+def test_statistical_parity_grid_subvolumes():
+    """'grid' subvolumes with nearest-centre temperatures (tests/golden/make_golden.py box_grid332: 4 reference runs,
+    1e5 particles x 1000 steps): subvolume temperatures, x heat flux, particle count and the conductivities of the
+    connections along the gradient, averaged over steps 500-1000."""
+    import ref_harness_args as A
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.phonon import Phonon
+    from nanokappa_amd.population import Population
+    g = golden('stats_box_grid332')
+    rr = g['rows']                                            # (seeds, 100, 2 + S + 3S + S + C)
+    common = list(A.COMMON)
+    common[common.index('--temp_interp') + 1] = 'nearest'
+    S = 18
+    rows = []
+    seeds = [201, 202, 203, 204]
+    for s in seeds:
+        argv = GRID_ARGV + common + ['--particles', 'total', '100000', '--iterations', '1000', '--seed', str(s)]
+        args = initialise_parser().parse_args(argv)
+        args.results_folder = ''
+        geo = Geometry(args)
+        ph = Phonon(args, 0, material=golden_material())
+        pop = Population(args, geo, ph)
+        rec = []
+        for _ in range(100):
+            pop.run(10, geo, ph)
+            rec.append(np.concatenate(([pop.current_timestep, pop.N_p], pop.subvol_temperature,
+                                       pop.subvol_heat_flux.ravel(), pop.subvol_N_p, pop.svcon_kappa)))
+        rows.append(np.array(rec))
+        pop.engine.close()
+    rows = np.array(rows)
+    assert rows.shape[2] == rr.shape[2]
+    lo = 50
+
+    def cmp(sl, nsig, what):
+        # 4 + 4 runs: a per-subvolume variance from 4 samples is too noisy to standardise with, so the run-to-run
+        # variance is pooled over the (statistically equivalent) subvolumes
+        a, b = rr[:, lo:, sl].mean(axis=1), rows[:, lo:, sl].mean(axis=1)
+        se = np.sqrt(a.var(axis=0, ddof=1).mean() / a.shape[0] + b.var(axis=0, ddof=1).mean() / b.shape[0])
+        z = np.abs(a.mean(axis=0) - b.mean(axis=0)) / se
+        assert np.all(z < nsig), (what, z)
+
+    cmp(slice(2, 2 + S), 4.0, 'T')
+    cmp(slice(2 + S, 2 + 4 * S, 3), 4.0, 'phi_x')
+    assert abs(rows[:, lo:, 1].mean() / rr[:, lo:, 1].mean() - 1) < 0.01
+    con = geo.subvol_connections
+    along_x = np.nonzero(np.abs(geo.subvol_con_vectors[:, 0]) > 1e-6)[0]
+    k0 = 2 + 5 * S
+    a = np.nanmean(rr[:, lo:, k0:][:, :, along_x], axis=(1, 2))
+    b = np.nanmean(rows[:, lo:, k0:][:, :, along_x], axis=(1, 2))
+    se = np.sqrt(a.var(ddof=1) / a.size + b.var(ddof=1) / b.size)
+    assert abs(a.mean() - b.mean()) < 4 * se, (a, b)

@@ -114,3 +114,32 @@ def test_setup_tables_k_model_equal_reference():
     rate, roul = ST.diffuse_roulette(geo, ph, geo.rough_facets, spec, corr, scat_model='k', degeneracies=deg)
     assert np.allclose(rate, g['creation_rate'], rtol=0, atol=1e-12)
     assert np.allclose(roul, g['creation_roulette'], rtol=0, atol=1e-12)
+
+
+GRID_CASES = {
+    'box_grid332': ['--geometry', 'box', '--dimensions', '200', '200', '200', '--subvolumes', 'grid', '3', '3', '2'],
+    'box_grid441': ['--geometry', 'box', '--dimensions', '400', '300', '100', '--subvolumes', 'grid', '4', '4', '1'],
+}
+GRID_BC = ['--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5', '--bound_cond', 'T', 'T', 'P',
+           '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
+           '--bound_values', '302', '298']
+
+
+def grid_argv(name, particles=1000):
+    common = list(A.COMMON)
+    common[common.index('--temp_interp') + 1] = 'nearest'
+    return GRID_CASES[name] + GRID_BC + common + ['--particles', 'total', str(particles)]
+
+
+@pytest.mark.parametrize('name', sorted(GRID_CASES))
+def test_grid_subvolumes_equal_reference(name):
+    """'grid' subvolumes (Geometry.py:508-538), their neighbour list (get_subvol_connections, :961-1052) and the 3-D
+    nearest-centre classifier against the reference's own Geometry (tests/golden/grid.npz)."""
+    geo, _ = make_geo(grid_argv(name))
+    g = sub(golden('grid'), name)
+    assert geo.n_of_subvols == int(g['n_of_subvols'])
+    assert np.allclose(geo.subvol_center, g['subvol_center'], rtol=0, atol=1e-9)
+    assert np.array_equal(geo.subvol_connections, g['subvol_connections'])
+    assert np.allclose(geo.subvol_con_vectors, g['subvol_con_vectors'], rtol=0, atol=1e-9)
+    assert np.allclose(geo.subvol_volume, g['subvol_volume'], rtol=1e-12)
+    assert np.array_equal(geo.subvol_classifier.predict(g['cls_x']), g['cls_id'])

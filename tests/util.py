@@ -96,7 +96,8 @@ def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=29
     import nk_oracle as O
     mat = O.make_material(ct['tables'])
     mesh = O.make_mesh(ct['mesh'])
-    sv = O.make_subvols(ct['centers'], ct['volumes'], 0, ct['axis'], interp)
+    kind = ct.get('kind', 0)
+    sv = O.make_subvols(ct['centers'], ct['volumes'], kind, ct['axis'], 2 if kind == 1 else interp)
     ep = ct['enter_prob'] * emit_scale
     res = O.make_reservoirs(ct['res_facets'], ct['res_T'], ep, counter.copy(), gen=gen,
                             n_leaving=(first_n_leaving(ep) if gen == 2 else None))
@@ -128,7 +129,9 @@ def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scal
     eng = Engine(device, seed)
     eng.set_material(ct['tables'])
     eng.set_mesh(ct['mesh'])
-    eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], interp, np.full(ct['centers'].shape[0], T0))
+    kind = ct.get('kind', 0)
+    eng.set_subvolumes(ct['centers'], ct['volumes'], kind, ct['axis'], 2 if kind == 1 else interp,
+                       np.full(ct['centers'].shape[0], T0))
     ep = ct['enter_prob'] * emit_scale
     eng.set_reservoirs(ct['res_facets'], ct['res_T'], ep, counter, gen=gen,
                        n_leaving=(first_n_leaving(ep) if gen == 2 else None))
@@ -162,7 +165,8 @@ def case_from_args(argv, species='Si', scat_model='velocity'):
     density = n_p / geo.volume
     g = geo.tables()
     out = dict(ph=ph, J=J, M=M, mesh=g, tables=ph.tables(), centers=geo.subvol_center, volumes=geo.subvol_volume,
-               axis=geo.slice_axis, res_facets=geo.res_facets, res_T=np.asarray(geo.res_values, dtype=float),
+               axis=(geo.slice_axis if geo.subvol_type == 'slice' else 0), kind=(0 if geo.subvol_type == 'slice' else 1),
+               res_facets=geo.res_facets, res_T=np.asarray(geo.res_values, dtype=float),
                enter_prob=ST.enter_probability(geo, ph, geo.res_facets, density, 1.0).reshape(-1, M),
                particle_density=density, geo=geo)
     if geo.rough_facets.shape[0] > 0:
