@@ -770,10 +770,11 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     ctx->timing.total_ms = ms;
     std::vector<double> h((size_t)nsteps * HROW);
     NK_HIP(hipMemcpy(h.data(), ctx->hist, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-    bool overflow = false;
+    int overflow = 0;      // reason mask: 1 more entering particles than free slots, 2 / 4 a segment filled up (tile commit /
+                           // event survivors), 8 spawn list full, 16 one_to_one index overflow
     for (int s = 0; s < nsteps; ++s) {
         const double *row = &h[(size_t)s * HROW];
-        if (row[NB + 2 * S + 3] != 0.0) overflow = true;
+        if (row[NB + 2 * S + 3] != 0.0) overflow |= (int)row[NB + 2 * S + 3];
         if (!out) continue;
         if (out->E_raw) memcpy(out->E_raw + (size_t)s * S, row, S * 8);
         if (out->N_sv) memcpy(out->N_sv + (size_t)s * S, row + S, S * 8);
@@ -795,7 +796,8 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     for (int k = 0; k < S; ++k) live += last[S + k];
     ctx->timing.live = (int64_t)live;
     if (overflow) {
-        ctx->err = "particle capacity exceeded during nk_step: particles were dropped; call nk_reserve with a larger capacity";
+        ctx->err = "particle capacity exceeded during nk_step (reason mask " + std::to_string(overflow) +
+                   "): particles were dropped; call nk_reserve with a larger capacity";
         return NK_ERR_CAPACITY;
     }
     return NK_OK;

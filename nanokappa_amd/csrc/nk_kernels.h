@@ -243,7 +243,7 @@ __device__ __forceinline__ void nk_emit_block(const NkDev &d, uint32_t step, int
         for (int level = c; level >= 1 && cm > 0; --level) {
             if (d.nranks > 1 && (((uint32_t)rm + (uint32_t)level + step) % (uint32_t)d.nranks) != (uint32_t)d.rank) continue;
             if (g < d.spawn_cap) list[g] = ((uint64_t)rm << 12) | (uint64_t)level;
-            else *d.overflow = 1;
+            else atomicOr(d.overflow, 8);       // spawn list full
             ++g;
         }
     }
@@ -277,7 +277,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t ste
                 int m = nk_ss_left(d.res_roulette + (int64_t)r * d.M, d.M, um);
                 m = m > d.M - 1 ? d.M - 1 : m;
                 if (i < (1ll << 24)) { rec = ((uint64_t)i << 40) | ((uint64_t)((int64_t)r * d.M + m) << 12); mine = 1; }
-                else *d.overflow = 1;
+                else atomicOr(d.overflow, 16);      // one_to_one index beyond 2^24
             }
         }
         int incl = mine;
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t ste
         int base = bbase;
         for (int w = 0; w < wave; ++w) base += wsum[w];
         const int64_t g = (int64_t)base + incl - mine;
-        if (mine) { if (g < d.spawn_cap) list[g] = rec; else *d.overflow = 1; }
+        if (mine) { if (g < d.spawn_cap) list[g] = rec; else atomicOr(d.overflow, 8); }
         __syncthreads();
     }
 }
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
     int64_t total = d.R > 0 ? (int64_t)d.alloc_count[buf] : 0;
     if (total > d.spawn_cap) total = d.spawn_cap;
     const int64_t total_free = d.seg_free_prefix[d.nseg];
-    if (total > total_free) { total = total_free; if (tid == 0) *d.overflow = 1; }
+    if (total > total_free) { total = total_free; if (tid == 0) atomicOr(d.overflow, 1); }
     if (NK_ABL(16)) total = 0;
     if (NK_ABL(4)) do_relax = 0;
     if (tid == 0 && blockIdx.x == 0) L.bins.misc[0] = (unsigned int)total;          // "emitted" column
@@ -360,12 +360,13 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
         // self-balancing, and the share always fits
         int64_t g0 = total_free > 0 ? total * d.seg_free_prefix[seg] / total_free : 0;
         int64_t g1 = total_free > 0 ? total * d.seg_free_prefix[seg + 1] / total_free : 0;
-        // whole tiles: share boundaries rounded down to multiples of 64 (a 9-lane tile costs as much as a full one).
-        // The prefix only counts segments with >= NK_MIN_FREE free slots, so a share grown by up to 63 still fits
-        // whenever the entering particles fill at most half of that space.
-        if (d.segcap >= NK_QUANT_SEGCAP && total * 2 <= total_free) {
-            g0 &= ~(int64_t)63;
-            g1 = (seg + 1 == d.nseg) ? total : (g1 & ~(int64_t)63);
+        // whole tiles: share boundaries rounded UP to multiples of 64 and clipped at the total (a 9-lane tile costs as
+        // much as a full one).  A share grows by at most 63, and a segment whose exact share is empty stays empty -- in
+        // particular the excluded ones: the prefix only counts segments with >= NK_MIN_FREE free slots, so the grown
+        // share still fits whenever the entering particles fill at most half of that space.
+        if (d.segcap >= NK_QUANT_SEGCAP && total * 2 <= total_free && !NK_ABL(256)) {
+            g0 = (g0 + 63) & ~(int64_t)63; g0 = g0 < total ? g0 : total;
+            g1 = (g1 + 63) & ~(int64_t)63; g1 = g1 < total ? g1 : total;
         }
         const int nA = (count + NK_TILE - 1) / NK_TILE, nB = (int)((g1 - g0 + NK_TILE - 1) / NK_TILE);
         int w = 0, ev_n = 0;
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
             if (done) {
                 const int o = w + __popcll(mD & lower);
                 if (o < d.segcap) { if (!NK_ABL(1)) nk_store(d, base + o, x, y, z, occ, nts, mode, facet, pid); }
-                else *d.overflow = 1;
+                else atomicOr(d.overflow, 2);       // segment full at the commit of a tile
             }
             w += __popcll(mD);
             // ---- drain (Population.py:1546-1683): one boundary event per particle and pass; finished particles are
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 if (alive) {
                     const int o = w + __popcll(mA & lower);
                     if (o < d.segcap) { if (!NK_ABL(1)) nk_store(d, base + o, p.x, p.y, p.z, p.occ, p.nts, p.mode, p.facet, ppid); }
-                    else *d.overflow = 1;
+                    else atomicOr(d.overflow, 4);   // segment full while appending event survivors
                 }
                 w += __popcll(mA);
                 ev_n -= n;

@@ -268,6 +268,20 @@ def test_grid_subvolumes_vs_oracle():
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
+def test_long_run_keeps_segments_balanced():
+    """Regression: entering particles are dealt in whole 64-particle tiles; the remainder once always landed in the last
+    segment, which filled up after a few dozen steps.  Few entering particles per step and many steps."""
+    from util import case_from_args, population_in_mesh
+    argv, species = EXTRA_CASES['wire16']
+    ct = case_from_args(argv + COMMON_ARGS[:-1] + ['200000'], species)
+    pos, mode, occ, counter = population_in_mesh(ct, 200000, seed=3)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=11)
+    for _ in range(4):
+        t = eng.step(100)
+    live = t['N_sv'][-1].sum()
+    assert 0.8 * 200000 < live < 1.2 * 200000
+
+
 def test_k_reflection_model_vs_oracle():
     """--bound_scat k: wavevector-mirror specular pairs plus the degenerate-branch coin flip (Population.py:963-969);
     tables from setup_tables.specular_correspondences_k (equal to the reference's, test_host_geometry), engine and
