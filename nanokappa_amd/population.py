@@ -441,6 +441,12 @@ class Population(Constants):
             if (self.current_timestep % 100) == 0:
                 self._every_hundred(geometry)
             chunk = min(nsteps - done, 100 - (self.current_timestep % 100))
+            # the reference grows its arrays as the ensemble grows; here the particle store is re-laid out with head room
+            # before it can fill up (this rank's share of N_p against the engine's slots)
+            tm = self.engine.timing()
+            local = self.N_p / max(self.nranks, 1)
+            if tm['slots'] > 0 and local > 0.7 * tm['slots']:
+                self.engine.reserve(int(2.0 * local) + 65536)
             t = self.engine.step(chunk)
             for s in range(chunk):
                 self.current_timestep += 1

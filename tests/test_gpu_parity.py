@@ -268,6 +268,29 @@ def test_grid_subvolumes_vs_oracle():
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
+def test_reserve_mid_run_preserves_state():
+    """nk_reserve between steps re-lays the particle store out (new segment count, mode-sorted): the deferred
+    relaxation and the prepared emission of the next step must survive, i.e. the run continues exactly like the oracle."""
+    ct = case_tables('ttrrp')
+    pos, mode, occ, counter = random_population(ct, 30000, seed=15)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=8)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=8)
+    t1 = eng.step(7)
+    eng.reserve(400000)
+    t2 = eng.step(8)
+    T = np.concatenate((t1['T_sv'], t2['T_sv']))
+    N = np.concatenate((t1['N_sv'], t2['N_sv']))
+    for s in range(15):
+        sim.run_timestep()
+        assert np.array_equal(N[s], sim.N_sv), 'step %d' % s
+        assert np.allclose(T[s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+    p = eng.download()
+    n = sim.P.N
+    o1, o2 = np.argsort(p['pid']), np.argsort(sim.P.pid[:n])
+    assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+
+
 def test_long_run_keeps_segments_balanced():
     """Regression: entering particles are dealt in whole 64-particle tiles; the remainder once always landed in the last
     segment, which filled up after a few dozen steps.  Few entering particles per step and many steps."""
