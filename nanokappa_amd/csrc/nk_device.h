@@ -19,6 +19,7 @@
 #define NK_LDS_FACES 256     // meshes up to this many faces keep their plane/face tables in LDS
 #define NK_LDS_RESFACES 64   // reservoir facets with up to this many faces in total keep their sampling tables in LDS
 #define NK_TAU_ROWS 4        // lifetime rows packed into each mode record
+#define NK_MAX_SEGMENTS 8192  // upper bound of nseg (the update keeps 32 per thread in registers)
 #define NK_EVCAP 512         // entries of the per-workgroup LDS event buffer (< NK_WG pending + NK_WG new)
 
 // RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")
@@ -59,6 +60,8 @@ struct NkDev {
     double active_modes;
     // ---- mesh
     int32_t F, Fc, NP;                // faces, facets, distinct planes
+    const double *pgroups;            // [NG*NK_GROUP_DOUBLES] plane groups with bounding boxes (large meshes), or NG = 0
+    int32_t NG;
     const double *planes;             // [NP*NK_PLANE_DOUBLES]
     const double *faces;              // [F*NK_FACE_DOUBLES], grouped by plane
     const NkFacet *facets;            // [Fc]
@@ -325,25 +328,25 @@ __device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen,
 // plane and only when x.n + k and v.n have opposite signs (t >= tol > 0 is impossible otherwise, Mesh.py:820); the
 // per-triangle AABB (:828-829) and barycentric tests (:837-843) then run on that plane's faces.  Face record rows
 // iu/iw are the first two rows of the inverse of face_basis_matrix: (u, w) = rows . (c - o) is the solve() of :840.
-__device__ __forceinline__ void nk_find_boundary(const double *planes, const double *faces, int NP, double tol, double x,
-                                                 double y, double z, double vx, double vy, double vz, double &tc, int &fc) {
+struct NkHit { double t; int face, facet; };
+// The planes [pl0, pl1) against one ray; `h` carries the best hit so far.
+__device__ __forceinline__ void nk_fb_planes(const double *planes, const double *faces, int pl0, int pl1, double tol, double x,
+                                             double y, double z, double vx, double vy, double vz, NkHit &h) {
     // numpy evaluates these dot products without fused multiply-adds; num cancels near a plane, so a fused evaluation
     // moves t by many ulps.  Keep the reference's rounding here.
 #pragma clang fp contract(off)
-    double tbest = __builtin_inf();
-    int fbest = 0x7fffffff, facet = -1;
     // The tables are the same for all lanes, so every read is a latency, not a bandwidth, cost: records are fetched with
     // 16-byte reads issued together, and the next plane is requested while the current one is evaluated.
     const double2 *P = reinterpret_cast<const double2 *>(planes);
-    double2 n0 = P[0], n1 = P[1], n2 = P[2];
-    for (int pl = 0; pl < NP; ++pl) {
+    double2 n0 = P[3 * pl0], n1 = P[3 * pl0 + 1], n2 = P[3 * pl0 + 2];
+    for (int pl = pl0; pl < pl1; ++pl) {
         const double2 p01 = n0, p23 = n1, pr = n2;
-        if (pl + 1 < NP) { n0 = P[3 * pl + 3]; n1 = P[3 * pl + 4]; n2 = P[3 * pl + 5]; }
+        if (pl + 1 < pl1) { n0 = P[3 * pl + 3]; n1 = P[3 * pl + 4]; n2 = P[3 * pl + 5]; }
         const double num = x * p01.x + y * p01.y + z * p23.x + p23.y;
         const double den = vx * p01.x + vy * p01.y + vz * p23.x;
         if (!((num < 0.0 && den > 0.0) || (num > 0.0 && den < 0.0))) continue;
         const double t = -num / den;
-        if (!(t >= tol) || isinf(t) || t > tbest) continue;
+        if (!(t >= tol) || isinf(t) || t > h.t) continue;
         const double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
         const int f_lo = __double2loint(pr.x), f_hi = __double2hiint(pr.x);
         for (int f = f_lo; f < f_hi; ++f) {
@@ -359,11 +362,46 @@ __device__ __forceinline__ void nk_find_boundary(const double *planes, const dou
             const double r = 1.0 - (u + w);
             if (!(u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol)) continue;
             const int idf = __double2loint(q7.y), idc = __double2hiint(q7.y);
-            if (t < tbest || idf < fbest) { tbest = t; fbest = idf; facet = idc; }
+            if (t < h.t || idf < h.face) { h.t = t; h.face = idf; h.facet = idc; }
         }
     }
-    tc = tbest;
-    fc = facet;
+}
+__device__ __forceinline__ void nk_find_boundary(const double *planes, const double *faces, int NP, double tol, double x,
+                                                 double y, double z, double vx, double vy, double vz, double &tc, int &fc) {
+    NkHit h = {__builtin_inf(), 0x7fffffff, -1};
+    nk_fb_planes(planes, faces, 0, NP, tol, x, y, z, vx, vy, vz, h);
+    tc = h.t;
+    fc = h.facet;
+}
+// Large meshes: the planes are sorted along a space-filling curve and cut into groups of NK_GROUP_PLANES; a group record
+// holds the (slightly inflated) bounding box of its faces.  A ray only visits the groups whose box it crosses before the
+// best hit so far -- a hit point lies inside its face's box, so nothing is lost and the result equals the plain sweep
+// (ties still go to the lowest face index, whatever the visiting order).
+#define NK_GROUP_PLANES 16
+#define NK_GROUP_DOUBLES 8       // lo(3) hi(3) {plane_begin, plane_end} pad
+__device__ __forceinline__ void nk_find_boundary_grouped(const double *groups, int NG, const double *planes,
+                                                         const double *faces, double tol, double x, double y, double z,
+                                                         double vx, double vy, double vz, double &tc, int &fc) {
+    NkHit h = {__builtin_inf(), 0x7fffffff, -1};
+    const double ix = 1.0 / vx, iy = 1.0 / vy, iz = 1.0 / vz;         // +-inf for an axis-parallel ray: handled below
+    for (int g = 0; g < NG; ++g) {
+        const double2 *B = reinterpret_cast<const double2 *>(groups + g * NK_GROUP_DOUBLES);
+        const double2 b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3];    // lo.x lo.y | lo.z hi.x | hi.y hi.z | range pad
+        double t0 = 0.0, t1 = h.t;                                   // the part of the ray that can still matter
+        bool miss = false;
+        {
+            if (vx != 0.0) { const double a = (b0.x - x) * ix, b = (b1.y - x) * ix; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
+            else miss |= (x < b0.x) | (x > b1.y);
+            if (vy != 0.0) { const double a = (b0.y - y) * iy, b = (b2.x - y) * iy; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
+            else miss |= (y < b0.y) | (y > b2.x);
+            if (vz != 0.0) { const double a = (b1.x - z) * iz, b = (b2.y - z) * iz; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
+            else miss |= (z < b1.x) | (z > b2.y);
+        }
+        if (miss || !(t0 <= t1)) continue;
+        nk_fb_planes(planes, faces, __double2loint(b3.x), __double2hiint(b3.x), tol, x, y, z, vx, vy, vz, h);
+    }
+    tc = h.t;
+    fc = h.facet;
 }
 
 // ---------------------------------------------------------------------------------- rough reflection
@@ -418,8 +456,8 @@ struct NkParticle {
 #define NK_EV_DEAD 1
 #define NK_EV_MORE 2
 template <bool ROUGH>
-__device__ __forceinline__ int nk_event_one(const NkDev &d, const double *planes, const double *faces,
-                                            const NkFacet *facets, const double *cen, const double *Tsv,
+__device__ __forceinline__ int nk_event_one(const NkDev &d, const double *groups, int NG, const double *planes,
+                                            const double *faces, const NkFacet *facets, const double *cen, const double *Tsv,
                                             const double *resT, NkBins &b, NkParticle &p, double &cts, uint32_t &ev,
                                             uint64_t pid, uint32_t step) {
     const double dt = d.dt;
@@ -469,7 +507,8 @@ __device__ __forceinline__ int nk_event_one(const NkDev &d, const double *planes
 #ifdef NK_ABLATE
         if (d.dbg & 32) { tc = 3.0 * dt; fcn = p.facet; } else
 #endif
-        nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
+        if (NG > 0) nk_find_boundary_grouped(groups, NG, planes, faces, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
+        else nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
         p.nts = tc / dt;
         p.facet = fcn;
         if (++ev > 4096u) cts = 1.0;                         // the reference would spin

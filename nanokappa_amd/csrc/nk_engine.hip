@@ -241,6 +241,33 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         members[found].push_back(f);
     }
     d.NP = (int)members.size();
+    // Large meshes (tables in global memory): order the planes along a Morton curve of their faces' box centres so that
+    // consecutive planes are neighbours in space; groups of NK_GROUP_PLANES then have tight bounding boxes.
+    const bool grouped = !(m->F <= NK_LDS_FACES && m->Fc <= NK_LDS_FACES);
+    if (grouped) {
+        std::vector<uint64_t> key(members.size());
+        double ext[3];
+        for (int k = 0; k < 3; ++k) ext[k] = std::max(m->bbox[3 + k] - m->bbox[k], 1e-300);
+        for (size_t pl = 0; pl < members.size(); ++pl) {
+            double c[3] = {0, 0, 0};
+            for (int f : members[pl]) for (int k = 0; k < 3; ++k) c[k] += 0.5 * (m->bounds_lo[3 * f + k] + m->bounds_hi[3 * f + k]);
+            uint64_t code = 0;
+            uint32_t q[3];
+            for (int k = 0; k < 3; ++k) {
+                double u = (c[k] / members[pl].size() - m->bbox[k]) / ext[k];
+                u = u < 0 ? 0 : (u > 1 ? 1 : u);
+                q[k] = (uint32_t)(u * 1023.0);
+            }
+            for (int b = 9; b >= 0; --b) for (int k = 0; k < 3; ++k) code = (code << 1) | ((q[k] >> b) & 1u);
+            key[pl] = code;
+        }
+        std::vector<size_t> order(members.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
+        std::vector<std::vector<int>> sorted;
+        for (size_t i : order) sorted.push_back(members[i]);
+        members.swap(sorted);
+    }
     std::vector<double> planes((size_t)d.NP * NK_PLANE_DOUBLES, 0.0), faces((size_t)m->F * NK_FACE_DOUBLES, 0.0);
     int pos = 0;
     for (int pl = 0; pl < d.NP; ++pl) {
@@ -264,6 +291,29 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
             memcpy(q + 15, id, 8);
             ++pos;
         }
+    }
+    d.NG = 0;
+    if (grouped) {
+        // group boxes: union of the member faces' boxes, inflated by far more than any rounding in the slab test
+        double big = 0.0;
+        for (int k = 0; k < 6; ++k) big = std::max(big, fabs(m->bbox[k]));
+        const double margin = m->tol + 1e-6 * (1.0 + big);
+        d.NG = (d.NP + NK_GROUP_PLANES - 1) / NK_GROUP_PLANES;
+        std::vector<double> groups((size_t)d.NG * NK_GROUP_DOUBLES, 0.0);
+        for (int g = 0; g < d.NG; ++g) {
+            double *G = &groups[(size_t)g * NK_GROUP_DOUBLES];
+            const int p0 = g * NK_GROUP_PLANES, p1 = std::min(d.NP, p0 + NK_GROUP_PLANES);
+            for (int k = 0; k < 3; ++k) { G[k] = 1e300; G[3 + k] = -1e300; }
+            for (int pl = p0; pl < p1; ++pl)
+                for (int f : members[pl])
+                    for (int k = 0; k < 3; ++k) {
+                        G[k] = std::min(G[k], m->bounds_lo[3 * f + k] - margin);
+                        G[3 + k] = std::max(G[3 + k], m->bounds_hi[3 * f + k] + margin);
+                    }
+            int32_t rng[2] = {p0, p1};
+            memcpy(G + 6, rng, 8);
+        }
+        NK_UP(groups.data(), groups.size(), &d.pgroups);
     }
     NK_UP(planes.data(), planes.size(), &d.planes);
     NK_UP(faces.data(), faces.size(), &d.faces);
@@ -593,8 +643,13 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
     for (void *p : ctx->pallocs) hipFree(p);
     ctx->pallocs.clear();
     // segments: load-balance granularity of the persistent sweep (a few tiles of 256 each)
-    int64_t nseg = capacity / 2048;
-    nseg = nseg < 64 ? 64 : (nseg > 8192 ? 8192 : nseg);
+    // about four segments per resident wave (3072 waves on 256 CUs), each between 512 and 2048 slots
+    int64_t per_wave = 4;
+    if (const char *e = getenv("NK_SEG_PER_WAVE")) per_wave = atoi(e) > 0 ? atoi(e) : 4;      // developer probe
+    int64_t target = capacity / (per_wave * 3072);
+    target = target < 512 ? 512 : (target > 2048 ? 2048 : target);
+    int64_t nseg = capacity / target;
+    nseg = nseg < 64 ? 64 : (nseg > NK_MAX_SEGMENTS ? NK_MAX_SEGMENTS : nseg);
     int64_t segcap = (capacity + nseg - 1) / nseg;
     segcap = ((segcap + 63) / 64) * 64;
     d.nseg = (int32_t)nseg;

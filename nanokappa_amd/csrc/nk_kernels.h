@@ -174,6 +174,13 @@ __device__ __forceinline__ void nk_sample_res_face(const int *off, const double 
     z0 = a0 * fv[2] + a1 * fv[5] + a2 * fv[8];
 }
 
+// Ray cast as the kernels call it: grouped sweep for meshes whose tables stay in global memory, plain sweep over LDS.
+#define NK_RAY(GEOM, d, L, x, y, z, vx, vy, vz, tc, fc)                                                              \
+    do {                                                                                                              \
+        if ((GEOM) == 2 && (d).NG > 0) nk_find_boundary_grouped((d).pgroups, (d).NG, (L).planes, (L).faces, (d).tol, x, y, z, vx, vy, vz, tc, fc); \
+        else nk_find_boundary((L).planes, (L).faces, (d).NP, (d).tol, x, y, z, vx, vy, vz, tc, fc);                   \
+    } while (0)
+
 // ========================================================================================= kernels
 // Which modes enter at each reservoir at `step`, and how many particles of each: fill_reservoirs 'constant'
 // (Population.py:358-370) / 'fixed_rate' (:408-420) for one (reservoir, mode) entry.  c = particles entering,
@@ -431,7 +438,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w;
                     occ = nk_occupation(d, L.resT[r], omega);                        // Population.py:506
                     double tc;
-                    nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x0, y0, z0, vx, vy, vz, tc, facet);
+                    NK_RAY(GEOM, d, L, x0, y0, z0, vx, vy, vz, tc, facet);
                     nts = tc / d.dt - dt_in / d.dt;                                  // :535
                     x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;   // :536
                 }
@@ -483,7 +490,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     const double4 ra = first ? pre : *reinterpret_cast<const double4 *>(d.modetab + p.mode);
                     p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                     p.alive = true;
-                    st = nk_event_one<ROUGH>(d, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, cts, evc, ppid, step);
+                    st = nk_event_one<ROUGH>(d, d.pgroups, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, cts, evc, ppid, step);
                 }
                 first = false;
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
@@ -530,7 +537,7 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
     // the 0.1 K table step per timestep; the general search is the fallback), and the segment counts stay in registers.
     const int tid = threadIdx.x, nth = blockDim.x;
     const int S = d.S, NB = d.NB, n = d.nE;
-    constexpr int KMAX = 32;                                   // nseg <= 8192, nth = 256
+    constexpr int KMAX = NK_MAX_SEGMENTS / NK_WG;              // segments per thread of the update workgroup
     const int lane = tid & 63, wave = tid >> 6, nw = (nth + 63) >> 6;
     const int per = (d.nseg + nth - 1) / nth;                  // <= KMAX contiguous segments per thread
     int fr[KMAX];
@@ -677,7 +684,7 @@ __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
             const int64_t i = base + k;
             const NkMode *rec = d.modetab + d.mode[i];
             double tc; int fc;
-            nk_find_boundary(L.planes, L.faces, d.NP, d.tol, d.x[i], d.y[i], d.z[i], rec->vx, rec->vy, rec->vz, tc, fc);
+            NK_RAY(GEOM, d, L, d.x[i], d.y[i], d.z[i], rec->vx, rec->vy, rec->vz, tc, fc);
             d.nts[i] = tc / d.dt;
             d.facet[i] = fc;
         }
@@ -713,7 +720,7 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
             for (int q = 0; q < 4; ++q) { double wq = a[q] / asum; x += wq * sp[3 * q]; y += wq * sp[3 * q + 1]; z += wq * sp[3 * q + 2]; }
             const NkMode *rec = d.modetab + d.mode[i];
             double tc; int fc;
-            nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
+            NK_RAY(GEOM, d, L, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
             d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = tc / d.dt; d.facet[i] = fc;
         }
     }
@@ -743,8 +750,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n,
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
     double t; int f;
-    nk_find_boundary(L.planes, L.faces, d.NP, d.tol, x[3 * i], x[3 * i + 1], x[3 * i + 2], v[3 * i], v[3 * i + 1],
-                     v[3 * i + 2], t, f);
+    NK_RAY(GEOM, d, L, x[3 * i], x[3 * i + 1], x[3 * i + 2], v[3 * i], v[3 * i + 1], v[3 * i + 2], t, f);
     tc[i] = t; fc[i] = f;
     for (int k = 0; k < 3; ++k) xc[3 * i + k] = x[3 * i + k] + t * v[3 * i + k];
 }

@@ -36,6 +36,43 @@ def test_find_boundary(name):
     assert np.allclose(xc[hit], g['ray_xc'][hit], rtol=1e-12, atol=1e-9)
 
 
+def test_find_boundary_large_mesh_grouped():
+    """1600-face wire: the tables stay in global memory and the ray caster visits bounding-box groups of planes.
+    Must equal the plain all-faces evaluation (this package's NumPy Mesh.find_boundary, itself checked against the
+    reference goldens in test_host_geometry) ray by ray, including rays that start outside or run along an axis."""
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.engine import Engine
+    argv = ['--geometry', 'cylinder', '--dimensions', '2000', '200', '400', '--subvolumes', 'slice', '20', '2',
+            '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+            '--bound_values', '302', '298', '5'] + COMMON_ARGS
+    args = initialise_parser().parse_args(argv)
+    args.results_folder = ''
+    geo = Geometry(args)
+    assert geo.mesh.n_of_faces == 1600
+    ph = golden_phonon()
+    eng = Engine(0, 1)
+    eng.set_material(ph.tables())
+    eng.set_mesh(geo.tables())
+    eng.set_subvolumes(geo.subvol_center, geo.subvol_volume, 0, geo.slice_axis, 1, np.full(geo.n_of_subvols, 300.0))
+    rng = np.random.default_rng(5)
+    n = 3000
+    b = geo.mesh.bounds
+    x = geo.mesh.sample_volume(n, rng)
+    v = rng.normal(size=(n, 3)) * 40.0
+    v[:50, :2] = 0.0                                          # along the wire axis
+    v[50:100, 2] = 0.0                                        # in the cross-section
+    x[100:150] = b[1] + 7.0                                   # outside: mostly misses
+    x[150:200, 2] = b[0, 2]                                   # on an end cap
+    xr, tr, fr = geo.mesh.find_boundary(x.copy(), v.copy())
+    xc, tc, fc = eng.find_boundary(x, v)
+    assert np.array_equal(fc, fr)
+    hit = fr >= 0
+    assert hit.sum() > 2500
+    assert rel_err(tc[hit], tr[hit]) < 1e-12
+    assert np.all(np.isinf(tc[~hit]))
+
+
 @pytest.mark.parametrize('name', ['box200', 'box5000', 'cyl'])
 def test_classifier(name):
     eng, g, ph = base_engine(name)
