@@ -200,6 +200,16 @@ int nk_uniform2(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double
  * the access shape of the step kernel, so that rocprofv3 FETCH_SIZE / WRITE_SIZE readings can be calibrated */
 int nk_calibrate_stream(nk_ctx *ctx, int32_t launches, int64_t *bytes_read, int64_t *bytes_written);
 
+/* Set-up table builder: find_specular_correspondences, 'velocity' model
+ * (Population.py:1241-1454) for one surface normal.  group_vel [M*3], omega [M], delta_omega [M] (the grid tolerance
+ * of :1245-1247) are uploaded by nk_specular_begin; nk_specular_pairs returns every (in-mode, out-mode) pair of flat
+ * mode indices, unordered, for the (rounded, inward) normal; *n_pairs receives the count (call again with a larger
+ * `cap` when it exceeds it). */
+int nk_specular_begin(nk_ctx *ctx, int64_t M, const double *group_vel, const double *omega, const double *delta_omega);
+int nk_specular_pairs(nk_ctx *ctx, const double *normal /* [3] */, double crit, int64_t cap, int32_t *pair_in,
+                      int32_t *pair_out, int64_t *n_pairs);
+int nk_specular_end(nk_ctx *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -38,6 +38,13 @@ struct nk_ctx {
     int g_sweep = 0;               // persistent grid of k_sweep = rows of `partials`
     std::vector<int32_t> h_seg_count;
     std::vector<hipEvent_t> evpool;
+    // set-up table builder state (nk_specular_*)
+    int64_t spec_M = 0;
+    double *spec_v = nullptr, *spec_om = nullptr, *spec_dl = nullptr;
+    NkSpecMode *spec_modes = nullptr;
+    int32_t *spec_in = nullptr, *spec_out = nullptr;
+    unsigned long long *spec_count = nullptr;
+    int64_t spec_cap = 0;
     bool spawn_ready = false;         // spawn_list[step & 1] already holds the particles entering at the next step
     double *acc = nullptr;         // [NB]
     double *hist = nullptr;        // [hist_cap][HROW]
@@ -180,12 +187,16 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     return NK_OK;
 }
 
+static void nk_specular_free(nk_ctx *ctx);
+static inline void nk_specular_free_fwd(nk_ctx *ctx) { nk_specular_free(ctx); }
+
 void nk_destroy(nk_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     if (ctx->comm && ctx->rccl.CommDestroy) ctx->rccl.CommDestroy(ctx->comm);
     for (auto &e : ctx->evpool) hipEventDestroy(e);
+    nk_specular_free_fwd(ctx);
     for (void *p : ctx->allocs) hipFree(p);
     for (void *p : ctx->pallocs) hipFree(p);
     if (ctx->acc) hipFree(ctx->acc);
@@ -1045,3 +1056,67 @@ int nk_uniform2(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double
 }
 
 }  // extern "C"
+
+
+// ------------------------------------------------------------------------------ set-up table builder
+static void nk_specular_free(nk_ctx *ctx) {
+    for (void *p : {(void *)ctx->spec_v, (void *)ctx->spec_om, (void *)ctx->spec_dl, (void *)ctx->spec_modes,
+                    (void *)ctx->spec_in, (void *)ctx->spec_out, (void *)ctx->spec_count})
+        if (p) hipFree(p);
+    ctx->spec_v = ctx->spec_om = ctx->spec_dl = nullptr;
+    ctx->spec_modes = nullptr; ctx->spec_in = ctx->spec_out = nullptr; ctx->spec_count = nullptr;
+    ctx->spec_M = 0; ctx->spec_cap = 0;
+}
+int nk_specular_begin(nk_ctx *ctx, int64_t M, const double *group_vel, const double *omega, const double *delta_omega) {
+    NK_ARG(ctx && M > 0 && M < (1ll << 31) && group_vel && omega && delta_omega, "nk_specular_begin: bad arguments");
+    NK_HIP(hipSetDevice(ctx->device));
+    nk_specular_free(ctx);
+    NK_HIP(hipMalloc((void **)&ctx->spec_v, (size_t)M * 24));
+    NK_HIP(hipMalloc((void **)&ctx->spec_om, (size_t)M * 8));
+    NK_HIP(hipMalloc((void **)&ctx->spec_dl, (size_t)M * 8));
+    NK_HIP(hipMalloc((void **)&ctx->spec_modes, (size_t)M * sizeof(NkSpecMode)));
+    NK_HIP(hipMalloc((void **)&ctx->spec_count, 8));
+    NK_HIP(hipMemcpy(ctx->spec_v, group_vel, (size_t)M * 24, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ctx->spec_om, omega, (size_t)M * 8, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ctx->spec_dl, delta_omega, (size_t)M * 8, hipMemcpyHostToDevice));
+    ctx->spec_M = M;
+    return NK_OK;
+}
+int nk_specular_pairs(nk_ctx *ctx, const double *normal, double crit, int64_t cap, int32_t *pair_in, int32_t *pair_out,
+                      int64_t *n_pairs) {
+    NK_ARG(ctx && normal && n_pairs && cap >= 0 && (cap == 0 || (pair_in && pair_out)), "nk_specular_pairs: bad arguments");
+    NK_ARG(ctx->spec_M > 0, "nk_specular_pairs: call nk_specular_begin first");
+    NK_HIP(hipSetDevice(ctx->device));
+    const int M = (int)ctx->spec_M;
+    if (cap > ctx->spec_cap) {
+        if (ctx->spec_in) hipFree(ctx->spec_in);
+        if (ctx->spec_out) hipFree(ctx->spec_out);
+        ctx->spec_in = ctx->spec_out = nullptr;
+        NK_HIP(hipMalloc((void **)&ctx->spec_in, (size_t)cap * 4));
+        NK_HIP(hipMalloc((void **)&ctx->spec_out, (size_t)cap * 4));
+        ctx->spec_cap = cap;
+    }
+    const int blocks = (M + NK_WG - 1) / NK_WG;
+    NK_HIP(hipMemsetAsync(ctx->spec_count, 0, 8, ctx->stream));
+    k_specular_prepare<<<blocks, NK_WG, 0, ctx->stream>>>(M, ctx->spec_v, ctx->spec_om, ctx->spec_dl, normal[0], normal[1],
+                                                          normal[2], ctx->spec_modes);
+    k_specular_pairs<<<blocks, NK_WG, 0, ctx->stream>>>(M, ctx->spec_modes, normal[0], normal[1], normal[2], crit, cap,
+                                                        ctx->spec_in, ctx->spec_out, ctx->spec_count);
+    NK_HIP(hipGetLastError());
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long n = 0;
+    NK_HIP(hipMemcpy(&n, ctx->spec_count, 8, hipMemcpyDeviceToHost));
+    *n_pairs = (int64_t)n;
+    const int64_t got = (int64_t)n < cap ? (int64_t)n : cap;
+    if (got > 0) {
+        NK_HIP(hipMemcpy(pair_in, ctx->spec_in, (size_t)got * 4, hipMemcpyDeviceToHost));
+        NK_HIP(hipMemcpy(pair_out, ctx->spec_out, (size_t)got * 4, hipMemcpyDeviceToHost));
+    }
+    return NK_OK;
+}
+int nk_specular_end(nk_ctx *ctx) {
+    NK_ARG(ctx, "nk_specular_end: NULL context");
+    NK_HIP(hipSetDevice(ctx->device));
+    nk_specular_free(ctx);
+    return NK_OK;
+}

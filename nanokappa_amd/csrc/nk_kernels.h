@@ -802,3 +802,64 @@ __global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32
     nk_uniform2_dev(seed, pid, step, tag, a, b);
     out[0] = a; out[1] = b;
 }
+
+
+// ============================================================================ set-up tables
+// find_specular_correspondences, 'velocity' model (Population.py:1241-1454), for ONE surface normal: all pairs
+// (in-mode, out-mode) whose mirrored group velocity and frequency agree within the grid tolerance.  The reference
+// walks the in-modes in Python (minutes at 31^3 q-points, per normal); here every in-mode is a thread that sweeps the
+// out-modes through LDS tiles.  The arithmetic is the reference's, operation by operation and without fused
+// multiply-adds, because the pair set depends on roundings (the angle test rejects a pair when the dot product of two
+// unit vectors rounds above 1: arccos -> NaN -> pi, :1357-1369).
+struct NkSpecMode { double vx, vy, vz, nrm, om, dl, vdn, pad; };     // 64 bytes per mode
+__global__ __launch_bounds__(NK_WG) void k_specular_prepare(int M, const double *v, const double *omega, const double *delta,
+                                                            double nx, double ny, double nz, NkSpecMode *out) {
+#pragma clang fp contract(off)
+    const int m = blockIdx.x * NK_WG + threadIdx.x;
+    if (m >= M) return;
+    NkSpecMode r;
+    r.vx = v[3 * m]; r.vy = v[3 * m + 1]; r.vz = v[3 * m + 2];
+    r.vdn = (r.vx * nx + r.vy * ny) + r.vz * nz;                       // np.sum(v * n, axis=2)
+    r.nrm = sqrt((r.vx * r.vx + r.vy * r.vy) + r.vz * r.vz);           // np.linalg.norm(v_out, axis=1)
+    r.om = omega[m]; r.dl = delta[m]; r.pad = 0.0;
+    out[m] = r;
+}
+__global__ __launch_bounds__(NK_WG) void k_specular_pairs(int M, const NkSpecMode *modes, double nx, double ny, double nz,
+                                                          double crit, int64_t cap, int32_t *pin, int32_t *pout,
+                                                          unsigned long long *count) {
+#pragma clang fp contract(off)
+    __shared__ NkSpecMode tile[NK_WG];
+    const int a = blockIdx.x * NK_WG + threadIdx.x;
+    NkSpecMode me = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (a < M) me = modes[a];
+    const bool is_in = a < M && me.vdn < 0.0;
+    // mirrored velocity and its norm (v_ref = v_in - 2 n (v_in . n)), unit in-velocity mirrored the same way
+    const double t2x = 2.0 * nx, t2y = 2.0 * ny, t2z = 2.0 * nz;
+    const double rx = me.vx - t2x * me.vdn, ry = me.vy - t2y * me.vdn, rz = me.vz - t2z * me.vdn;
+    const double nrm_in = sqrt((rx * rx + ry * ry) + rz * rz);
+    const double vn = sqrt((me.vx * me.vx + me.vy * me.vy) + me.vz * me.vz);
+    const double ux = me.vx / vn, uy = me.vy / vn, uz = me.vz / vn;
+    const double udn = (ux * nx + uy * ny) + uz * nz;
+    const double tx = ux - t2x * udn, ty = uy - t2y * udn, tz = uz - t2z * udn;
+    for (int b0 = 0; b0 < M; b0 += NK_WG) {
+        __syncthreads();
+        if (b0 + (int)threadIdx.x < M) tile[threadIdx.x] = modes[b0 + threadIdx.x];
+        __syncthreads();
+        const int nb = M - b0 < NK_WG ? M - b0 : NK_WG;
+        if (!is_in) continue;
+        for (int k = 0; k < nb; ++k) {
+            const NkSpecMode &o = tile[k];
+            if (!(o.vdn > 0.0)) continue;
+            const double ref = fmax(nrm_in, o.nrm);
+            if (!(fabs(rx - o.vx) / ref < crit)) continue;
+            if (!(fabs(ry - o.vy) / ref < crit) || !(fabs(rz - o.vz) / ref < crit)) continue;
+            if (!(fabs(me.om - o.om) < me.dl + o.dl)) continue;
+            const double ox = o.vx / o.nrm, oy = o.vy / o.nrm, oz = o.vz / o.nrm;
+            const double dot = (tx * ox + ty * oy) + tz * oz;
+            const double ang = acos(dot);                               // NaN (dot rounded above 1) rejects the pair
+            if (!(ang < crit)) continue;
+            const unsigned long long at = atomicAdd(count, 1ull);
+            if ((int64_t)at < cap) { pin[at] = a; pout[at] = b0 + k; }
+        }
+    }
+}

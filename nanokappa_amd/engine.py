@@ -75,7 +75,8 @@ EXPORTS = ['nk_create', 'nk_destroy', 'nk_last_error', 'nk_set_material', 'nk_se
            'nk_set_reservoirs', 'nk_set_rough', 'nk_set_params', 'nk_reserve', 'nk_upload_particles',
            'nk_init_boundaries', 'nk_step', 'nk_download_particles', 'nk_get_subvol_temperature',
            'nk_set_subvol_temperature', 'nk_get_step', 'nk_get_timing', 'nk_comm_unique_id', 'nk_comm_init',
-           'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2', 'nk_calibrate_stream']
+           'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2', 'nk_calibrate_stream',
+           'nk_specular_begin', 'nk_specular_pairs', 'nk_specular_end']
 
 _lib = None
 
@@ -116,6 +117,9 @@ def load_library():
     L.nk_reflect.argtypes = [C.c_void_p, C.c_int64, c_ip, c_ip, c_dp, c_dp, c_dp, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp]
     L.nk_uniform2.argtypes = [C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, c_dp, c_dp]
     L.nk_calibrate_stream.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    L.nk_specular_begin.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp]
+    L.nk_specular_pairs.argtypes = [C.c_void_p, c_dp, C.c_double, C.c_int64, c_ip, c_ip, C.POINTER(C.c_int64)]
+    L.nk_specular_end.argtypes = [C.c_void_p]
     _lib = L
     return L
 
@@ -334,6 +338,28 @@ class Engine(object):
         return dict(step_kernel_ms=t.step_kernel_ms, emit_kernel_ms=t.emit_kernel_ms, events_kernel_ms=t.events_kernel_ms,
                     total_ms=t.total_ms,
                     slots=int(t.slots), live=int(t.live))
+
+    # ---- set-up table builder (find_specular_correspondences 'velocity', Population.py:1241-1454)
+    def specular_begin(self, group_vel, omega, delta_omega):
+        v, om, dl = _d(np.asarray(group_vel).reshape(-1, 3)), _d(np.ravel(omega)), _d(np.ravel(delta_omega))
+        self._ck(self.L.nk_specular_begin(self.h, om.shape[0], _p(v), _p(om), _p(dl)), 'nk_specular_begin')
+        self._spec_M = om.shape[0]
+
+    def specular_pairs(self, normal, crit=1e-3):
+        """(in, out) flat mode indices of every specular pair for one normal, unordered."""
+        nrm = _d(np.asarray(normal, dtype=float))
+        cap = 4 * self._spec_M
+        while True:
+            pi, po = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
+            n = C.c_int64(0)
+            self._ck(self.L.nk_specular_pairs(self.h, _p(nrm), float(crit), cap, _p(pi, c_ip), _p(po, c_ip), C.byref(n)),
+                     'nk_specular_pairs')
+            if n.value <= cap:
+                return pi[:n.value].astype(np.int64), po[:n.value].astype(np.int64)
+            cap = int(n.value)
+
+    def specular_end(self):
+        self._ck(self.L.nk_specular_end(self.h), 'nk_specular_end')
 
     def calibrate_stream(self, launches=3):
         """Known-traffic sweeps for counter calibration; returns (bytes_read, bytes_written) per launch."""

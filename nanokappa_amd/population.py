@@ -114,6 +114,9 @@ class Population(Constants):
         self.seed = int(getattr(args, 'seed', [0])[0])
         self.rng = np.random.default_rng(self.seed)
 
+        # ---- device engine (created first: the specular-pair search of the set-up tables already runs on it)
+        self.engine = engine if engine is not None else Engine(int(getattr(args, 'device', [0])[0]), self.seed)
+
         print('Calculating diffuse scattering probabilities...')
         self._build_rough_tables(geometry, phonon)
 
@@ -136,8 +139,6 @@ class Population(Constants):
         self.prng = np.random.default_rng([self.seed, 7919, self.rank])
         pos, modes, occ = self.initialise_all_particles(geometry, phonon)
 
-        # ---- device engine
-        self.engine = engine if engine is not None else Engine(int(getattr(args, 'device', [0])[0]), self.seed)
         self._configure_engine(geometry, phonon)
         if comm is not None and self.nranks > 1:
             self.engine.comm_init(comm[0], self.rank, self.nranks)
@@ -186,7 +187,8 @@ class Population(Constants):
         if self.k_model:
             self.correspondent_modes, self.true_specular = ST.specular_correspondences_k(geometry, phonon, self.rough_facets)
         elif self.scat_model in ('v', 'vel', 'velocity', 'groupvel', 'group_vel'):
-            self.correspondent_modes, self.true_specular = ST.specular_correspondences_velocity(geometry, phonon, self.rough_facets)
+            self.correspondent_modes, self.true_specular = ST.specular_correspondences_velocity(
+                geometry, phonon, self.rough_facets, engine=self.engine)        # pair search on the GPU
         else:
             raise Exception('Invalid --bound_scat')
         self.specularity = self.true_specular.astype(int) * spec0                  # Population.py:1459

@@ -52,10 +52,14 @@ def find_degeneracies(phonon):
     return deg, idx
 
 
-def specular_correspondences_velocity(geometry, phonon, rough_facets, crit=1e-3, keep_nan_pairs=False):
+def specular_correspondences_velocity(geometry, phonon, rough_facets, crit=1e-3, keep_nan_pairs=False, engine=None):
     """Pairs (in-mode -> out-mode) whose mirrored group velocity and frequency agree within the grid tolerance.
 
     Returns (correspondent_modes (K,7): n(3) q_in j_in q_out j_out, true_spec (Fr,Q,J) bool).
+
+    With `engine` (a nanokappa_amd.engine.Engine) the pair search of every normal runs on the GPU
+    (nk_specular_pairs: same arithmetic, same pair set); the NumPy path below is its CPU statement and the one the
+    reference goldens pin.
     """
     normals = -np.round(geometry.facets_normal[rough_facets, :], decimals=10)
     normals, inv_normals = np.unique(normals, axis=0, return_inverse=True)
@@ -66,12 +70,20 @@ def specular_correspondences_velocity(geometry, phonon, rough_facets, crit=1e-3,
     k_grid = phonon.q_to_k(np.absolute(1 / (2 * phonon.data_mesh)))
     delta_omega = np.sum((v * k_grid) ** 2, axis=2) ** 0.5
     rows = []
+    if engine is not None and not keep_nan_pairs:
+        engine.specular_begin(v.reshape(-1, 3), phonon.omega.ravel(), delta_omega.ravel())
     for i_n, n in enumerate(normals):
         vdn = np.sum(v * n, axis=2)
         in_modes = np.vstack(np.nonzero(vdn < 0)).T
         out_modes = np.vstack(np.nonzero(vdn > 0)).T
         v_in = v[in_modes[:, 0], in_modes[:, 1], :]
         v_ref = v_in - 2 * n * np.sum(v_in * n, axis=1, keepdims=True)
+        if engine is not None and not keep_nan_pairs:
+            gi, go = engine.specular_pairs(n, crit)
+            pi = np.searchsorted(in_modes[:, 0] * J + in_modes[:, 1], gi)        # positions in the in / out lists
+            po = np.searchsorted(out_modes[:, 0] * J + out_modes[:, 1], go)
+            rows.append(_corr_rows(n, pi, po, in_modes, out_modes, v_ref, true_spec, inv_normals, i_n))
+            continue
         v_out = v[out_modes[:, 0], out_modes[:, 1], :]
         nrm_in = np.linalg.norm(v_ref, axis=1)
         nrm_out = np.linalg.norm(v_out, axis=1)
@@ -111,18 +123,23 @@ def specular_correspondences_velocity(geometry, phonon, rough_facets, crit=1e-3,
                     cand = cand[ang < crit]
                     pi += [a] * cand.size
                     po += list(np.sort(cand))
-        pi = np.array(pi, dtype=int)
-        po = np.array(po, dtype=int)
-        # reference ordering: by sorted reflected-vx of the in-mode, then ascending out index within it
-        key = np.lexsort((po, np.argsort(np.argsort(v_ref[:, 0], kind='stable'))[pi])) if pi.size else np.zeros(0, dtype=int)
-        pi, po = pi[key], po[key]
-        im, om_ = in_modes[pi], out_modes[po]
-        facets_here = np.nonzero(inv_normals == i_n)[0]
-        for fct in facets_here:
-            true_spec[fct, im[:, 0], im[:, 1]] = True
-        rows.append(np.hstack((np.tile(n, (im.shape[0], 1)), im, om_)))
+        rows.append(_corr_rows(n, np.array(pi, dtype=int), np.array(po, dtype=int), in_modes, out_modes, v_ref, true_spec,
+                               inv_normals, i_n))
+    if engine is not None and not keep_nan_pairs:
+        engine.specular_end()
     corr = np.vstack(rows) if rows else np.zeros((0, 7))
     return corr, true_spec
+
+
+def _corr_rows(n, pi, po, in_modes, out_modes, v_ref, true_spec, inv_normals, i_n):
+    """Rows of correspondent_modes for one normal in the reference's order (by sorted reflected-vx of the in-mode, then
+    ascending out index within it) and the true_specular mask of the facets that share the normal."""
+    key = np.lexsort((po, np.argsort(np.argsort(v_ref[:, 0], kind='stable'))[pi])) if pi.size else np.zeros(0, dtype=int)
+    pi, po = pi[key], po[key]
+    im, om_ = in_modes[pi], out_modes[po]
+    for fct in np.nonzero(inv_normals == i_n)[0]:
+        true_spec[fct, im[:, 0], im[:, 1]] = True
+    return np.hstack((np.tile(n, (im.shape[0], 1)), im, om_))
 
 
 def specular_correspondences_k(geometry, phonon, rough_facets):

@@ -305,6 +305,36 @@ def test_grid_subvolumes_vs_oracle():
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
+def test_specular_pairs_on_device_equal_host_builder():
+    """nk_specular_pairs (find_specular_correspondences 'velocity', Population.py:1241-1454, one thread per in-mode)
+    returns exactly the pair set of the NumPy builder, which test_host_geometry pins to the reference's goldens --
+    including the pairs the reference loses to arccos(>1) = NaN."""
+    import ref_harness_args as A
+    from nanokappa_amd import setup_tables as ST
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.engine import Engine
+    args = initialise_parser().parse_args(A.argv_for('ttrrp', 20000))
+    args.results_folder = ''
+    geo = Geometry(args)
+    ph = golden_phonon()
+    corr_h, ts_h = ST.specular_correspondences_velocity(geo, ph, geo.rough_facets)
+    eng = Engine(0, 1)
+    corr_d, ts_d = ST.specular_correspondences_velocity(geo, ph, geo.rough_facets, engine=eng)
+    assert corr_h.shape[0] > 1000
+    assert np.array_equal(ts_h, ts_d)
+    assert np.array_equal(corr_h, corr_d)
+    g = sub(golden('setup'), 'velocity')
+    assert np.array_equal(ts_d, g['true_specular'])
+    # a tilted normal (no symmetry with the q-mesh axes)
+    class G2(object):
+        facets_normal = np.array([[0.6, 0.64, 0.48]])
+    a, ta = ST.specular_correspondences_velocity(G2, ph, np.array([0]))
+    b, tb = ST.specular_correspondences_velocity(G2, ph, np.array([0]), engine=eng)
+    assert np.array_equal(a, b) and np.array_equal(ta, tb)
+    eng.close()
+
+
 def test_reserve_mid_run_preserves_state():
     """nk_reserve between steps re-lays the particle store out (new segment count, mode-sorted): the deferred
     relaxation and the prepared emission of the next step must survive, i.e. the run continues exactly like the oracle."""
