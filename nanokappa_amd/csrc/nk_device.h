@@ -60,7 +60,7 @@ struct NkDev {
     double active_modes;
     // ---- mesh
     int32_t F, Fc, NP;                // faces, facets, distinct planes
-    const double *pgroups;            // [NG*NK_GROUP_DOUBLES] plane groups with bounding boxes (large meshes), or NG = 0
+    const double *pgroups;            // [(NG+NS)*NK_GROUP_DOUBLES] plane groups, then super-groups, with bounding boxes (large meshes); or NG = 0
     int32_t NG;
     const double *planes;             // [NP*NK_PLANE_DOUBLES]
     const double *faces;              // [F*NK_FACE_DOUBLES], grouped by plane
@@ -379,26 +379,39 @@ __device__ __forceinline__ void nk_find_boundary(const double *planes, const dou
 // (ties still go to the lowest face index, whatever the visiting order).
 #define NK_GROUP_PLANES 16
 #define NK_GROUP_DOUBLES 8       // lo(3) hi(3) {plane_begin, plane_end} pad
+#define NK_SUPER_GROUPS 8
+// Does the ray x + t v, 0 <= t <= tmax, cross the box record B = lo.x lo.y | lo.z hi.x | hi.y hi.z ?  (inv = 1 / v)
+__device__ __forceinline__ bool nk_ray_box(const double2 b0, const double2 b1, const double2 b2, double x, double y, double z,
+                                           double vx, double vy, double vz, double ix, double iy, double iz, double tmax) {
+    double t0 = 0.0, t1 = tmax;
+    bool miss = false;
+    if (vx != 0.0) { const double a = (b0.x - x) * ix, b = (b1.y - x) * ix; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
+    else miss |= (x < b0.x) | (x > b1.y);
+    if (vy != 0.0) { const double a = (b0.y - y) * iy, b = (b2.x - y) * iy; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
+    else miss |= (y < b0.y) | (y > b2.x);
+    if (vz != 0.0) { const double a = (b1.x - z) * iz, b = (b2.y - z) * iz; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
+    else miss |= (z < b1.x) | (z > b2.y);
+    return !miss && t0 <= t1;
+}
+// Two levels: super-groups of NK_SUPER_GROUPS groups, then the groups, then their planes.  `groups` holds the NG group
+// records followed by the NS super-group records (same layout, the range then counts groups).
 __device__ __forceinline__ void nk_find_boundary_grouped(const double *groups, int NG, const double *planes,
                                                          const double *faces, double tol, double x, double y, double z,
                                                          double vx, double vy, double vz, double &tc, int &fc) {
     NkHit h = {__builtin_inf(), 0x7fffffff, -1};
-    const double ix = 1.0 / vx, iy = 1.0 / vy, iz = 1.0 / vz;         // +-inf for an axis-parallel ray: handled below
-    for (int g = 0; g < NG; ++g) {
-        const double2 *B = reinterpret_cast<const double2 *>(groups + g * NK_GROUP_DOUBLES);
-        const double2 b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3];    // lo.x lo.y | lo.z hi.x | hi.y hi.z | range pad
-        double t0 = 0.0, t1 = h.t;                                   // the part of the ray that can still matter
-        bool miss = false;
-        {
-            if (vx != 0.0) { const double a = (b0.x - x) * ix, b = (b1.y - x) * ix; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
-            else miss |= (x < b0.x) | (x > b1.y);
-            if (vy != 0.0) { const double a = (b0.y - y) * iy, b = (b2.x - y) * iy; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
-            else miss |= (y < b0.y) | (y > b2.x);
-            if (vz != 0.0) { const double a = (b1.x - z) * iz, b = (b2.y - z) * iz; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
-            else miss |= (z < b1.x) | (z > b2.y);
+    const double ix = 1.0 / vx, iy = 1.0 / vy, iz = 1.0 / vz;         // +-inf for an axis-parallel ray: not used then
+    const int NS = (NG + NK_SUPER_GROUPS - 1) / NK_SUPER_GROUPS;
+    const double2 *SB = reinterpret_cast<const double2 *>(groups + (size_t)NG * NK_GROUP_DOUBLES);
+    for (int sg = 0; sg < NS; ++sg) {
+        const double2 s0 = SB[4 * sg], s1 = SB[4 * sg + 1], s2 = SB[4 * sg + 2], s3 = SB[4 * sg + 3];
+        if (!nk_ray_box(s0, s1, s2, x, y, z, vx, vy, vz, ix, iy, iz, h.t)) continue;
+        const int g0 = __double2loint(s3.x), g1 = __double2hiint(s3.x);
+        for (int g = g0; g < g1; ++g) {
+            const double2 *B = reinterpret_cast<const double2 *>(groups + (size_t)g * NK_GROUP_DOUBLES);
+            const double2 b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3];
+            if (!nk_ray_box(b0, b1, b2, x, y, z, vx, vy, vz, ix, iy, iz, h.t)) continue;
+            nk_fb_planes(planes, faces, __double2loint(b3.x), __double2hiint(b3.x), tol, x, y, z, vx, vy, vz, h);
         }
-        if (miss || !(t0 <= t1)) continue;
-        nk_fb_planes(planes, faces, __double2loint(b3.x), __double2hiint(b3.x), tol, x, y, z, vx, vy, vz, h);
     }
     tc = h.t;
     fc = h.facet;

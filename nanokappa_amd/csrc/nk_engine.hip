@@ -310,7 +310,8 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         for (int k = 0; k < 6; ++k) big = std::max(big, fabs(m->bbox[k]));
         const double margin = m->tol + 1e-6 * (1.0 + big);
         d.NG = (d.NP + NK_GROUP_PLANES - 1) / NK_GROUP_PLANES;
-        std::vector<double> groups((size_t)d.NG * NK_GROUP_DOUBLES, 0.0);
+        const int NS = (d.NG + NK_SUPER_GROUPS - 1) / NK_SUPER_GROUPS;
+        std::vector<double> groups((size_t)(d.NG + NS) * NK_GROUP_DOUBLES, 0.0);
         for (int g = 0; g < d.NG; ++g) {
             double *G = &groups[(size_t)g * NK_GROUP_DOUBLES];
             const int p0 = g * NK_GROUP_PLANES, p1 = std::min(d.NP, p0 + NK_GROUP_PLANES);
@@ -323,6 +324,17 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
                     }
             int32_t rng[2] = {p0, p1};
             memcpy(G + 6, rng, 8);
+        }
+        for (int sg = 0; sg < NS; ++sg) {                   // super-groups: unions of NK_SUPER_GROUPS consecutive groups
+            double *SG = &groups[(size_t)(d.NG + sg) * NK_GROUP_DOUBLES];
+            const int g0 = sg * NK_SUPER_GROUPS, g1 = std::min(d.NG, g0 + NK_SUPER_GROUPS);
+            for (int k = 0; k < 3; ++k) { SG[k] = 1e300; SG[3 + k] = -1e300; }
+            for (int g = g0; g < g1; ++g) {
+                const double *G = &groups[(size_t)g * NK_GROUP_DOUBLES];
+                for (int k = 0; k < 3; ++k) { SG[k] = std::min(SG[k], G[k]); SG[3 + k] = std::max(SG[3 + k], G[3 + k]); }
+            }
+            int32_t rng[2] = {g0, g1};
+            memcpy(SG + 6, rng, 8);
         }
         NK_UP(groups.data(), groups.size(), &d.pgroups);
     }

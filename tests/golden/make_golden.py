@@ -498,7 +498,7 @@ def gen_stats_one(case, seed):
 
 def gen_stats_merge():
     import glob
-    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332'):
+    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332', 'film'):
         files = sorted(glob.glob(os.path.join(HERE, '_stats_%s_[0-9]*.npz' % case)))
         if not files:
             continue

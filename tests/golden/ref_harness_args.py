@@ -14,6 +14,14 @@ BOX_TTRRP = ['--geometry', 'box', '--dimensions', '200', '200', '200',
              '--connect_pos', 'relative', '0.5', '-0.1', '0.5', '0.5', '1.1', '0.5',
              '--bound_values', '302', '298', '5', '5']
 
+# BASELINE config 3 in small: cross-plane film, 2000 A thick, 500 x 500 A periodic cell
+FILM_TTP = ['--geometry', 'box', '--dimensions', '2000', '500', '500',
+            '--subvolumes', 'slice', '20', '0',
+            '--bound_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5',
+            '--bound_cond', 'T', 'T', 'P',
+            '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
+            '--bound_values', '302', '298']
+
 COMMON = ['--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
           '--reference_temp', 'local', '--temp_dist', 'cold', '--temp_interp', 'linear',
           '--part_dist', 'random_subvol', '--timestep', '1', '--n_mean', '10',
@@ -22,6 +30,6 @@ COMMON = ['--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
 
 
 def argv_for(case, particles, iterations=1000, extra=()):
-    base = {'ttp': BOX_TTP, 'ttrrp': BOX_TTRRP}[case]
+    base = {'ttp': BOX_TTP, 'ttrrp': BOX_TTRRP, 'film': FILM_TTP}[case]
     return list(base) + list(COMMON) + ['--particles', 'total', str(particles),
                                         '--iterations', str(iterations)] + list(extra)

@@ -38,11 +38,11 @@ def window_stats(rows, lo=50):
     return T, phi, kap, Np
 
 
-STAT_CASES = {'ttp': ('ttp', []), 'ttrrp': ('ttrrp', []),
+STAT_CASES = {'ttp': ('ttp', []), 'ttrrp': ('ttrrp', []), 'film': ('film', []),
               'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one'])}      # same table as make_golden.CASE_EXTRA
 
 
-@pytest.mark.parametrize('case', ['ttp', 'ttrrp', 'ttp_o2o'])
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp', 'ttp_o2o', 'film'])
 def test_statistical_parity_with_reference(case, tmp_path):
     """Same configuration as the reference goldens (C1a / C1b of SURVEY 8d, 729 x 6 synthetic Si): per-subvolume
     temperature, heat flux, kappa and particle count, averaged over steps 500-1000, must lie within the
