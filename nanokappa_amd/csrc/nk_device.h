@@ -2,7 +2,7 @@
 //
 // One particle = one lane.  Particle state is SoA in HBM (x, y, z, occupation, time-to-boundary as doubles; mode and
 // next facet as int32; a 64-bit particle id that keys the counter-based RNG), split into `nseg` equal segments; a
-// segment holds its live particles contiguously from its start and is owned by one workgroup at a time.  Small
+// segment holds its live particles contiguously from its start and is owned by one wave at a time.  Small
 // read-only tables (planes, faces, facets, slice centres, subvolume temperatures), the tally bins and the per-workgroup
 // event buffer live in LDS; per-mode records (64 B: omega, group velocity and the four lifetime rows around the live
 // temperature range) are gathered through L2 (particles of one segment come in runs of neighbouring modes).

@@ -2,32 +2,34 @@
 //
 // Stream order of one timestep (reference Population.run_timestep, Population.py:1724-1769):
 //   [k_relax + k_contains every `contains_every` steps]            contains_check       :1712-1722
-//   k_emit_count  which modes enter at each reservoir, how many     fill_reservoirs      :356-455
-//   k_sweep       per segment: relax(previous step) -> drift -> boundary events -> tally -> compaction,
-//                 then the segment's share of the entering particles
+//   [k_emit_count / k_emit_one_to_one: only to prime a run, for very large (reservoir, mode) tables, or for the
+//    'one_to_one' generator]                                        fill_reservoirs      :356-489
+//   k_sweep       per segment (one wave): relax(previous step) -> drift -> boundary events -> tally -> compaction,
+//                 then the segment's share of the entering particles; in its tail the NEXT step's emission
 //                                                                   lifetime_scattering  :1701-1710 (deferred)
 //                                                                   drift                :790-795
 //                                                                   boundary_scattering  :1546-1683
 //                                                                   add_reservoir_particles :525-552
 //                                                                   calculate_energy     :704-717
-//   k_reduce      deterministic column sums of the per-workgroup tally rows
-//   (RCCL all-reduce of the tally vector when nranks > 1)
-//   k_update      normalisation, E -> T, history row                calculate_energy :719-728, refresh_temperatures :692
+//                                                                   fill_reservoirs      :356-455 (for step + 1)
+//   k_reduce      deterministic column sums of the per-workgroup tally rows; single rank: the last workgroup also
+//                 normalises, inverts E -> T and writes the history row    calculate_energy :719-728, refresh_temperatures :692
+//   (nranks > 1: RCCL all-reduce of the tally vector, then k_update does that part)
 //
 // Deferred relaxation: the reference relaxes occupations at the END of step k with the temperatures of step k.  Those
 // need the global tally of step k, so the relaxation is carried into the BEGINNING of the sweep of step k+1 (same
 // positions, same T_sv): one pass over the particles per step instead of two.  A pending relaxation is flushed by
 // k_relax before anything observes the particles (download, contains_check).
 //
-// Why one fused sweep (measured, profiles/r01_pmc_traffic.json): with a separate event kernel and free-slot reuse the
-// step kernel moved 2.8 GB per launch for 0.68 GB of algorithmic traffic -- random 64-B mode gathers (1.2 GB) and
-// line-granular write-backs of the scattered event kernel -- and ran AT the HBM roof (6.3 TB/s).  Here
-//   * a workgroup owns a segment and walks it tile by tile (256 particles, coalesced loads, next tile prefetched);
-//   * particles that meet a boundary inside the step (a third of them in a 20 nm box) are parked in an LDS buffer and
-//     processed 256 at a time by all lanes (no divergence against the streaming lanes, no second pass over HBM);
+// Why one fused sweep (measured, profiles/r01_c2_1e7_pmc_v2_uncalibrated.json): with a separate event kernel and
+// free-slot reuse the step kernel moved 2.8 GB per launch for 0.68 GB of algorithmic traffic -- random 64-B mode gathers
+// (1.2 GB) and line-granular write-backs of the scattered event kernel -- and ran AT the HBM roof (6.3 TB/s).  Here
+//   * a WAVE owns a segment and walks it tile by tile (64 particles, coalesced loads, next tile prefetched);
+//   * particles that meet a boundary inside the step (a third of them in a 20 nm box) are parked in the wave's slice of
+//     an LDS buffer and processed 64 at a time by all lanes, one event per pass (no divergence against the streaming
+//     lanes, no second trip through HBM); the few that meet another wall are parked again;
 //   * survivors are written back compacted IN PLACE (write cursor <= read cursor), absorbed particles simply vanish;
-//   * entering particles are appended to the segment in (reservoir, mode) order, so a segment is a few sorted runs of
-//     neighbouring modes and its mode gathers hit L1/L2 instead of the Infinity Cache.
+//   * entering particles are appended to the segment in whole tiles, in runs of (reservoir, mode) order.
 #pragma once
 #include "nk_device.h"
 
