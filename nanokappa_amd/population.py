@@ -50,8 +50,18 @@ class _Stats(object):
             self.mean_k, self.std_k = np.nanmean(kk), np.nanstd(kk)
         else:                                                   # per-connection conductivities, Visualisation.py:196-199
             ck = np.array([r['con_k'] for r in rows])
+            con = p._geo.subvol_connections
+            dirs = p._geo.subvol_con_vectors / np.linalg.norm(p._geo.subvol_con_vectors, axis=1, keepdims=True)
             with np.errstate(invalid='ignore'):
                 self.mean_con_k, self.std_con_k = np.nanmean(ck, axis=0), np.nanstd(ck, axis=0)
+                dT = T[:, con[:, 1]] - T[:, con[:, 0]]                                    # Visualisation.py:177-184
+                self.mean_con_dT, self.std_con_dT = np.nanmean(dT, axis=0), np.nanstd(dT, axis=0)
+                ph3 = phi.reshape(len(rows), -1, 3)
+                cphi = np.sum((ph3[:, con[:, 0], :] + ph3[:, con[:, 1], :]) / 2 * dirs[None], axis=2)
+                self.mean_con_phi, self.std_con_phi = np.nanmean(cphi, axis=0), np.nanstd(cphi, axis=0)
+            weak = np.absolute(self.mean_con_k) < self.std_con_k                          # Visualisation.py:209-212
+            self.mean_con_k = np.where(weak, np.nan, self.mean_con_k)
+            self.std_con_k = np.where(weak, np.nan, self.std_con_k)
 
 
 class Population(Constants):
@@ -623,6 +633,29 @@ class Population(Constants):
             np.savetxt(os.path.join(self.results_folder_name, 'subvolumes.txt'), data,
                        '%d, %.3e, %.3e, %.3e, %.3e, %.3f, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e',
                        delimiter=',', header=header)
+        elif self.current_timestep > 0 and hasattr(self.view, 'mean_con_k'):
+            # non-slice subvolumes: subvolumes.txt without kappa columns + subvol_connections.txt (Population.py:2117-2151)
+            v = self.view
+            S = self.n_of_subvols
+            header = ('subvols final state data \n' + 'Date and time: {}\n'.format(time) +
+                      'hdf file = {}, POSCAR file = {}\n'.format(self.args.hdf_file, self.args.poscar_file) +
+                      'subvol id, subvol position, subvol volume, T [K], sigma T [K], HF x [W/m^2], HF y [W/m^2], HF z [W/m^2], '
+                      'sigma HF x [W/m^2], sigma HF y [W/m^2], sigma HF z [W/m^2]')
+            data = np.hstack((np.arange(S).reshape(-1, 1), geometry.subvol_center, np.asarray(self.subvol_volume).reshape(-1, 1),
+                              v.mean_T.reshape(-1, 1), v.std_T.reshape(-1, 1), v.mean_sv_phi.reshape(-1, 3),
+                              v.std_sv_phi.reshape(-1, 3)))
+            np.savetxt(os.path.join(self.results_folder_name, 'subvolumes.txt'), data,
+                       '%d, %.3e, %.3e, %.3e, %.3e, %.3f, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e, %.3e', delimiter=',', header=header)
+            C_ = geometry.n_of_subvol_con
+            header = ('connections final state data \n' + 'Date and time: {}\n'.format(time) +
+                      'hdf file = {}, POSCAR file = {}\n'.format(self.args.hdf_file, self.args.poscar_file) +
+                      'connection id, sv 1, sv 2, con dx, con dy, con dz, dT [K], sigma dT [K], HF [W/m^2], sigma HF [W/m^2], '
+                      'kappa [W/m K], sigma kappa [W/m K]')
+            data = np.hstack((np.arange(C_).reshape(-1, 1), geometry.subvol_connections, geometry.subvol_con_vectors,
+                              v.mean_con_dT.reshape(-1, 1), v.std_con_dT.reshape(-1, 1), v.mean_con_phi.reshape(-1, 1),
+                              v.std_con_phi.reshape(-1, 1), v.mean_con_k.reshape(-1, 1), v.std_con_k.reshape(-1, 1)))
+            np.savetxt(os.path.join(self.results_folder_name, 'subvol_connections.txt'), data,
+                       '%d, %d, %d, %.3e, %.3e, %.3e, %.3f, %.3e, %.3e, %.3e, %.3e, %.3e', delimiter=',', header=header)
 
     def save_plot_real_time(self):
         """Called by the reference driver (nanokappa.py:105) but defined nowhere there; a no-op here."""

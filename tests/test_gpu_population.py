@@ -149,3 +149,32 @@ def test_statistical_parity_grid_subvolumes():
     b = np.nanmean(rows[:, lo:, k0:][:, :, along_x], axis=(1, 2))
     se = np.sqrt(a.var(ddof=1) / a.size + b.var(ddof=1) / b.size)
     assert abs(a.mean() - b.mean()) < 4 * se, (a, b)
+
+
+def test_outputs_written_grid(tmp_path):
+    """Non-slice final state: subvolumes.txt without kappa columns and subvol_connections.txt (Population.py:2117-2151)."""
+    import ref_harness_args as A
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.phonon import Phonon
+    from nanokappa_amd.population import Population
+    common = list(A.COMMON)
+    common[common.index('--temp_interp') + 1] = 'nearest'
+    argv = GRID_ARGV + common + ['--particles', 'total', '20000', '--iterations', '1000', '--seed', '5']
+    args = initialise_parser().parse_args(argv)
+    args.results_folder = str(tmp_path)
+    geo = Geometry(args)
+    ph = Phonon(args, 0, material=golden_material())
+    pop = Population(args, geo, ph)
+    pop.run(210, geo, ph)
+    pop.view.postprocess()
+    pop.write_final_state(geo)
+    sv = np.loadtxt(tmp_path / 'subvolumes.txt', delimiter=',')
+    con = np.loadtxt(tmp_path / 'subvol_connections.txt', delimiter=',')
+    assert sv.shape == (18, 13) and con.shape == (33, 12)
+    assert np.array_equal(con[:, 1:3].astype(int), geo.subvol_connections)
+    conv = open(tmp_path / 'convergence.txt').read().splitlines()
+    assert 'K Con   0-  1' in conv[0]
+    res = np.loadtxt(tmp_path / 'residue.txt')
+    assert res.shape[1] == 4 * 18 + 2 + 33
+    pop.engine.close()
