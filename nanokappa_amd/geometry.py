@@ -9,6 +9,9 @@ import numpy as np
 from .mesh import Mesh, read_stl
 
 
+VORONOI_MAX_SAMPLES = 1000000      # routines/subvolumes.py: n_s_max (tests lower it)
+
+
 class SubvolClassifier(object):
     """Nearest-centre classifier (Geometry.py:1198-1213).  Host copy for initialisation; the hot path classifies
     on the GPU."""
@@ -178,9 +181,11 @@ class Geometry(object):
         if self.subvol_type == 'grid':
             self._set_grid_subvolumes(grid)
             return
+        if self.subvol_type == 'voronoi':
+            self._set_voronoi_subvolumes(int(self.args.subvolumes[1]))
+            return
         if self.subvol_type != 'slice':
-            raise NotImplementedError("subvolume type %r: 'slice' and 'grid' are built (voronoi needs the reference's "
-                                      "random point relaxation, SURVEY 8f row 4)" % self.subvol_type)
+            raise Exception('Invalid subvolume type!')
         self.n_of_subvols = int(self.args.subvolumes[1])                                # Geometry.py:449-471
         self.slice_axis = int(self.args.subvolumes[2])
         ext = self.bounds[1] - self.bounds[0]
@@ -211,6 +216,35 @@ class Geometry(object):
         c = np.vstack(list(map(np.ravel, g))).T * ext + self.bounds[0, :]
         _, dist, _ = self.mesh.closest_face(c)
         c = c[dist > 0, :]                                                             # closest_point(...)[1] > 0
+        self.subvol_center = c[np.lexsort((c[:, 2], c[:, 1], c[:, 0]))]
+        self.n_of_subvols = self.subvol_center.shape[0]
+        self.get_subvol_connections()
+        self.subvol_classifier = SubvolClassifier(self.n_of_subvols, self.subvol_center)
+        self.subvol_volume = self.calculate_subvol_volume()
+
+    def _set_voronoi_subvolumes(self, n, seed=20231003):
+        """n reference points spread by Lloyd relaxation on Monte-Carlo samples of the solid (routines/subvolumes.py:
+        centres move to the centroid of the samples nearest to them; the sample set doubles every time the centres
+        stop moving, up to 1e6), then as Geometry.py:474-491.  The reference draws from numpy's global generator;
+        here the generator is seeded, so the same arguments always give the same subvolumes."""
+        from scipy.spatial import cKDTree
+        rng = np.random.default_rng(seed)
+        x_r = self.mesh.sample_volume(n, rng)
+        n_s, n_s_max, crit = 1000, VORONOI_MAX_SAMPLES, 1e-8
+        x_s = self.mesh.sample_volume(n_s, rng)
+        for _ in range(10000):
+            r = cKDTree(x_r).query(x_s)[1]
+            cnt = np.bincount(r, minlength=n)
+            new = np.vstack([np.bincount(r, weights=x_s[:, k], minlength=n) for k in range(3)]).T
+            new = np.where(cnt[:, None] > 0, new / np.maximum(cnt, 1)[:, None], x_r)
+            move = np.linalg.norm(new - x_r, axis=1).max()
+            x_r = new
+            if move < crit:
+                if n_s >= n_s_max:
+                    break
+                n_s = min(2 * n_s, n_s_max)
+                x_s = self.mesh.sample_volume(n_s, rng)
+        c = x_r[self.mesh.contains(x_r), :]
         self.subvol_center = c[np.lexsort((c[:, 2], c[:, 1], c[:, 0]))]
         self.n_of_subvols = self.subvol_center.shape[0]
         self.get_subvol_connections()
