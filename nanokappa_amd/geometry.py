@@ -54,6 +54,87 @@ def cylinder_primitive(dims):
     return v, np.array(f, dtype=int)
 
 
+def ring_stack(rings, bottom=None, top=None):
+    """Closed surface from a stack of polygonal rings (each (N,3), same N, same angular order): a fan cap on the first
+    and the last ring, two triangles per quad between consecutive rings.  Two consecutive rings in the same plane give a
+    flat annulus (the lids of the 'castle').  All the wire-like primitives of Geometry.generate_primitives are such
+    stacks; the triangulation is this builder's own (coplanar triangles are merged into facets by Mesh anyway)."""
+    N = rings[0].shape[0]
+    bottom = rings[0].mean(axis=0) if bottom is None else np.asarray(bottom, dtype=float)
+    top = rings[-1].mean(axis=0) if top is None else np.asarray(top, dtype=float)
+    v = np.vstack([bottom[None, :]] + list(rings) + [top[None, :]])
+    nxt = (np.arange(N) + 1) % N
+    f = [[0, 1 + i, 1 + nxt[i]] for i in range(N)]
+    for k in range(len(rings) - 1):
+        a, b = 1 + k * N, 1 + (k + 1) * N
+        for i in range(N):
+            f.append([a + i, a + nxt[i], b + nxt[i]])
+            f.append([a + i, b + nxt[i], b + i])
+    last, tip = 1 + (len(rings) - 1) * N, v.shape[0] - 1
+    f += [[tip, last + i, last + nxt[i]] for i in range(N)]
+    return v, np.array(f, dtype=int)
+
+
+def _circle(R, N, z=0.0, dx=0.0, dy=0.0, phase=0.0):
+    ang = (np.arange(N) + phase) * 2 * np.pi / N
+    return np.vstack((np.cos(ang) * R + dx, np.sin(ang) * R + dy, np.full(N, float(z)))).T
+
+
+def zigzag_primitive(dims):
+    """'zigzag' (Geometry.py:143-178): L, R, dx, dy, N_sides, N_sections -- rings of radius R every L along z, every odd
+    one displaced by (dx, dy)."""
+    L, R, dx, dy, Ns, Nc = float(dims[0]), float(dims[1]), float(dims[2]), float(dims[3]), int(dims[4]), int(dims[5])
+    rings = [_circle(R, Ns, i * L, (i % 2) * dx, (i % 2) * dy) for i in range(Nc + 1)]
+    return ring_stack(rings, bottom=[0, 0, 0], top=[(Nc % 2) * dx, (Nc % 2) * dy, Nc * L])
+
+
+def corrugated_primitive(dims):
+    """'corrugated' (Geometry.py:180-215): L, R, r, N_sides, N_sections -- rings every L, radius R at even and r at odd
+    stations."""
+    L, R, r, Ns, Nc = float(dims[0]), float(dims[1]), float(dims[2]), int(dims[3]), int(dims[4])
+    return ring_stack([_circle(R if i % 2 == 0 else r, Ns, i * L) for i in range(Nc + 1)])
+
+
+def castle_primitive(dims):
+    """'castle' (Geometry.py:217-316): L, l, R, r, N_sides, N_sections, start_large -- alternating cylinders of radius R
+    (length L) and r (length l) joined by flat annular lids."""
+    L, l, R, r, Ns, Nc, s = float(dims[0]), float(dims[1]), float(dims[2]), float(dims[3]), int(dims[4]), int(dims[5]), bool(float(dims[6]))
+    if R <= r:
+        raise Exception('Outer radius smaller or equal to the inner radius. Check parameters.')
+    rings, z, large = [_circle(r, Ns, 0.0)], 0.0, s
+    for _ in range(Nc):
+        if large:
+            rings += [_circle(R, Ns, z), _circle(R, Ns, z + L), _circle(r, Ns, z + L)]
+            z += L
+        else:
+            rings.append(_circle(r, Ns, z + l))
+            z += l
+        large = not large
+    return ring_stack(rings)
+
+
+def star_primitive(dims):
+    """'star' (Geometry.py:318-368): H, R, r, N_points -- prism of height H over a 2N-gon alternating between r (at
+    half-step angles) and R."""
+    H, R, r, N = float(dims[0]), float(dims[1]), float(dims[2]), int(dims[3])
+    if R <= r:
+        raise Exception('Outer radius smaller or equal to the inner radius. Check parameters.')
+    inner, outer = _circle(r, N, 0.0, phase=-0.5), _circle(R, N, 0.0)
+    poly = np.empty((2 * N, 3))
+    poly[0::2], poly[1::2] = inner, outer
+    return ring_stack([poly, poly + np.array([0, 0, H])], bottom=[0, 0, 0], top=[0, 0, H])
+
+
+def freewire_primitive(dims):
+    """'freewire' (Geometry.py:370-400): R0, L0, R1, L1, ..., R(n), N_sides -- rings of the given radii at the running
+    sum of the section lengths."""
+    R = np.array([dims[i] for i in range(0, len(dims) - 1, 2)], dtype=float)
+    L = np.array([dims[i] for i in range(1, len(dims) - 1, 2)], dtype=float)
+    N = int(float(dims[-1]))
+    z = np.concatenate(([0.0], np.cumsum(L)))[:R.shape[0]]
+    return ring_stack([_circle(R[i], N, z[i]) for i in range(R.shape[0])])
+
+
 class Geometry(object):
     def __init__(self, args):
         self.args = args
@@ -82,10 +163,20 @@ class Geometry(object):
             v, f = box_primitive(self.dimensions)
         elif shape in ('cylinder', 'rod', 'bar'):
             v, f = cylinder_primitive(self.dimensions)
+        elif shape == 'zigzag':
+            v, f = zigzag_primitive(self.dimensions)
+        elif shape == 'corrugated':
+            v, f = corrugated_primitive(self.dimensions)
+        elif shape == 'castle':
+            v, f = castle_primitive(self.dimensions)
+        elif shape == 'star':
+            v, f = star_primitive(self.dimensions)
+        elif shape == 'freewire':
+            v, f = freewire_primitive(self.dimensions)
         elif str(shape).lower().endswith('.stl'):
             v, f = read_stl(shape)
         else:
-            raise NotImplementedError('geometry %r: only box, cylinder and STL files are built so far' % shape)
+            raise Exception('geometry %r: not a standard shape and not an STL file' % shape)
         self._raw = (v, f)
 
     def transform_mesh(self):

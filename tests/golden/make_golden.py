@@ -150,6 +150,42 @@ def gen_grid():
     np.savez_compressed(os.path.join(HERE, 'grid.npz'), **out)
 
 
+SHAPE_ARGS = {   # the wire-like primitives of Geometry.generate_primitives (Geometry.py:143-400)
+    'zigzag': ['zigzag', '100', '50', '20', '10', '8', '4'],
+    'corrugated': ['corrugated', '80', '60', '35', '10', '5'],
+    'castle1': ['castle', '90', '40', '70', '45', '8', '5', '1'],
+    'castle0': ['castle', '90', '40', '70', '45', '8', '4', '0'],
+    'star': ['star', '150', '80', '40', '6'],
+    'freewire': ['freewire', '50', '100', '70', '60', '30', '120', '55', '12'],
+}
+
+
+def shape_argv(name):
+    d = SHAPE_ARGS[name]
+    return (['--geometry', d[0], '--dimensions'] + d[1:] + ['--subvolumes', 'slice', '4', '2',
+            '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+            '--bound_values', '302', '298', '5'] + H.COMMON + ['--particles', 'total', '1000'])
+
+
+def gen_shapes():
+    """Triangulation-independent invariants of the reference's primitives: volume, bounds, facet planes and areas."""
+    out = {}
+    for name in SHAPE_ARGS:
+        args = H.make_args(ref, shape_argv(name))
+        geo = ref.Geometry(args)
+        m = geo.mesh
+        p = name + '__'
+        out[p + 'volume'] = np.array(m.volume)
+        out[p + 'bounds'] = m.bounds
+        out[p + 'n_of_facets'] = np.array(m.n_of_facets)
+        out[p + 'facets_area'] = m.facets_area
+        out[p + 'facets_normal'] = m.facets_normal
+        out[p + 'facet_centroid'] = m.facet_centroid
+        out[p + 'bound_cond'] = bc_codes(geo.bound_cond)
+        print(name, 'faces', m.n_of_faces, 'facets', m.n_of_facets, 'volume', m.volume)
+    np.savez_compressed(os.path.join(HERE, 'shapes.npz'), **out)
+
+
 def material_small():
     return make_material(9, 'Si', temperatures=T_GRID)
 

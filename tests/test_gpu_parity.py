@@ -245,6 +245,13 @@ EXTRA_CASES = {
     'wire16': (['--geometry', 'cylinder', '--dimensions', '500', '100', '16', '--subvolumes', 'slice', '10', '2',
                 '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
                 '--bound_values', '302', '298', '5'], 'Si'),
+    # non-convex wires: corrugated (alternating radii) and castle (flat annular lids), rough everywhere but the ends
+    'corrugated': (['--geometry', 'corrugated', '--dimensions', '80', '60', '35', '10', '5', '--subvolumes', 'slice', '8', '2',
+                    '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+                    '--bound_values', '302', '298', '5'], 'Si'),
+    'castle': (['--geometry', 'castle', '--dimensions', '90', '40', '70', '45', '8', '5', '1', '--subvolumes', 'slice', '8', '2',
+                '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+                '--bound_values', '302', '298', '5'], 'Si'),
     # same with 72 sides: 288 faces -> the ray-casting tables stay in global memory (large-mesh code path)
     'wire72': (['--geometry', 'cylinder', '--dimensions', '500', '100', '72', '--subvolumes', 'slice', '10', '2',
                 '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
@@ -252,7 +259,7 @@ EXTRA_CASES = {
 }
 
 
-@pytest.mark.parametrize('name', ['ge_film', 'wire16', 'wire72'])
+@pytest.mark.parametrize('name', ['ge_film', 'wire16', 'wire72', 'corrugated', 'castle'])
 def test_other_geometries_vs_oracle(name):
     """Film with periodic sides, and wires with many rough facets (LDS and global-memory table paths): engine and
     oracle from the same state and seed, compared step by step and particle by particle."""
