@@ -67,8 +67,9 @@ __host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int 
 // compile-time choice, so that the table pointers are provably LDS and are read with ds_read, not flat loads);
 // EVBUF = carve the event buffer.  Plane, face and facet tables start on 16-byte boundaries (they are read 16 bytes
 // at a time).
+// The pointer arithmetic alone (also what an out-of-line helper needs to find the tables again).
 template <int GEOM, bool EVBUF>
-__device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem, NkLds &L) {
+__device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem, NkLds &L) {
     const int S = d.S, R = d.R;
     const int Fl = GEOM == 1 ? d.F : 0;
     const int Pl = Fl ? d.NP : 0;
@@ -99,6 +100,23 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     L.bins.misc = u; u += 1;
     int *rf_off = (int *)u; u += R + 1;
     if (EVBUF) { L.ev.mode = (int *)u; u += NK_EVCAP; L.ev.facet = (int *)u; u += NK_EVCAP; L.ev.evc = (int *)u; u += NK_EVCAP; }
+    L.resT = resT;
+    L.rf_off = rf_off; L.rf_cdf = rf_cdf; L.rf_verts = rf_verts;
+    if (GEOM == 1) { L.faces = faces; L.planes = planes; L.facets = facets; }
+    else { L.faces = d.faces; L.planes = d.planes; L.facets = d.facets; }
+}
+template <int GEOM, bool EVBUF>
+__device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem, NkLds &L) {
+    nk_lds_carve<GEOM, EVBUF>(d, smem, L);
+    const int S = d.S, R = d.R;
+    const int Fl = GEOM == 1 ? d.F : 0;
+    const int Pl = Fl ? d.NP : 0;
+    const int Fcl = GEOM == 1 ? d.Fc : 0;
+    const int nrf = (GEOM == 1 && d.res_lds) ? d.res_nf : 0;
+    double *faces = const_cast<double *>(L.faces), *planes = const_cast<double *>(L.planes);
+    NkFacet *facets = const_cast<NkFacet *>(L.facets);
+    double *resT = const_cast<double *>(L.resT), *rf_cdf = const_cast<double *>(L.rf_cdf), *rf_verts = const_cast<double *>(L.rf_verts);
+    int *rf_off = const_cast<int *>(L.rf_off);
     const int t = threadIdx.x;
     for (int i = t; i < S; i += NK_WG) L.Tsv[i] = d.T_sv[i];
     for (int i = t; i < 3 * S; i += NK_WG) L.cen[i] = d.centers[i];
@@ -120,10 +138,6 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
         int32_t *dst = (int32_t *)facets;
         for (int i = t; i < nw; i += NK_WG) dst[i] = src[i];
     }
-    if (GEOM == 1) { L.faces = faces; L.planes = planes; L.facets = facets; }
-    else { L.faces = d.faces; L.planes = d.planes; L.facets = d.facets; }
-    L.resT = resT;
-    L.rf_off = rf_off; L.rf_cdf = rf_cdf; L.rf_verts = rf_verts;
     __syncthreads();
 }
 
