@@ -365,6 +365,84 @@ def test_reserve_mid_run_preserves_state():
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
+def test_closed_periodic_box_conserves_particles():
+    """No reservoirs at all (every facet periodic): nk_set_reservoirs is never called, nothing enters or leaves, and the
+    oracle agrees step by step."""
+    from util import case_from_args
+    argv = ['--geometry', 'box', '--dimensions', '200', '200', '200', '--subvolumes', 'slice', '10', '0',
+            '--bound_pos', 'relative', '0', '.5', '.5', '--bound_cond', 'P', 'P',
+            '--connect_pos', 'relative', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1', '.5',
+            '.5', '.5', '0', '.5', '.5', '1'] + COMMON_ARGS
+    ct = case_from_args(argv, 'Si')
+    assert ct['res_facets'].shape[0] == 0
+    pos, mode, occ, counter = random_population(ct, 30000, seed=2)
+    from nanokappa_amd.engine import Engine
+    eng = Engine(0, 3)
+    eng.set_material(ct['tables'])
+    eng.set_mesh(ct['mesh'])
+    eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], 1, np.full(10, 298.0))
+    eng.set_params(dt=1.0, particle_density=ct['particle_density'])
+    eng.upload(pos, mode, occ)
+    eng.init_boundaries()
+    t = eng.step(30)
+    assert np.all(t['N_sv'].sum(axis=1) == 30000)
+    assert np.all(t['N_emitted'] == 0)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=3)
+    for s in range(30):
+        sim.run_timestep(emit=False)
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8)
+
+
+def test_empty_start_fills_from_reservoirs():
+    """An ensemble that starts with no particle at all: everything comes from the reservoirs."""
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 16, seed=1)
+    from nanokappa_amd.engine import Engine
+    eng = Engine(0, 5)
+    eng.set_material(ct['tables'])
+    eng.set_mesh(ct['mesh'])
+    eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], 1, np.full(ct['centers'].shape[0], 298.0))
+    eng.set_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'], counter)
+    eng.set_params(dt=1.0, particle_density=ct['particle_density'])
+    eng.reserve(200000)
+    eng.upload(pos[:0], mode[:0], occ[:0])
+    eng.init_boundaries()
+    t = eng.step(40)
+    live = t['N_sv'].sum(axis=1)
+    assert live[0] > 0 and live[-1] > live[0]
+    assert np.all(t['N_emitted'] > 0)
+    p = eng.download()
+    assert p['pid'].shape[0] == live[-1]
+    assert np.unique(p['pid']).shape[0] == p['pid'].shape[0]
+
+
+def test_error_paths_raise():
+    """Misuse of the C ABI comes back as a negative status + message (NkError in the wrapper), never as a crash."""
+    from nanokappa_amd.engine import Engine, NkError
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 1000, seed=1)
+    eng = Engine(0, 1)
+    with pytest.raises(NkError, match='not configured'):
+        eng.step(1)
+    eng.set_material(ct['tables'])
+    with pytest.raises(NkError, match='mode index out of range'):
+        eng.upload(pos, mode + 10 ** 6, occ)
+    eng.set_mesh(ct['mesh'])
+    eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], 1, np.full(ct['centers'].shape[0], 298.0))
+    eng.set_params(dt=1.0, particle_density=ct['particle_density'])
+    with pytest.raises(NkError, match="has BC 'T'"):          # reservoir facets without nk_set_reservoirs
+        eng.upload(pos, mode, occ)
+        eng.step(1)
+    with pytest.raises(NkError, match='one_to_one needs n_leaving'):
+        eng.set_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'], counter, gen=2)
+    eng.set_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'], counter)
+    eng.upload(pos, mode, occ)
+    eng.init_boundaries()
+    eng.step(2)
+    eng.close()
+
+
 def test_long_run_keeps_segments_balanced():
     """Regression: entering particles are dealt in whole 64-particle tiles; the remainder once always landed in the last
     segment, which filled up after a few dozen steps.  Few entering particles per step and many steps."""
