@@ -82,9 +82,16 @@ typedef struct {
     int32_t kind;            /* 0 slice (centres ascending along `axis`), 1 general nearest centre */
     int32_t axis;
     int32_t interp;          /* per-particle T: 0 interp1d 'nearest' on slices, 1 'linear' on slices,
-                                2 nearest centre (Population.py:570-573, :694-702) */
+                                2 nearest centre, 3 cubic radial basis functions = scipy RBFInterpolator
+                                (Population.py:570-590, :694-702) */
     const double *centers;   /* [S*3] */
     const double *volumes;   /* [S] */
+    /* interp 3 only (else NULL / 0): inverse of the RBF system of these centres, row-major (P x P), P = S + n_used
+     * + 1; shift and scale of its polynomial part; which coordinates take part (Population.py:651-656) */
+    const double *rbf_inv;
+    const double *rbf_shift; /* [3] */
+    const double *rbf_scale; /* [3] */
+    int32_t rbf_used[3];
 } nk_subvols;
 
 /* Reservoirs, reference Population.py:323-354 (initialise_reservoirs), :146-161 (enter_probability) */

@@ -79,7 +79,11 @@ struct NkDev {
     const double *centers;            // [S*3]
     const double *sv_volume;          // [S]
     double sv_lo, sv_invL;            // slice fast path: first edge and 1/slice_length
-    double *T_sv;                     // [S] current subvolume temperatures (updated by k_update)
+    double *T_sv;                     // [S + rbf_P] current subvolume temperatures (updated by k_update), followed by the
+                                      // RBF coefficients [w (S); p (n_used + 1)] when sv_interp == 3
+    const double *rbf_inv;            // [rbf_P * rbf_P] inverse of the RBF system (sv_interp 3)
+    int32_t rbf_P, rbf_used[3];
+    double rbf_shift[3], rbf_scale[3];
     // ---- reservoirs
     int32_t R, res_gen;
     const int32_t *res_facet;         // [R]
@@ -289,6 +293,24 @@ __device__ __forceinline__ int nk_classify(const NkDev &d, const double *cen, do
 __device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen, const double *Tsv, double x, double y,
                                               double z, int sv_hint) {
     const int S = d.S;
+    if (d.sv_interp == 3) {
+        // RBFInterpolator(kernel='cubic'): sum_i w_i |x - c_i|^3 + p_0 + sum_k p_k (x_k - shift_k) / scale_k; the
+        // coefficients follow the temperatures in the same array (k_update refreshes them with every new T_sv)
+        const double *w = Tsv + S;
+        double out = 0.0;
+        for (int i = 0; i < S; ++i) {
+            const double dx = d.rbf_used[0] ? x - cen[3 * i] : 0.0, dy = d.rbf_used[1] ? y - cen[3 * i + 1] : 0.0,
+                         dz = d.rbf_used[2] ? z - cen[3 * i + 2] : 0.0;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            out += w[i] * (r2 * sqrt(r2));
+        }
+        out += w[S];
+        int q = S + 1;
+        if (d.rbf_used[0]) out += w[q++] * ((x - d.rbf_shift[0]) / d.rbf_scale[0]);
+        if (d.rbf_used[1]) out += w[q++] * ((y - d.rbf_shift[1]) / d.rbf_scale[1]);
+        if (d.rbf_used[2]) out += w[q++] * ((z - d.rbf_shift[2]) / d.rbf_scale[2]);
+        return out;
+    }
     if (d.sv_interp == 2 || S == 1) return Tsv[sv_hint >= 0 ? sv_hint : nk_classify(d, cen, x, y, z)];
     const int a = d.sv_axis;
     double xa = a == 0 ? x : (a == 1 ? y : z);

@@ -56,6 +56,7 @@ struct nk_ctx {
     int num_cu = 256;
     std::vector<int32_t> h_ffo, h_ffi;   // host copies of the mesh's facet -> faces CSR, its area cdf and the vertices
     std::vector<double> h_fcdf, h_verts;
+    std::vector<double> h_rbf_inv;       // host copy of the RBF system inverse (sv_interp 3)
     std::vector<NkFacet> host_facets;   // host mirror of d.facets (patched by nk_set_reservoirs / nk_set_rough)
     const double *d_omega = nullptr, *d_vg = nullptr;   // kept to rebuild the packed mode records
     std::vector<double> h_Tgrid;
@@ -94,7 +95,7 @@ static inline int nk_geom_mode(const nk_ctx *ctx) { return (ctx->d.F <= NK_LDS_F
 static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool evbuf = false) {
     const NkDev &d = ctx->d;
     const int gm = geom ? nk_geom_mode(ctx) : 0;
-    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, evbuf, (gm == 1 && d.res_lds) ? d.res_nf : 0);
+    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, evbuf, (gm == 1 && d.res_lds) ? d.res_nf : 0, d.rbf_P);
 }
 #define NK_GEOM_LAUNCH(kernel, grid, lds, ...)                                                        \
     do {                                                                                               \
@@ -403,6 +404,17 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     return NK_OK;
 }
 
+// Append [w; p] = inv[:, :S] @ T_sv to a host copy of the temperatures (what k_update does on the device).
+static void nk_rbf_coefficients(nk_ctx *ctx, std::vector<double> &T) {
+    const int S = ctx->d.S, P = ctx->d.rbf_P;
+    T.resize((size_t)S + P);
+    for (int j = 0; j < P; ++j) {
+        double a = 0.0;
+        for (int i = 0; i < S; ++i) a += ctx->h_rbf_inv[(size_t)j * P + i] * T[i];
+        T[(size_t)S + j] = a;
+    }
+}
+
 int nk_set_subvolumes(nk_ctx *ctx, const nk_subvols *s, const double *T_sv_init) {
     NK_ARG(ctx && s && T_sv_init, "nk_set_subvolumes: NULL argument");
     NK_ARG(s->S > 0 && s->S <= 512, "nk_set_subvolumes: S must be in [1, 512]");
@@ -411,11 +423,27 @@ int nk_set_subvolumes(nk_ctx *ctx, const nk_subvols *s, const double *T_sv_init)
     NkDev &d = ctx->d;
     d.S = s->S; d.sv_kind = s->kind; d.sv_axis = s->axis; d.sv_interp = s->interp;
     NK_ARG(s->axis >= 0 && s->axis < 3, "nk_set_subvolumes: axis");
-    NK_ARG(!(s->kind != 0 && s->interp != 2), "nk_set_subvolumes: slice interpolation needs slice subvolumes");
+    NK_ARG(!(s->kind != 0 && s->interp != 2 && s->interp != 3), "nk_set_subvolumes: slice interpolation needs slice subvolumes");
+    NK_ARG(s->interp >= 0 && s->interp <= 3, "nk_set_subvolumes: interp must be 0..3");
     NK_UP(s->centers, (size_t)s->S * 3, &d.centers);
     NK_UP(s->volumes, (size_t)s->S, &d.sv_volume);
+    d.rbf_P = 0;
+    std::vector<double> t0(T_sv_init, T_sv_init + s->S);
+    if (s->interp == 3) {
+        NK_ARG(s->rbf_inv && s->rbf_shift && s->rbf_scale, "nk_set_subvolumes: interp 3 needs the RBF tables");
+        const int nd = (s->rbf_used[0] != 0) + (s->rbf_used[1] != 0) + (s->rbf_used[2] != 0);
+        NK_ARG(nd >= 1, "nk_set_subvolumes: RBF interpolation over no coordinate");
+        d.rbf_P = s->S + nd + 1;
+        for (int k = 0; k < 3; ++k) {
+            d.rbf_used[k] = s->rbf_used[k] != 0; d.rbf_shift[k] = s->rbf_shift[k]; d.rbf_scale[k] = s->rbf_scale[k];
+            NK_ARG(!d.rbf_used[k] || d.rbf_scale[k] != 0.0, "nk_set_subvolumes: zero RBF scale");
+        }
+        NK_UP(s->rbf_inv, (size_t)d.rbf_P * d.rbf_P, &d.rbf_inv);
+        ctx->h_rbf_inv.assign(s->rbf_inv, s->rbf_inv + (size_t)d.rbf_P * d.rbf_P);
+        nk_rbf_coefficients(ctx, t0);
+    }
     const double *t;
-    NK_UP(T_sv_init, (size_t)s->S, &t);
+    NK_UP(t0.data(), t0.size(), &t);
     d.T_sv = (double *)t;
     if (s->kind == 0 && s->S > 1) {
         double c0 = s->centers[s->axis], c1 = s->centers[3 + s->axis];
@@ -918,7 +946,9 @@ int nk_set_subvol_temperature(nk_ctx *ctx, const double *T_sv) {
     NK_ARG(ctx && T_sv && ctx->have_sv, "nk_set_subvol_temperature: bad arguments");
     NK_HIP(hipSetDevice(ctx->device));
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    NK_HIP(hipMemcpy(ctx->d.T_sv, T_sv, (size_t)ctx->d.S * 8, hipMemcpyHostToDevice));
+    std::vector<double> t(T_sv, T_sv + ctx->d.S);
+    if (ctx->d.sv_interp == 3) nk_rbf_coefficients(ctx, t);
+    NK_HIP(hipMemcpy(ctx->d.T_sv, t.data(), t.size() * 8, hipMemcpyHostToDevice));
     nk_track_T(ctx, T_sv, ctx->d.S);
     return NK_OK;
 }

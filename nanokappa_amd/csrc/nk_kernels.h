@@ -52,11 +52,11 @@ struct NkLds {
 
 // geom: 0 = no ray-casting tables, 1 = planes/faces/facets staged in LDS, 2 = read from global memory (large meshes)
 // nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged)
-__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, bool evbuf, int nrf) {
+__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, bool evbuf, int nrf, int rbfP) {
     int Fl = geom == 1 ? F : 0;
     int Pl = Fl ? NP : 0;
     int Fcl = geom == 1 ? Fc : 0;
-    size_t nd = (size_t)S + 3 * S + NK_NREP * S + NK_NREP * 3 * S + 4 * R + (size_t)Fl * NK_FACE_DOUBLES +
+    size_t nd = (size_t)S + (size_t)((rbfP + 1) & ~1) + 3 * S + NK_NREP * S + NK_NREP * 3 * S + 4 * R + (size_t)Fl * NK_FACE_DOUBLES +
                 (size_t)Pl * NK_PLANE_DOUBLES + (evbuf ? 7 * NK_EVCAP : 0) + (size_t)R + 10 * (size_t)nrf + 2;
     size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) +
                    (size_t)(NK_NREP * S + R + 1 + (R + 1) + (evbuf ? 3 * NK_EVCAP : 0)) * 4 + 16;
@@ -76,7 +76,7 @@ __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem
     const int Fcl = GEOM == 1 ? d.Fc : 0;
     const int nrf = (GEOM == 1 && d.res_lds) ? d.res_nf : 0;
     double *p = (double *)smem;
-    L.Tsv = p; p += S;
+    L.Tsv = p; p += S + ((d.rbf_P + 1) & ~1);          // temperatures, then the RBF coefficients (even count)
     L.cen = p; p += 3 * S;
     L.bins.E = p; p += NK_NREP * S;
     L.bins.flux = p; p += NK_NREP * 3 * S;
@@ -118,7 +118,7 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     double *resT = const_cast<double *>(L.resT), *rf_cdf = const_cast<double *>(L.rf_cdf), *rf_verts = const_cast<double *>(L.rf_verts);
     int *rf_off = const_cast<int *>(L.rf_off);
     const int t = threadIdx.x;
-    for (int i = t; i < S; i += NK_WG) L.Tsv[i] = d.T_sv[i];
+    for (int i = t; i < S + d.rbf_P; i += NK_WG) L.Tsv[i] = d.T_sv[i];
     for (int i = t; i < 3 * S; i += NK_WG) L.cen[i] = d.centers[i];
     for (int i = t; i < NK_NREP * S; i += NK_WG) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
     for (int i = t; i < NK_NREP * 3 * S; i += NK_WG) L.bins.flux[i] = 0.0;
@@ -604,6 +604,15 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
         if (!NK_ABL(2)) d.T_sv[t] = Tnew;
     }
     for (int b = tid; b < NB; b += nth) hist_row[b] = acc[b];
+    if (d.sv_interp == 3) {                          // RBF coefficients of the new temperatures: [w; p] = inv[:, :S] @ T_sv
+        __syncthreads();
+        const int P = d.rbf_P;
+        for (int j = tid; j < P; j += nth) {
+            double a = 0.0;
+            for (int i = 0; i < S; ++i) a += d.rbf_inv[(int64_t)j * P + i] * d.T_sv[i];
+            d.T_sv[S + j] = a;
+        }
+    }
     // free-space prefix over the segments for the next step's spawn distribution: thread t owns the contiguous
     // segments [t*per, (t+1)*per); one workgroup scan of the per-thread sums
     long long mine = 0;

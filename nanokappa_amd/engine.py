@@ -41,7 +41,8 @@ class nk_mesh(C.Structure):
 
 class nk_subvols(C.Structure):
     _fields_ = [('S', C.c_int32), ('kind', C.c_int32), ('axis', C.c_int32), ('interp', C.c_int32),
-                ('centers', c_dp), ('volumes', c_dp)]
+                ('centers', c_dp), ('volumes', c_dp), ('rbf_inv', c_dp), ('rbf_shift', c_dp), ('rbf_scale', c_dp),
+                ('rbf_used', C.c_int32 * 3)]
 
 
 class nk_reservoirs(C.Structure):
@@ -240,12 +241,18 @@ class Engine(object):
             m.nS = 0
         self._ck(self.L.nk_set_mesh(self.h, C.byref(m)), 'nk_set_mesh')
 
-    def set_subvolumes(self, centers, volumes, kind, axis, interp, T_sv):
+    def set_subvolumes(self, centers, volumes, kind, axis, interp, T_sv, rbf=None):
+        """interp 3 (cubic RBF) needs rbf = (inv, shift, scale, used) from setup_tables.rbf_system."""
         s = nk_subvols()
         c, v, t = _d(centers), _d(volumes), _d(T_sv)
         s.S = c.shape[0]
         s.kind, s.axis, s.interp = int(kind), int(axis), int(interp)
         s.centers, s.volumes = _p(c), _p(v)
+        if rbf is not None:
+            inv, sh, sc = _d(rbf[0]), _d(rbf[1]), _d(rbf[2])
+            s.rbf_inv, s.rbf_shift, s.rbf_scale = _p(inv), _p(sh), _p(sc)
+            for k in range(3):
+                s.rbf_used[k] = int(rbf[3][k])
         self._ck(self.L.nk_set_subvolumes(self.h, C.byref(s), _p(t)), 'nk_set_subvolumes')
         self.S = int(s.S)
 

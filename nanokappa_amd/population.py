@@ -330,10 +330,18 @@ class Population(Constants):
             kind, axis, interp = 0, geometry.slice_axis, (1 if self.temp_interp_type == 'linear' else 0)
         elif self.temp_interp_type == 'nearest':
             kind, axis, interp = 1, 0, 2
+        elif self.temp_interp_type in ('radial', 'linear'):
+            # non-slice subvolumes: cubic radial basis functions (Population.py:573-590; 'linear' falls back to them
+            # there too), over the coordinates a grid actually resolves (:651-656)
+            if self.temp_interp_type == 'linear':
+                print('Linear T interpolation is currently valid for slice subvolumes only. Defaulting to RBF interpolation to avoid extrapolation problems.')
+            kind, axis, interp = 1, 0, 3
+            used = (np.asarray(geometry.grid) != 1) if (geometry.subvol_type == 'grid' and np.any(np.asarray(geometry.grid) == 1)) else (True, True, True)
+            rbf = ST.rbf_system(geometry.subvol_center, used)
         else:
-            raise NotImplementedError('--temp_interp %s on %s subvolumes (RBF) is not built'
-                                      % (self.temp_interp_type, geometry.subvol_type))
-        eng.set_subvolumes(geometry.subvol_center, geometry.subvol_volume, kind, axis, interp, self.subvol_temperature)
+            raise Exception('Invalid T interpolator type.')
+        eng.set_subvolumes(geometry.subvol_center, geometry.subvol_volume, kind, axis, interp, self.subvol_temperature,
+                           rbf=(rbf if interp == 3 else None))
         Q, J = phonon.omega.shape
         if self.n_of_reservoirs > 0:
             eng.set_reservoirs(self.res_facet, self.res_facet_temperature, self.enter_prob.reshape(-1, Q * J),

@@ -254,3 +254,43 @@ def diffuse_roulette(geometry, phonon, rough_facets, specularity, corr, scat_mod
         c = np.cumsum(rate[f])
         roul[f] = c / c.max()
     return rate, roul
+
+
+def rbf_system(centers, used=(True, True, True)):
+    """Inverse of the linear system behind scipy's RBFInterpolator(centers, T, kernel='cubic') -- the temperature
+    interpolator of non-slice subvolumes with --temp_interp radial / linear (Population.py:573-590, :651-656).
+
+    T(x) = sum_i w_i |x - c_i|^3 + p_0 + sum_k p_k (x_k - shift_k) / scale_k over the used coordinates, with
+    [w; p] = inv @ [T_sv; 0].  The centres do not move, so the inverse is computed once and every new T_sv costs one
+    matrix-vector product.  Returns (inv (P,P), shift (3,), scale (3,), used (3,) int32) with P = S + n_used + 1.
+    """
+    c = np.asarray(centers, dtype=float)
+    used = np.asarray(used, dtype=bool)
+    y = c[:, used]
+    S, nd = y.shape
+    mins, maxs = y.min(axis=0), y.max(axis=0)
+    shift = (maxs + mins) / 2
+    scale = (maxs - mins) / 2
+    scale[scale == 0.0] = 1.0
+    r = np.sqrt(((y[:, None, :] - y[None, :, :]) ** 2).sum(axis=2))
+    P = S + nd + 1
+    lhs = np.zeros((P, P))
+    lhs[:S, :S] = r ** 3
+    poly = np.hstack((np.ones((S, 1)), (y - shift) / scale))
+    lhs[:S, S:] = poly
+    lhs[S:, :S] = poly.T
+    sh, sc = np.zeros(3), np.ones(3)
+    sh[used], sc[used] = shift, scale
+    return np.linalg.inv(lhs), sh, sc, used.astype(np.int32)
+
+
+def rbf_evaluate(inv, shift, scale, used, centers, T_sv, x):
+    """NumPy statement of the device / oracle evaluation (used by the tests)."""
+    used = np.asarray(used, dtype=bool)
+    S = centers.shape[0]
+    coef = inv[:, :S] @ np.asarray(T_sv, dtype=float)
+    d = np.asarray(x, dtype=float)[:, None, used] - centers[None, :, used]
+    r2 = (d ** 2).sum(axis=2)
+    out = (r2 * np.sqrt(r2)) @ coef[:S] + coef[S]
+    xh = (np.asarray(x, dtype=float)[:, used] - shift[used]) / scale[used]
+    return out + xh @ coef[S + 1:]

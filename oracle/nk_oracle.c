@@ -176,8 +176,39 @@ void nko_E_of_T(const nko_material *mat, int64_t n, const double *T, double *E) 
 }
 
 /* per-particle temperature: Population.py:570-571, :694-702 */
+/* RBFInterpolator(kernel='cubic') evaluation: coefficients [w; p] = inv[:, :S] @ T_sv, cached until T_sv changes
+ * (the oracle is single-threaded test infrastructure) */
+static double rbf_T_one(const nko_subvols *sv, const double *T_sv, const double x[3]) {
+    static double cache_T[1024], coef[1032];
+    static const nko_subvols *cache_sv = NULL;
+    const int32_t S = sv->S;
+    int32_t nd = sv->rbf_used[0] + sv->rbf_used[1] + sv->rbf_used[2];
+    const int32_t P = S + nd + 1;
+    if (cache_sv != sv || memcmp(cache_T, T_sv, sizeof(double) * (size_t)S) != 0) {
+        for (int32_t j = 0; j < P; ++j) {
+            double acc = 0.0;
+            for (int32_t i = 0; i < S; ++i) acc += sv->rbf_inv[(int64_t)j * P + i] * T_sv[i];
+            coef[j] = acc;
+        }
+        memcpy(cache_T, T_sv, sizeof(double) * (size_t)S);
+        cache_sv = sv;
+    }
+    double out = 0.0;
+    for (int32_t i = 0; i < S; ++i) {
+        double r2 = 0.0;
+        for (int k = 0; k < 3; ++k)
+            if (sv->rbf_used[k]) { double dd = x[k] - sv->centers[3 * i + k]; r2 += dd * dd; }
+        out += coef[i] * (r2 * sqrt(r2));
+    }
+    out += coef[S];
+    int32_t q = S + 1;
+    for (int k = 0; k < 3; ++k)
+        if (sv->rbf_used[k]) out += coef[q++] * ((x[k] - sv->rbf_shift[k]) / sv->rbf_scale[k]);
+    return out;
+}
 static double interp_T_one(const nko_subvols *sv, const double *T_sv, const double x[3], int32_t svid) {
     int32_t S = sv->S;
+    if (sv->interp == 3) return rbf_T_one(sv, T_sv, x);
     if (sv->interp == 2 || S == 1) return T_sv[svid >= 0 ? svid : classify_one(sv, x)];
     double xa = x[sv->axis];
     /* centres along the axis are ascending (Geometry.py:456-463) */

@@ -63,9 +63,16 @@ typedef struct {
     int32_t S;
     int32_t kind;            /* 0 = slice (nearest centre along axis), 1 = general nearest centre */
     int32_t axis;
-    int32_t interp;          /* 0 nearest (interp1d kind='nearest' on slices), 1 linear slice, 2 nearest-ND */
+    int32_t interp;          /* 0 nearest (interp1d kind='nearest' on slices), 1 linear slice, 2 nearest-ND,
+                              * 3 cubic RBF (RBFInterpolator, Population.py:573-590) */
     const double *centers;   /* [S*3] Geometry.py:453-463 */
     const double *volumes;   /* [S] */
+    /* interp 3 only: inverse of scipy's RBF system for these centres, P = S + n_used + 1 (row-major), the shift /
+     * scale of its polynomial part and which coordinates take part (Population.py:651-656) */
+    const double *rbf_inv;   /* [P*P] */
+    const double *rbf_shift; /* [3] */
+    const double *rbf_scale; /* [3] */
+    int32_t rbf_used[3];
 } nko_subvols;
 
 typedef struct {

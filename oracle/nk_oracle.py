@@ -40,7 +40,8 @@ class Mesh(C.Structure):
 
 class Subvols(C.Structure):
     _fields_ = [('S', C.c_int32), ('kind', C.c_int32), ('axis', C.c_int32), ('interp', C.c_int32),
-                ('centers', c_dp), ('volumes', c_dp)]
+                ('centers', c_dp), ('volumes', c_dp), ('rbf_inv', c_dp), ('rbf_shift', c_dp), ('rbf_scale', c_dp),
+                ('rbf_used', C.c_int32 * 3)]
 
 
 class Reservoirs(C.Structure):
@@ -168,13 +169,20 @@ def make_mesh(g):
     return m
 
 
-def make_subvols(centers, volumes, kind, axis, interp):
+def make_subvols(centers, volumes, kind, axis, interp, rbf=None):
+    """interp 3 (cubic RBF) needs rbf = (inv, shift, scale, used) from nanokappa_amd.setup_tables.rbf_system."""
     s = Subvols()
     c = _d(centers); v = _d(volumes)
     s.S = c.shape[0]
     s.kind, s.axis, s.interp = int(kind), int(axis), int(interp)
     s.centers, s.volumes = _p(c, c_dp), _p(v, c_dp)
     _keep(s, c, v)
+    if rbf is not None:
+        inv, sh, sc = _d(rbf[0]), _d(rbf[1]), _d(rbf[2])
+        s.rbf_inv, s.rbf_shift, s.rbf_scale = _p(inv, c_dp), _p(sh, c_dp), _p(sc, c_dp)
+        for k in range(3):
+            s.rbf_used[k] = int(rbf[3][k])
+        _keep(s, inv, sh, sc)
     return s
 
 

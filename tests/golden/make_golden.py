@@ -124,10 +124,12 @@ GRID_ARGS = {   # 'grid' subvolumes (Geometry.py:473-539, :961-1052): box and cy
 
 
 def grid_argv(name, particles=1000, iterations=1000):
+    """<case>: nearest-centre temperatures; <case>_rbf: --temp_interp radial (RBFInterpolator, Population.py:573-590)."""
     common = [a for a in H.COMMON]
     i = common.index('--temp_interp')
-    common[i + 1] = 'nearest'
-    return GRID_ARGS[name] + common + ['--particles', 'total', str(particles), '--iterations', str(iterations)]
+    common[i + 1] = 'radial' if name.endswith('_rbf') else 'nearest'
+    base = name[:-4] if name.endswith('_rbf') else name
+    return GRID_ARGS[base] + common + ['--particles', 'total', str(particles), '--iterations', str(iterations)]
 
 
 def gen_grid():
@@ -498,7 +500,7 @@ def build_case_argv(argv, seed):
 
 
 def run_stats(case, seed, particles=100000, steps=1000, extra=()):
-    if case in GRID_ARGS:
+    if case in GRID_ARGS or case.endswith('_rbf'):
         args, geo, ph, pop, mat = build_case_argv(grid_argv(case, particles, steps), seed)
     else:
         args, geo, ph, pop, mat = build_case(case, particles, seed, extra=extra, iterations=steps)
@@ -534,7 +536,7 @@ def gen_stats_one(case, seed):
 
 def gen_stats_merge():
     import glob
-    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332', 'film'):
+    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332', 'film', 'box_grid332_rbf'):
         files = sorted(glob.glob(os.path.join(HERE, '_stats_%s_[0-9]*.npz' % case)))
         if not files:
             continue
@@ -542,7 +544,7 @@ def gen_stats_merge():
         walls = np.array([float(np.load(f)['wall']) for f in files])
         ps = np.array([float(np.load(f)['phonon_steps']) for f in files])
         seeds = np.array([int(os.path.basename(f).split('_')[-1].split('.')[0]) for f in files])
-        if case in GRID_ARGS:
+        if case in GRID_ARGS or case.endswith('_rbf'):
             np.savez_compressed(os.path.join(HERE, 'stats_%s.npz' % case), rows=rows, wall=walls, phonon_steps=ps, seeds=seeds)
             print(case, rows.shape, 'mean throughput', (ps / walls).mean())
             continue

@@ -285,7 +285,8 @@ def test_other_geometries_vs_oracle(name):
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
-def test_grid_subvolumes_vs_oracle():
+@pytest.mark.parametrize('interp', [2, 3])
+def test_grid_subvolumes_vs_oracle(interp):
     """'grid' subvolumes: 3-D nearest-centre classification and nearest-centre particle temperatures on the device
     (nk_classify general branch) against the oracle, step by step."""
     from util import case_from_args
@@ -298,8 +299,17 @@ def test_grid_subvolumes_vs_oracle():
     assert ct['kind'] == 1 and ct['centers'].shape[0] == 18
     pos, mode, occ, counter = random_population(ct, 30000, seed=21)
     nsteps = 20
-    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=5)
-    eng = make_engine(ct, pos, mode, occ, counter, seed=5)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=5, interp=interp)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=5, interp=interp)
+    if interp == 3:      # the device evaluation of the cubic-RBF temperature field against the NumPy statement of scipy's
+        from nanokappa_amd import setup_tables as ST
+        rbf = ST.rbf_system(ct['centers'])
+        Tt = 300.0 + np.random.default_rng(1).normal(size=18)
+        eng.set_subvol_temperature(Tt)
+        x = np.random.default_rng(2).random((2000, 3)) * 200.0
+        got = eng.eval('interp_T', x)
+        assert np.abs(got - ST.rbf_evaluate(*rbf, ct['centers'], Tt, x)).max() < 1e-9
+        eng.set_subvol_temperature(np.full(18, 298.0))
     t = eng.step(nsteps)
     for s in range(nsteps):
         sim.run_timestep()

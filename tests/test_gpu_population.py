@@ -97,7 +97,8 @@ GRID_ARGV = ['--geometry', 'box', '--dimensions', '200', '200', '200', '--subvol
              '--bound_values', '302', '298']
 
 
-def test_statistical_parity_grid_subvolumes():
+@pytest.mark.parametrize('interp', ['nearest', 'radial'])
+def test_statistical_parity_grid_subvolumes(interp):
     """'grid' subvolumes with nearest-centre temperatures (tests/golden/make_golden.py box_grid332: 4 reference runs,
     1e5 particles x 1000 steps): subvolume temperatures, x heat flux, particle count and the conductivities of the
     connections along the gradient, averaged over steps 500-1000."""
@@ -106,10 +107,10 @@ def test_statistical_parity_grid_subvolumes():
     from nanokappa_amd.geometry import Geometry
     from nanokappa_amd.phonon import Phonon
     from nanokappa_amd.population import Population
-    g = golden('stats_box_grid332')
+    g = golden('stats_box_grid332' + ('_rbf' if interp == 'radial' else ''))
     rr = g['rows']                                            # (seeds, 100, 2 + S + 3S + S + C)
     common = list(A.COMMON)
-    common[common.index('--temp_interp') + 1] = 'nearest'
+    common[common.index('--temp_interp') + 1] = interp          # 'radial' = cubic RBF temperature field (Population.py:573-590)
     S = 18
     rows = []
     seeds = [201, 202, 203, 204]

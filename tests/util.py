@@ -97,7 +97,8 @@ def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=29
     mat = O.make_material(ct['tables'])
     mesh = O.make_mesh(ct['mesh'])
     kind = ct.get('kind', 0)
-    sv = O.make_subvols(ct['centers'], ct['volumes'], kind, ct['axis'], 2 if kind == 1 else interp)
+    itp, rbf = sv_interp_of(ct, kind, interp)
+    sv = O.make_subvols(ct['centers'], ct['volumes'], kind, ct['axis'], itp, rbf=rbf)
     ep = ct['enter_prob'] * emit_scale
     res = O.make_reservoirs(ct['res_facets'], ct['res_T'], ep, counter.copy(), gen=gen,
                             n_leaving=(first_n_leaving(ep) if gen == 2 else None))
@@ -117,6 +118,15 @@ def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=29
     return sim
 
 
+def sv_interp_of(ct, kind, interp):
+    """Interpolation code + RBF tables for a case: slices take `interp` (0 nearest / 1 linear); general subvolumes take
+    nearest-centre (2) unless the cubic RBF (3) is asked for."""
+    if interp == 3:
+        from nanokappa_amd import setup_tables as ST
+        return 3, ST.rbf_system(ct['centers'])
+    return (interp if kind == 0 else 2), None
+
+
 def first_n_leaving(enter_prob):
     """Population.py:344: the first step of 'one_to_one' emits round(sum of enter_prob) particles per reservoir."""
     ep = np.asarray(enter_prob)
@@ -130,8 +140,8 @@ def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scal
     eng.set_material(ct['tables'])
     eng.set_mesh(ct['mesh'])
     kind = ct.get('kind', 0)
-    eng.set_subvolumes(ct['centers'], ct['volumes'], kind, ct['axis'], 2 if kind == 1 else interp,
-                       np.full(ct['centers'].shape[0], T0))
+    itp, rbf = sv_interp_of(ct, kind, interp)
+    eng.set_subvolumes(ct['centers'], ct['volumes'], kind, ct['axis'], itp, np.full(ct['centers'].shape[0], T0), rbf=rbf)
     ep = ct['enter_prob'] * emit_scale
     eng.set_reservoirs(ct['res_facets'], ct['res_T'], ep, counter, gen=gen,
                        n_leaving=(first_n_leaving(ep) if gen == 2 else None))
