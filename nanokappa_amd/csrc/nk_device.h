@@ -290,10 +290,13 @@ __device__ __forceinline__ int nk_classify(const NkDev &d, const double *cen, do
     return best;
 }
 // per-particle temperature, Population.py:570-571, :694-702
+// RBF = false compiles the radial-basis branch out (the sweep is instantiated with and without it: inlined it costs
+// registers in every configuration, and it is a rarely used mode).
+template <bool RBF = true>
 __device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen, const double *Tsv, double x, double y,
                                               double z, int sv_hint) {
     const int S = d.S;
-    if (d.sv_interp == 3) {
+    if (RBF && d.sv_interp == 3) {
         // RBFInterpolator(kernel='cubic'): sum_i w_i |x - c_i|^3 + p_0 + sum_k p_k (x_k - shift_k) / scale_k; the
         // coefficients follow the temperatures in the same array (k_update refreshes them with every new T_sv)
         const double *w = Tsv + S;
@@ -441,6 +444,7 @@ __device__ __forceinline__ void nk_find_boundary_grouped(const double *groups, i
 
 // ---------------------------------------------------------------------------------- rough reflection
 // select_reflected_modes + pick_diffuse_modes, Population.py:941-1015.
+template <bool RBF = true>
 __device__ __forceinline__ void nk_reflect(const NkDev &d, const double *cen, const double *Tsv, int rough_idx, int mode_in,
                                            double cx, double cy, double cz, double n_in, double omega_in, double r_spec,
                                            double r_deg, double r_diff, int &mode_out, double &n_out, double &omega_out) {
@@ -460,7 +464,7 @@ __device__ __forceinline__ void nk_reflect(const NkDev &d, const double *cen, co
         if (flat > d.M - 1) flat = d.M - 1;
         mode_out = flat;
         omega_out = d.modetab[flat].omega;
-        double T = nk_interp_T(d, cen, Tsv, cx, cy, cz, -1);
+        double T = nk_interp_T<RBF>(d, cen, Tsv, cx, cy, cz, -1);
         n_out = nk_occupation(d, T, omega_out);
     }
 }
@@ -490,7 +494,7 @@ struct NkParticle {
 #define NK_EV_DONE 0
 #define NK_EV_DEAD 1
 #define NK_EV_MORE 2
-template <bool ROUGH>
+template <bool ROUGH, bool RBF = true>
 __device__ __forceinline__ int nk_event_one(const NkDev &d, const double *groups, int NG, const double *planes,
                                             const double *faces, const NkFacet *facets, const double *cen, const double *Tsv,
                                             const double *resT, NkBins &b, NkParticle &p, double &cts, uint32_t &ev,
@@ -533,7 +537,7 @@ __device__ __forceinline__ int nk_event_one(const NkDev &d, const double *groups
             nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);
             p.x = cx; p.y = cy; p.z = cz;
             int mo; double no, oo;
-            nk_reflect(d, cen, Tsv, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, r0, r1, r1, mo, no, oo);
+            nk_reflect<RBF>(d, cen, Tsv, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, r0, r1, r1, mo, no, oo);
             p.mode = mo; p.occ = no; p.omega = oo;
             const NkMode *rec = d.modetab + mo;
             p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;

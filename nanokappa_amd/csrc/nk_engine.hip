@@ -38,6 +38,7 @@ struct nk_ctx {
     int g_sweep = 0;               // persistent grid of k_sweep = rows of `partials`
     std::vector<int32_t> h_seg_count;
     std::vector<hipEvent_t> evpool;
+    int g_sweep_key = -1;              // which k_sweep instantiation g_sweep was sized for
     // set-up table builder state (nk_specular_*)
     int64_t spec_M = 0;
     double *spec_v = nullptr, *spec_om = nullptr, *spec_dl = nullptr;
@@ -103,6 +104,19 @@ static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool evbuf = false) {
         else kernel<2><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);                                \
     } while (0)
 static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
+// The sweep is instantiated per (table placement, rough facets, RBF temperatures): run STMT with KERNEL bound to the one
+// that matches.
+#define NK_SWEEP_CASE(G, R, B, STMT) { auto KERNEL = k_sweep<G, R, B>; STMT; }
+#define NK_SWEEP_DISPATCH(gm, rough, rbf, STMT)                                                       \
+    do {                                                                                               \
+        if ((gm) == 1) {                                                                               \
+            if (rough) { if (rbf) NK_SWEEP_CASE(1, true, true, STMT) else NK_SWEEP_CASE(1, true, false, STMT) }       \
+            else { if (rbf) NK_SWEEP_CASE(1, false, true, STMT) else NK_SWEEP_CASE(1, false, false, STMT) }            \
+        } else {                                                                                       \
+            if (rough) { if (rbf) NK_SWEEP_CASE(2, true, true, STMT) else NK_SWEEP_CASE(2, true, false, STMT) }       \
+            else { if (rbf) NK_SWEEP_CASE(2, false, true, STMT) else NK_SWEEP_CASE(2, false, false, STMT) }            \
+        }                                                                                              \
+    } while (0)
 
 // Choose the four lifetime rows packed into the mode records so that they bracket [T_lo, T_hi]; rebuild on change.
 static int nk_update_tau_window(nk_ctx *ctx, bool force) {
@@ -255,7 +269,7 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
     d.NP = (int)members.size();
     // Large meshes (tables in global memory): order the planes along a Morton curve of their faces' box centres so that
     // consecutive planes are neighbours in space; groups of NK_GROUP_PLANES then have tight bounding boxes.
-    const bool grouped = !(m->F <= NK_LDS_FACES && m->Fc <= NK_LDS_FACES);
+    const bool grouped = !(m->F <= NK_LDS_FACES && m->Fc <= NK_LDS_FACES) && !getenv("NK_NO_GROUPS");   // env: developer probe
     if (grouped) {
         std::vector<uint64_t> key(members.size());
         double ext[3];
@@ -794,17 +808,16 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     }
     const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, true);
     const int count_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
-    if (ctx->g_sweep == 0) {                               // persistent grid = what the device keeps resident
+    const int gm_ = nk_geom_mode(ctx);
+    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3;
+    if (ctx->g_sweep == 0 || ctx->g_sweep_key != (gm_ | (rough_ << 2) | (rbf_ << 3))) {   // persistent grid = what stays resident
         int per_cu = 0;
-        const bool rough = d.Fr > 0;
-        if (nk_geom_mode(ctx) == 1 && rough) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1, true>, NK_WG, lds_w));
-        else if (nk_geom_mode(ctx) == 1) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<1, false>, NK_WG, lds_w));
-        else if (rough) NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<2, true>, NK_WG, lds_w));
-        else NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_sweep<2, false>, NK_WG, lds_w));
+        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
         if (per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
         if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
         ctx->g_sweep = ctx->num_cu * per_cu;
+        ctx->g_sweep_key = gm_ | (rough_ << 2) | (rbf_ << 3);
     }
     const int g_sweep = ctx->g_sweep < d.nseg ? ctx->g_sweep : d.nseg;
     const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the call
@@ -837,12 +850,8 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         const bool emit_next = R > 0 && d.res_gen != 2 && ((int64_t)R * d.M + g_sweep - 1) / g_sweep <= (int64_t)NK_EMIT_KMAX * NK_WG;
         {
             const int rl = ctx->pending_relax ? 1 : 0;
-            const int gm = nk_geom_mode(ctx);
             const int flags = do_flux | (emit_next ? 2 : 0);
-            if (gm == 1 && d.Fr > 0) k_sweep<1, true><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags);
-            else if (gm == 1) k_sweep<1, false><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags);
-            else if (d.Fr > 0) k_sweep<2, true><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags);
-            else k_sweep<2, false><<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags);
+            NK_SWEEP_DISPATCH(gm_, rough_, rbf_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags)));
         }
         ctx->spawn_ready = emit_next;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));

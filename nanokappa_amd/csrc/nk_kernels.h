@@ -161,9 +161,10 @@ __device__ __forceinline__ void nk_lds_flush(const NkDev &d, const NkLds &L, int
 
 // Deferred lifetime_scattering (Population.py:1701-1710) for one particle.
 // The mode record is passed as two 32-byte halves {omega, vx, vy, vz} {tau0..tau3} (two dwordx4 pairs, no struct copy).
+template <bool RBF = true>
 __device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const double4 &ra, const double4 &rb, double x,
                                            double y, double z, double occ, int mode) {
-    double T = nk_interp_T(d, L.cen, L.Tsv, x, y, z, -1);
+    double T = nk_interp_T<RBF>(d, L.cen, L.Tsv, x, y, z, -1);
     double tau = nk_lifetime(d, rb.x, rb.y, rb.z, rb.w, T, mode);
     double n0 = nk_occupation(d, T, ra.x);
     return (tau > 0.0) ? n0 + (occ - n0) * exp(-d.dt / tau) : n0;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
 #define NK_ABL(b) false
 #endif
 #define NK_WAVE_EVCAP (NK_EVCAP / (NK_WG / 64))     // 128 parked particles per wave (< 64 pending + 64 new)
-template <int GEOM, bool ROUGH>
+template <int GEOM, bool ROUGH, bool RBF>
 __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
@@ -421,7 +422,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 }
                 omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w;
                 if (act) {
-                    if (do_relax) occ = nk_relax(d, L, ra, rb, x, y, z, occ, mode);
+                    if (do_relax) occ = nk_relax<RBF>(d, L, ra, rb, x, y, z, occ, mode);
                     x += vx * d.dt; y += vy * d.dt; z += vz * d.dt;                 // drift, Population.py:793
                     nts -= 1.0;                                                     // :795
                 }
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     const double4 ra = first ? pre : *reinterpret_cast<const double4 *>(d.modetab + p.mode);
                     p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                     p.alive = true;
-                    st = nk_event_one<ROUGH>(d, d.pgroups, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, cts, evc, ppid, step);
+                    st = nk_event_one<ROUGH, RBF>(d, d.pgroups, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, cts, evc, ppid, step);
                 }
                 first = false;
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
