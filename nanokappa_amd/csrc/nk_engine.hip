@@ -570,6 +570,19 @@ int nk_set_rough(nk_ctx *ctx, const nk_rough *r) {
         NK_UP(r->true_spec, n, &d.true_spec);
         NK_UP(r->spec_map, n, &d.spec_map);
         NK_UP(r->roulette, n, &d.roulette);
+        {   // bucket index of the roulette search (nk_reflect): first position with roulette >= k / NK_ROUL_LUT * last
+            std::vector<int32_t> lut((size_t)r->Fr * (NK_ROUL_LUT + 1));
+            for (int f = 0; f < r->Fr; ++f) {
+                const double *ro = r->roulette + (size_t)f * d.M;
+                const double last = ro[d.M - 1];
+                for (int k = 0; k <= NK_ROUL_LUT; ++k) {
+                    const double thr = ((double)k / (double)NK_ROUL_LUT) * last;
+                    lut[(size_t)f * (NK_ROUL_LUT + 1) + k] = (int32_t)(std::lower_bound(ro, ro + d.M, thr) - ro);
+                }
+                lut[(size_t)f * (NK_ROUL_LUT + 1) + NK_ROUL_LUT] = d.M;        // everything is below the end of the last bucket
+            }
+            NK_UP(lut.data(), lut.size(), &d.roul_lut);
+        }
         if (r->degen_j2) NK_UP(r->degen_j2, (size_t)d.M, &d.degen_j2); else d.degen_j2 = nullptr;
         for (int i = 0; i < r->Fr; ++i) {
             NK_ARG(r->facet[i] >= 0 && r->facet[i] < d.Fc, "nk_set_rough: facet index");
