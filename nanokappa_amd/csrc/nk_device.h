@@ -13,7 +13,9 @@
 #include <stdint.h>
 
 #define NK_WG 256            // threads per workgroup (4 waves of 64)
+#ifndef NK_NREP
 #define NK_NREP 8            // LDS replicas of the tally bins (lane & 7) to thin same-address atomics
+#endif
 #define NK_PLANE_DOUBLES 6   // nx ny nz k {face_begin, face_end} pad  (48 B: three aligned 16-byte reads)
 #define NK_FACE_DOUBLES 16   // lo(3) hi(3) o(3) iu(3) iw(3) {orig_face, facet}
 #define NK_LDS_FACES 256     // meshes up to this many faces keep their plane/face tables in LDS

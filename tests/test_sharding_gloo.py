@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 NSTEPS = 12
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, gen=0):
     sys.path.insert(0, HERE)
     import torch
     import torch.distributed as dist
@@ -24,7 +24,7 @@ def _worker(rank, world, port, out_dir):
     ct = case_tables('ttrrp')
     pos, mode, occ, counter = random_population(ct, 12000, seed=3)
     lo, hi = shard_range(pos.shape[0], rank, world)
-    sim = make_oracle_sim(ct, pos[lo:hi], mode[lo:hi], occ[lo:hi], counter, seed=17, cap=30000)
+    sim = make_oracle_sim(ct, pos[lo:hi], mode[lo:hi], occ[lo:hi], counter, seed=17, cap=30000, gen=gen)
     sim.P.pid[:hi - lo] = np.arange(lo, hi, dtype=np.uint64)
     sim.rank, sim.nranks = rank, world
 
@@ -43,16 +43,19 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_union_equals_single_run(tmp_path):
+@pytest.mark.parametrize('gen', [0, 2])
+def test_two_rank_union_equals_single_run(tmp_path, gen):
+    """gen 0: 'constant' reservoirs (every rank advances all counters, keeps its share); gen 2: 'one_to_one' (the
+    all-reduced N_leaving of a step drives the next step's emission on every rank)."""
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000)
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    port = 29500 + (os.getpid() % 2000) + 7 * gen
+    mp.spawn(_worker, args=(2, port, str(tmp_path), gen), nprocs=2, join=True)
     r0 = np.load(tmp_path / 'rank0.npz')
     r1 = np.load(tmp_path / 'rank1.npz')
     # single-process reference
     ct = case_tables('ttrrp')
     pos, mode, occ, counter = random_population(ct, 12000, seed=3)
-    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=17, cap=30000)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=17, cap=30000, gen=gen)
     T_hist = []
     for _ in range(NSTEPS):
         sim.run_timestep()
