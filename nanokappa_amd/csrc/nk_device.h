@@ -22,7 +22,8 @@
 #define NK_LDS_RESFACES 64   // reservoir facets with up to this many faces in total keep their sampling tables in LDS
 #define NK_TAU_ROWS 4        // lifetime rows packed into each mode record
 #define NK_ROUL_LUT 1024      // buckets of the diffuse-roulette search index
-#define NK_MAX_SEGMENTS 8192  // upper bound of nseg (the update keeps 32 per thread in registers)
+#define NK_MAX_SEGMENTS 12288 // upper bound of nseg = 4 x 3072 = 6 x 2048 = 12 x 1024: a whole number of segments per
+                              // resident wave at 3, 2 or 1 workgroups per CU (the update keeps 48 per thread in registers)
 #define NK_EVCAP 512         // entries of the per-workgroup LDS event buffer (< NK_WG pending + NK_WG new)
 
 // RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")

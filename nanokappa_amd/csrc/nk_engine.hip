@@ -716,17 +716,41 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
     return NK_OK;
 }
 
+// Persistent grid of the sweep = what the device keeps resident of the instantiation this configuration uses (before the
+// tables are known: three workgroups per CU, the common case).
+static int nk_sweep_blocks(nk_ctx *ctx) {
+    NkDev &d = ctx->d;
+    if (!(ctx->have_material && ctx->have_mesh && ctx->have_sv)) return ctx->num_cu * 3;
+    const int gm_ = nk_geom_mode(ctx);
+    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3;
+    const int key = gm_ | (rough_ << 2) | (rbf_ << 3);
+    if (ctx->g_sweep == 0 || ctx->g_sweep_key != key) {
+        const size_t lds_w = nk_lds(ctx, true, true);
+        int per_cu = 0;
+        hipError_t e_ = hipSuccess;
+        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
+        if (e_ != hipSuccess || per_cu < 1) per_cu = 1;
+        if (per_cu > 8) per_cu = 8;
+        if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
+        ctx->g_sweep = ctx->num_cu * per_cu;
+        ctx->g_sweep_key = key;
+    }
+    return ctx->g_sweep;
+}
+
 static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
     NkDev &d = ctx->d;
     for (void *p : ctx->pallocs) hipFree(p);
     ctx->pallocs.clear();
     // segments: load-balance granularity of the persistent sweep (a few tiles of 256 each)
-    // about four segments per resident wave (3072 waves on 256 CUs), each between 512 and 2048 slots
-    int64_t per_wave = 4;
-    if (const char *e = getenv("NK_SEG_PER_WAVE")) per_wave = atoi(e) > 0 ? atoi(e) : 4;      // developer probe
-    int64_t target = capacity / (per_wave * 3072);
-    target = target < 512 ? 512 : (target > 2048 ? 2048 : target);
-    int64_t nseg = capacity / target;
+    // Segments of at least 512 slots, and for large ensembles exactly ONE per resident wave of the sweep: measured on
+    // 1e7 particles, 3072 segments (one per wave) 0.381 ms, 6144 0.397, 8192 0.39-0.40, 12288 0.401, and 4096 (a third
+    // of the waves gets a second segment) 0.413 -- long segments amortise the per-segment costs (first-tile latency, the
+    // partial last event batch and spawn tile), and a whole number per wave keeps the waves level.
+    int64_t nseg = capacity / 512;
+    const int64_t waves = (int64_t)nk_sweep_blocks(ctx) * (NK_WG / 64);
+    if (const char *e = getenv("NK_SEGMENTS")) nseg = atoi(e) > 0 ? atoi(e) : nseg;          // developer probe
+    else if (nseg >= waves) nseg = waves;
     nseg = nseg < 64 ? 64 : (nseg > NK_MAX_SEGMENTS ? NK_MAX_SEGMENTS : nseg);
     int64_t segcap = (capacity + nseg - 1) / nseg;
     segcap = ((segcap + 63) / 64) * 64;
@@ -823,15 +847,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     const int count_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
     const int gm_ = nk_geom_mode(ctx);
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3;
-    if (ctx->g_sweep == 0 || ctx->g_sweep_key != (gm_ | (rough_ << 2) | (rbf_ << 3))) {   // persistent grid = what stays resident
-        int per_cu = 0;
-        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, NK_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
-        if (per_cu < 1) per_cu = 1;
-        if (per_cu > 8) per_cu = 8;
-        if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
-        ctx->g_sweep = ctx->num_cu * per_cu;
-        ctx->g_sweep_key = gm_ | (rough_ << 2) | (rbf_ << 3);
-    }
+    (void)nk_sweep_blocks(ctx);
     const int g_sweep = ctx->g_sweep < d.nseg ? ctx->g_sweep : d.nseg;
     const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the call
     if (ctx->evpool.empty()) {                           // events are created once and reused
