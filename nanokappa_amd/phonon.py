@@ -41,6 +41,31 @@ class _Interp1dLinear(object):
         return out.reshape(shape)
 
 
+def material_from_phono3py(data, poscar_path):
+    """phono3py kappa file contents (datasets mesh, qpoint, weight, frequency, group_velocity, temperature, gamma;
+    Phonon.py:158-187) + POSCAR -> the FBZ-expanded tables of Phonon.load_base_properties (Phonon.py:66-113): the
+    irreducible q-points are expanded with the crystal's reciprocal point-group operations (expand_FBZ :515-564),
+    negative frequencies are clipped (:163), group velocities rounded to 10 decimals (:102)."""
+    from . import crystal
+    if poscar_path is None or not os.path.exists(poscar_path):
+        raise IOError('material: POSCAR file %r not found (it fixes the lattice and the symmetry of the expansion)' % poscar_path)
+    cell = crystal.read_poscar(poscar_path)
+    lattice = cell['lattice']
+    rec = np.linalg.inv(lattice) * 2 * np.pi                                     # vectors as columns, Phonon.py:72
+    rot = crystal.reciprocal_operations(lattice, cell['numbers'], cell['positions'])
+    w = np.array(data['weight'])
+    q = np.array(data['qpoint'], dtype=float)
+    freq = np.array(data['frequency'], dtype=float)
+    freq = np.where(freq < 0, 0, freq)
+    q_fbz, freq = crystal.expand_FBZ(w, q, freq, 0, 0, rot, rec)
+    _, vg = crystal.expand_FBZ(w, q, np.array(data['group_velocity'], dtype=float), 0, 1, rot, rec)
+    _, gamma = crystal.expand_FBZ(w, q, np.array(data['gamma'], dtype=float), 1, 0, rot, rec)
+    return dict(data_mesh=np.array(data['mesh']), q_points=q_fbz, frequency=freq, omega=freq * 2 * np.pi,
+                group_vel=np.around(vg, decimals=10), temperature=np.array(data['temperature'], dtype=float), gamma=gamma,
+                lattice=lattice, reciprocal_lattice=np.around(rec, decimals=6),
+                volume_unitcell=abs(np.linalg.det(lattice)))
+
+
 class Phonon(Constants):
     """Phonon(arguments, mat_index, material=None)
 
@@ -74,21 +99,23 @@ class Phonon(Constants):
             species = parts[2] if len(parts) > 2 else 'Si'
             return synthetic.make_material(n, species)
         path = os.path.join(folder, name)
+        poscar = os.path.join(folder, self.args.poscar_file[self.mat_index]) if len(getattr(self.args, 'poscar_file', [])) > self.mat_index else None
         if path.endswith('.npz'):
             with np.load(path) as z:
-                return {k: z[k] for k in z.files}
+                data = {k: z[k] for k in z.files}
+            if 'qpoint' in data:                     # phono3py datasets kept as .npz (irreducible wedge + weights)
+                return material_from_phono3py(data, poscar)
+            return data                              # FBZ-expanded tables (Phonon.save_npz, synthetic.make_material)
         if path.endswith('.hdf5') or path.endswith('.h5'):
             try:
                 import h5py
             except ImportError:
                 raise ImportError('reading %s needs h5py, which is not installed; convert the material to .npz '
-                                  '(Phonon.save_npz) or use hdf_file "synthetic"' % path)
+                                  '(same dataset names) or use hdf_file "synthetic"' % path)
             with h5py.File(path, 'r') as f:
-                w = np.array(f['weight'])
-                if not np.all(w == 1):
-                    raise NotImplementedError('irreducible-wedge phono3py files need the FBZ expansion of '
-                                              'Phonon.py:515-564 (SURVEY 8f row 2); supply an FBZ-expanded file')
-                raise NotImplementedError('POSCAR parsing for hdf5 materials is not built yet (SURVEY 8f row 2)')
+                data = {k: np.array(f[k]) for k in ('mesh', 'qpoint', 'weight', 'frequency', 'group_velocity',
+                                                     'temperature', 'gamma')}
+            return material_from_phono3py(data, poscar)
         raise ValueError('unknown material source %r' % name)
 
     def _ingest(self, m):

@@ -53,3 +53,59 @@ def test_find_min_k():
     kmin, disp = ph.find_min_k(g['s_k'].copy(), return_disp=True)
     assert np.allclose(kmin, g['s_kmin'], atol=1e-12)
     assert np.allclose(disp, g['s_kdisp'], atol=1e-12)
+
+
+def test_poscar_and_point_group():
+    """POSCAR -> lattice: reciprocal lattice and cell volume equal the values the reference obtained through phonopy
+    (tests/golden/phonon.npz); the symmetry finder returns the 48 operations of the diamond structure, a closed group
+    that contains the inversion (time reversal)."""
+    import os
+    from nanokappa_amd import crystal
+    here = os.path.dirname(os.path.abspath(__file__))
+    cell = crystal.read_poscar(os.path.join(here, 'golden', 'POSCAR_Si'))
+    g = golden('phonon')
+    rec = np.around(np.linalg.inv(cell['lattice']) * 2 * np.pi, decimals=6)
+    assert np.allclose(rec, g['mat_reciprocal_lattice'], rtol=0, atol=1e-6)
+    assert abs(abs(np.linalg.det(cell['lattice'])) / float(g['mat_volume_unitcell']) - 1) < 1e-9
+    R = crystal.reciprocal_operations(cell['lattice'], cell['numbers'], cell['positions'])
+    assert R.shape == (48, 3, 3)
+    S = {tuple(r.ravel()) for r in R}
+    assert all(tuple((a @ b).ravel()) in S for a in R for b in R)
+    assert tuple((-np.eye(3, dtype=int)).ravel()) in S
+
+
+def test_irreducible_wedge_round_trip():
+    """phono3py-style input (irreducible q-points + weights) -> expand_FBZ (Phonon.py:515-564) reproduces the full-mesh
+    tables it was reduced from: same q-point set, frequencies, rotated group velocities and linewidths."""
+    import os
+    from nanokappa_amd import crystal, synthetic
+    from nanokappa_amd.phonon import material_from_phono3py
+    here = os.path.dirname(os.path.abspath(__file__))
+    poscar = os.path.join(here, 'golden', 'POSCAR_Si')
+    full = synthetic.make_material(9, 'Si', temperatures=np.arange(250.0, 351.0, 50.0))
+    cell = crystal.read_poscar(poscar)
+    rot = crystal.reciprocal_operations(cell['lattice'], cell['numbers'], cell['positions'])
+    reps, weights = crystal.reduce_to_IBZ(full['q_points'], rot)
+    assert weights.sum() == 729 and reps.shape[0] < 60
+    data = dict(mesh=np.array([9, 9, 9]), qpoint=full['q_points'][reps], weight=weights,
+                frequency=full['frequency'][reps], group_velocity=full['group_vel'][reps],
+                temperature=full['temperature'], gamma=full['gamma'][:, reps, :])
+    m = material_from_phono3py(data, poscar)
+    assert m['q_points'].shape == (729, 3)
+
+    def keyed(q):
+        q = np.around(np.mod(q, 1.0), 6)
+        q = np.where(q == 1.0, 0.0, q)
+        return np.lexsort(q.T[::-1]), q
+
+    o1, q1 = keyed(m['q_points'])
+    o2, q2 = keyed(full['q_points'])
+    assert np.allclose(q1[o1], q2[o2], atol=1e-6)
+    assert np.allclose(m['frequency'][o1], full['frequency'][o2], rtol=0, atol=1e-12)
+    assert np.allclose(m['gamma'][:, o1, :], full['gamma'][:, o2, :], rtol=0, atol=1e-15)
+    # group velocities: rotated copies of the representative's; q-points on the zone boundary have several equally
+    # short images and the synthetic table picked one of them, so those are compared by length only
+    dv = np.abs(m['group_vel'][o1] - full['group_vel'][o2]).max(axis=(1, 2))
+    interior = dv < 1e-8
+    assert interior.mean() > 0.9
+    assert np.allclose(np.linalg.norm(m['group_vel'][o1], axis=2), np.linalg.norm(full['group_vel'][o2], axis=2), atol=1e-8)
