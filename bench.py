@@ -9,7 +9,8 @@ Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): synthetic Si (31^3 q-poi
 200 x 200 x 200 angstrom, 20 slices along x, BCs T T P (302 K / 298 K reservoirs on +-x, periodic sides), dt = 1 ps,
 1e7 particles PER GPU (weak scaling: the ensemble grows with N, the per-step tally is all-reduced over RCCL).
 A "step" is one Population.run_timestep: relax -> drift -> reservoir emission -> boundary events -> tally -> T update
-(kernels k_emit_count, k_sweep, k_reduce, k_update).
+(kernels k_sweep -- which also prepares the next step's emission -- and k_reduce with the fused update; with RCCL the
+all-reduce sits between k_reduce and k_update).
 Particles are resident in HBM before the timed region.  One JSON line is printed by rank 0.
 
 torch is used only as plumbing when WORLD_SIZE > 1 (gloo rendezvous: unique-id broadcast, barriers, max of the

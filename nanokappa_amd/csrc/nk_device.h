@@ -134,7 +134,7 @@ struct NkDev {
     int32_t *overflow;                // set when a particle had to be dropped for lack of capacity
     double *partials;                 // [rows][NB] per-workgroup tally rows
     int32_t NB;                       // bins per row = 5*S + 5*R + 1
-    int32_t dbg;                      // developer ablation mask (env NK_DEBUG; 0 in production): see k_step
+    int32_t dbg;                      // developer ablation mask (env NK_DEBUG; only read by the NK_ABLATE build, nk_kernels.h)
 };
 
 // ------------------------------------------------------------------------------------------------ RNG
