@@ -41,6 +41,17 @@ def read_poscar(path):
     return dict(lattice=lattice, species=species, numbers=numbers, positions=pos % 1.0)
 
 
+def write_poscar(path, lattice, species, counts, positions, comment='written by nanokappa_amd'):
+    """Minimal VASP-5 POSCAR (direct coordinates)."""
+    with open(path, 'w') as f:
+        f.write(comment + '\n   1.0\n')
+        for row in np.asarray(lattice, dtype=float):
+            f.write('   %22.16f %22.16f %22.16f\n' % tuple(row))
+        f.write('   ' + ' '.join(species) + '\n   ' + ' '.join(str(int(c)) for c in counts) + '\nDirect\n')
+        for row in np.asarray(positions, dtype=float):
+            f.write('  %19.16f %19.16f %19.16f\n' % tuple(row))
+
+
 def point_group(lattice, numbers, positions, tol=1e-5):
     """Rotation parts W (integer 3x3, acting on fractional coordinates x' = W x + t) of the space group of the crystal.
 

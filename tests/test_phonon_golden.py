@@ -55,14 +55,19 @@ def test_find_min_k():
     assert np.allclose(disp, g['s_kdisp'], atol=1e-12)
 
 
-def test_poscar_and_point_group():
+def diamond_poscar(path, species='Si'):
+    """Primitive diamond-structure cell on the synthetic materials' fcc lattice, as a POSCAR file."""
+    from nanokappa_amd import crystal, synthetic
+    crystal.write_poscar(str(path), synthetic.fcc_lattice(species), [species], [2], [[0.75, 0.75, 0.75], [0.5, 0.5, 0.5]])
+    return str(path)
+
+
+def test_poscar_and_point_group(tmp_path):
     """POSCAR -> lattice: reciprocal lattice and cell volume equal the values the reference obtained through phonopy
     (tests/golden/phonon.npz); the symmetry finder returns the 48 operations of the diamond structure, a closed group
     that contains the inversion (time reversal)."""
-    import os
     from nanokappa_amd import crystal
-    here = os.path.dirname(os.path.abspath(__file__))
-    cell = crystal.read_poscar(os.path.join(here, 'golden', 'POSCAR_Si'))
+    cell = crystal.read_poscar(diamond_poscar(tmp_path / 'POSCAR'))
     g = golden('phonon')
     rec = np.around(np.linalg.inv(cell['lattice']) * 2 * np.pi, decimals=6)
     assert np.allclose(rec, g['mat_reciprocal_lattice'], rtol=0, atol=1e-6)
@@ -74,14 +79,12 @@ def test_poscar_and_point_group():
     assert tuple((-np.eye(3, dtype=int)).ravel()) in S
 
 
-def test_irreducible_wedge_round_trip():
+def test_irreducible_wedge_round_trip(tmp_path):
     """phono3py-style input (irreducible q-points + weights) -> expand_FBZ (Phonon.py:515-564) reproduces the full-mesh
     tables it was reduced from: same q-point set, frequencies, rotated group velocities and linewidths."""
-    import os
     from nanokappa_amd import crystal, synthetic
     from nanokappa_amd.phonon import material_from_phono3py
-    here = os.path.dirname(os.path.abspath(__file__))
-    poscar = os.path.join(here, 'golden', 'POSCAR_Si')
+    poscar = diamond_poscar(tmp_path / 'POSCAR')
     full = synthetic.make_material(9, 'Si', temperatures=np.arange(250.0, 351.0, 50.0))
     cell = crystal.read_poscar(poscar)
     rot = crystal.reciprocal_operations(cell['lattice'], cell['numbers'], cell['positions'])
