@@ -468,8 +468,13 @@ class Population(Constants):
             if tm['slots'] > 0 and local > 0.7 * tm['slots']:
                 self.engine.reserve(int(2.0 * local) + 65536)
             t = self.engine.step(chunk)
-            for s in range(chunk):
-                self.current_timestep += 1
+            s0 = 0
+            while s0 < chunk:
+                # up to the next convergence step in one go: only the reservoir tallies accumulate in between
+                to_conv = self.n_dt_to_conv - (self.current_timestep % self.n_dt_to_conv)
+                s1 = min(chunk, s0 + to_conv)
+                s = s1 - 1
+                self.current_timestep += s1 - s0
                 self.t = self.current_timestep * self.dt
                 self.subvol_temperature = t['T_sv'][s]
                 self.subvol_energy = t['E_sv'][s]
@@ -478,14 +483,16 @@ class Population(Constants):
                 self.total_energy = float(t['E_raw'][s].sum())
                 if self.n_of_reservoirs > 0:
                     self.N_leaving = t['N_leaving'][s].astype(np.int64)
-                    self.res_energy_balance = self.res_energy_balance + t['res_energy'][s]
-                    self.res_heat_flux = self.res_heat_flux + t['res_flux'][s]
+                    for q in range(s0, s1):                     # same summation order as stepping one by one
+                        self.res_energy_balance = self.res_energy_balance + t['res_energy'][q]
+                        self.res_heat_flux = self.res_heat_flux + t['res_flux'][q]
                 if (self.current_timestep % self.n_dt_to_conv) == 0:                # Population.py:1762-1767
                     self.subvol_heat_flux = self._normalise_flux(phonon, t['flux_raw'][s], self.subvol_N_p)
                     self.calculate_kappa(geometry)
                     self.adjust_reservoir_balance(geometry, phonon)
                     self._record_convergence(geometry)
                     self.restart_reservoir_balance()
+                s0 = s1
             done += chunk
 
     def _every_hundred(self, geometry):
