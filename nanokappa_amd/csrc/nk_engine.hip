@@ -734,6 +734,7 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
         if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
         ctx->g_sweep = ctx->num_cu * per_cu;
         ctx->g_sweep_key = key;
+        if (getenv("NK_VERBOSE")) fprintf(stderr, "[nanokappa_hip] sweep: %d workgroups per CU (occupancy query rc %d), %zu B LDS each\n", per_cu, (int)e_, lds_w);
     }
     return ctx->g_sweep;
 }
