@@ -64,8 +64,11 @@ struct NkDev {
     double active_modes;
     // ---- mesh
     int32_t F, Fc, NP;                // faces, facets, distinct planes
-    const double *pgroups;            // [(NG+NS)*NK_GROUP_DOUBLES] plane groups, then super-groups, with bounding boxes (large meshes); or NG = 0
-    int32_t NG;
+    const double *tree_boxes;         // large meshes: node boxes (6 doubles) of the face tree, level by level; or NG = 0
+    const double *tree_faces;         // [tree_leaves * 4 * NK_TREE_FACE_DOUBLES] leaf face records (padded with null faces)
+    int32_t tree_base[8];             // first node of each level in tree_boxes
+    int32_t tree_top, tree_leaves;
+    int32_t NG;                       // 1: walk the face tree, 0: sweep all planes
     const double *planes;             // [NP*NK_PLANE_DOUBLES]
     const double *faces;              // [F*NK_FACE_DOUBLES], grouped by plane
     const NkFacet *facets;            // [Fc]
@@ -403,13 +406,16 @@ __device__ __forceinline__ void nk_find_boundary(const double *planes, const dou
     tc = h.t;
     fc = h.facet;
 }
-// Large meshes: the planes are sorted along a space-filling curve and cut into groups of NK_GROUP_PLANES; a group record
-// holds the (slightly inflated) bounding box of its faces.  A ray only visits the groups whose box it crosses before the
-// best hit so far -- a hit point lies inside its face's box, so nothing is lost and the result equals the plain sweep
-// (ties still go to the lowest face index, whatever the visiting order).
-#define NK_GROUP_PLANES 16
-#define NK_GROUP_DOUBLES 8       // lo(3) hi(3) {plane_begin, plane_end} pad
-#define NK_SUPER_GROUPS 8
+// Large meshes (tables in global memory): a 4-ary tree of bounding boxes over the FACES, walked by every lane on its own.
+// The faces are sorted along a space-filling curve; a leaf is 4 consecutive faces, node i of level l + 1 the union of
+// nodes 4i .. 4i + 3 of level l, so the tree is implicit (no child pointers) and the walk needs no stack: the only state
+// is the level, the index of the current family of four siblings, and four "still to visit" bits per level in one
+// register.  Boxes are slightly inflated; a ray only enters the boxes it crosses before the best hit so far, and a hit
+// point lies inside its face's box, so nothing is lost and the result equals the plain sweep (ties still go to the
+// lowest face index, whatever the visiting order).  The previous structure (two levels of wave-uniform groups of 16
+// planes) made a wave visit the union of its 64 rays' groups -- on a 5000-face wire nearly the whole mesh per batch.
+#define NK_TREE_LEVELS 8            // 4^8 leaves x 4 faces: meshes up to 262 144 faces
+#define NK_TREE_FACE_DOUBLES 20     // n(3) k | lo(3) hi(3) | o(3) iu(3) iw(3) {face, facet}
 // Does the ray x + t v, 0 <= t <= tmax, cross the box record B = lo.x lo.y | lo.z hi.x | hi.y hi.z ?  (inv = 1 / v)
 __device__ __forceinline__ bool nk_ray_box(const double2 b0, const double2 b1, const double2 b2, double x, double y, double z,
                                            double vx, double vy, double vz, double ix, double iy, double iz, double tmax) {
@@ -423,25 +429,74 @@ __device__ __forceinline__ bool nk_ray_box(const double2 b0, const double2 b1, c
     else miss |= (z < b1.x) | (z > b2.y);
     return !miss && t0 <= t1;
 }
-// Two levels: super-groups of NK_SUPER_GROUPS groups, then the groups, then their planes.  `groups` holds the NG group
-// records followed by the NS super-group records (same layout, the range then counts groups).
-__device__ __forceinline__ void nk_find_boundary_grouped(const double *groups, int NG, const double *planes,
-                                                         const double *faces, double tol, double x, double y, double z,
-                                                         double vx, double vy, double vz, double &tc, int &fc) {
+// The four faces of one leaf against one ray (same arithmetic and the same rounding as nk_fb_planes).
+__device__ __forceinline__ void nk_tree_leaf(const double *tree_faces, int leaf, double tol, double x, double y, double z,
+                                             double vx, double vy, double vz, NkHit &h) {
+#pragma clang fp contract(off)
+    const double2 *Q = reinterpret_cast<const double2 *>(tree_faces + (size_t)leaf * 4 * NK_TREE_FACE_DOUBLES);
+    double2 pn[4], pk[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { pn[c] = Q[10 * c]; pk[c] = Q[10 * c + 1]; }      // the plane parts, requested together
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const double num = x * pn[c].x + y * pn[c].y + z * pk[c].x + pk[c].y;
+        const double den = vx * pn[c].x + vy * pn[c].y + vz * pk[c].x;
+        if (!((num < 0.0 && den > 0.0) || (num > 0.0 && den < 0.0))) continue;     // padding faces have n = k = 0
+        const double t = -num / den;
+        if (!(t >= tol) || isinf(t) || t > h.t) continue;
+        const double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
+        const double2 *q = Q + 10 * c + 2;
+        const double2 q0 = q[0], q1 = q[1], q2 = q[2];              // lo.x lo.y | lo.z hi.x | hi.y hi.z
+        const bool inside = (cx >= q0.x - tol) & (cy >= q0.y - tol) & (cz >= q1.x - tol) & (cx <= q1.y + tol) &
+                            (cy <= q2.x + tol) & (cz <= q2.y + tol);
+        if (!inside) continue;
+        const double2 q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];   // o(3) iu(3) iw(3) {face, facet}
+        const double bx = cx - q3.x, by = cy - q3.y, bz = cz - q4.x;
+        const double u = q4.y * bx + q5.x * by + q5.y * bz;
+        const double w = q6.x * bx + q6.y * by + q7.x * bz;
+        const double r = 1.0 - (u + w);
+        if (!(u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol)) continue;
+        const int idf = __double2loint(q7.y), idc = __double2hiint(q7.y);
+        if (t < h.t || idf < h.face) { h.t = t; h.face = idf; h.facet = idc; }
+    }
+}
+__device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, double x, double y, double z, double vx, double vy,
+                                                      double vz, double &tc, int &fc) {
     NkHit h = {__builtin_inf(), 0x7fffffff, -1};
     const double ix = 1.0 / vx, iy = 1.0 / vy, iz = 1.0 / vz;         // +-inf for an axis-parallel ray: not used then
-    const int NS = (NG + NK_SUPER_GROUPS - 1) / NK_SUPER_GROUPS;
-    const double2 *SB = reinterpret_cast<const double2 *>(groups + (size_t)NG * NK_GROUP_DOUBLES);
-    for (int sg = 0; sg < NS; ++sg) {
-        const double2 s0 = SB[4 * sg], s1 = SB[4 * sg + 1], s2 = SB[4 * sg + 2], s3 = SB[4 * sg + 3];
-        if (!nk_ray_box(s0, s1, s2, x, y, z, vx, vy, vz, ix, iy, iz, h.t)) continue;
-        const int g0 = __double2loint(s3.x), g1 = __double2hiint(s3.x);
-        for (int g = g0; g < g1; ++g) {
-            const double2 *B = reinterpret_cast<const double2 *>(groups + (size_t)g * NK_GROUP_DOUBLES);
-            const double2 b0 = B[0], b1 = B[1], b2 = B[2], b3 = B[3];
-            if (!nk_ray_box(b0, b1, b2, x, y, z, vx, vy, vz, ix, iy, iz, h.t)) continue;
-            nk_fb_planes(planes, faces, __double2loint(b3.x), __double2hiint(b3.x), tol, x, y, z, vx, vy, vz, h);
+    const int top = d.tree_top, NL = d.tree_leaves;
+    int l = top, fam = 0;
+    uint32_t todo = 0;                  // bits 4l .. 4l + 3: siblings of the current family of level l still to visit
+    bool enter = true;
+    for (;;) {
+        if (enter) {                    // the four boxes of family `fam` of level l, requested together
+            int base = d.tree_base[0];
+#pragma unroll
+            for (int k = 1; k < NK_TREE_LEVELS; ++k) base = (l == k) ? d.tree_base[k] : base;
+            const int cnt = (NL + (1 << (2 * l)) - 1) >> (2 * l);
+            const double2 *B = reinterpret_cast<const double2 *>(d.tree_boxes + (size_t)(base + 4 * fam) * 6);
+            double2 b[12];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) b[k] = B[k];
+            uint32_t m = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (4 * fam + c < cnt && nk_ray_box(b[3 * c], b[3 * c + 1], b[3 * c + 2], x, y, z, vx, vy, vz, ix, iy, iz, h.t)) m |= 1u << c;
+            todo = (todo & ~(0xFu << (4 * l))) | (m << (4 * l));
+            enter = false;
         }
+        const uint32_t m = (todo >> (4 * l)) & 0xFu;
+        if (m == 0) {                   // family done: back to the parent's family
+            if (l == top) break;
+            ++l;
+            fam >>= 2;
+            continue;
+        }
+        const int c = __builtin_ctz(m);
+        todo &= ~(1u << (4 * l + c));
+        const int node = 4 * fam + c;
+        if (l > 0) { --l; fam = node; enter = true; }
+        else nk_tree_leaf(d.tree_faces, node, d.tol, x, y, z, vx, vy, vz, h);
     }
     tc = h.t;
     fc = h.facet;
@@ -507,7 +562,7 @@ struct NkParticle {
 #define NK_EV_DEAD 1
 #define NK_EV_MORE 2
 template <bool ROUGH, bool RBF = true>
-__device__ __forceinline__ int nk_event_one(const NkDev &d, const double *groups, int NG, const double *planes,
+__device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double *planes,
                                             const double *faces, const NkFacet *facets, const double *cen, const double *Tsv,
                                             const double *resT, NkBins &b, NkParticle &p, double &cts, uint32_t &ev,
                                             uint64_t pid, uint32_t step) {
@@ -558,7 +613,7 @@ __device__ __forceinline__ int nk_event_one(const NkDev &d, const double *groups
 #ifdef NK_ABLATE
         if (d.dbg & 32) { tc = 3.0 * dt; fcn = p.facet; } else
 #endif
-        if (NG > 0) nk_find_boundary_grouped(groups, NG, planes, faces, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
+        if (NG > 0) nk_find_boundary_tree(d, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
         else nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
         p.nts = tc / dt;
         p.facet = fcn;

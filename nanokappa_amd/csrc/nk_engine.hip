@@ -267,34 +267,8 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         members[found].push_back(f);
     }
     d.NP = (int)members.size();
-    // Large meshes (tables in global memory): order the planes along a Morton curve of their faces' box centres so that
-    // consecutive planes are neighbours in space; groups of NK_GROUP_PLANES then have tight bounding boxes.
-    const bool grouped = !(m->F <= NK_LDS_FACES && m->Fc <= NK_LDS_FACES) && !getenv("NK_NO_GROUPS");   // env: developer probe
-    if (grouped) {
-        std::vector<uint64_t> key(members.size());
-        double ext[3];
-        for (int k = 0; k < 3; ++k) ext[k] = std::max(m->bbox[3 + k] - m->bbox[k], 1e-300);
-        for (size_t pl = 0; pl < members.size(); ++pl) {
-            double c[3] = {0, 0, 0};
-            for (int f : members[pl]) for (int k = 0; k < 3; ++k) c[k] += 0.5 * (m->bounds_lo[3 * f + k] + m->bounds_hi[3 * f + k]);
-            uint64_t code = 0;
-            uint32_t q[3];
-            for (int k = 0; k < 3; ++k) {
-                double u = (c[k] / members[pl].size() - m->bbox[k]) / ext[k];
-                u = u < 0 ? 0 : (u > 1 ? 1 : u);
-                q[k] = (uint32_t)(u * 1023.0);
-            }
-            for (int b = 9; b >= 0; --b) for (int k = 0; k < 3; ++k) code = (code << 1) | ((q[k] >> b) & 1u);
-            key[pl] = code;
-        }
-        std::vector<size_t> order(members.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return key[a] < key[b]; });
-        std::vector<std::vector<int>> sorted;
-        for (size_t i : order) sorted.push_back(members[i]);
-        members.swap(sorted);
-    }
     std::vector<double> planes((size_t)d.NP * NK_PLANE_DOUBLES, 0.0), faces((size_t)m->F * NK_FACE_DOUBLES, 0.0);
+    std::vector<int> face_pos((size_t)m->F, 0);     // where face f went
     int pos = 0;
     for (int pl = 0; pl < d.NP; ++pl) {
         double *p = &planes[(size_t)pl * NK_PLANE_DOUBLES];
@@ -315,43 +289,90 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
             q[12] = (a12 * a20 - a10 * a22) / det; q[13] = (a00 * a22 - a02 * a20) / det; q[14] = (a02 * a10 - a00 * a12) / det;
             int32_t id[2] = {f, m->face_facet[f]};
             memcpy(q + 15, id, 8);
+            face_pos[f] = pos;
             ++pos;
         }
     }
+    // Large meshes (tables in global memory): the face tree of nk_find_boundary_tree.  Faces in Morton order of their box
+    // centres, leaves of 4, every level the unions of 4 consecutive nodes of the level below.
     d.NG = 0;
-    if (grouped) {
-        // group boxes: union of the member faces' boxes, inflated by far more than any rounding in the slab test
+    d.tree_top = 0; d.tree_leaves = 0;
+    for (int k = 0; k < NK_TREE_LEVELS; ++k) d.tree_base[k] = 0;
+    const bool use_tree = !(m->F <= NK_LDS_FACES && m->Fc <= NK_LDS_FACES) && !getenv("NK_NO_TREE") &&   // env: developer probe
+                          m->F <= 4 * (1 << (2 * NK_TREE_LEVELS));
+    if (use_tree) {
+        const int F = m->F;
+        std::vector<uint64_t> key((size_t)F);
+        double ext[3];
+        for (int k = 0; k < 3; ++k) ext[k] = std::max(m->bbox[3 + k] - m->bbox[k], 1e-300);
+        for (int f = 0; f < F; ++f) {
+            uint32_t q[3];
+            for (int k = 0; k < 3; ++k) {
+                double u = (0.5 * (m->bounds_lo[3 * f + k] + m->bounds_hi[3 * f + k]) - m->bbox[k]) / ext[k];
+                u = u < 0 ? 0 : (u > 1 ? 1 : u);
+                q[k] = (uint32_t)(u * 1023.0);
+            }
+            uint64_t code = 0;
+            for (int b = 9; b >= 0; --b) for (int k = 0; k < 3; ++k) code = (code << 1) | ((q[k] >> b) & 1u);
+            key[f] = code;
+        }
+        std::vector<int> order((size_t)F);
+        for (int i = 0; i < F; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
+        const int NL = (F + 3) / 4;
+        // leaf records: plane, box, barycentric rows; the padding faces keep n = k = 0 and can never be hit
+        std::vector<double> tf((size_t)NL * 4 * NK_TREE_FACE_DOUBLES, 0.0);
+        for (int i = 0; i < F; ++i) {
+            const int f = order[i];
+            double *q = &tf[(size_t)i * NK_TREE_FACE_DOUBLES];
+            const double *src = &faces[(size_t)face_pos[f] * NK_FACE_DOUBLES];
+            q[0] = m->normals[3 * f]; q[1] = m->normals[3 * f + 1]; q[2] = m->normals[3 * f + 2]; q[3] = m->k[f];
+            memcpy(q + 4, src, NK_FACE_DOUBLES * sizeof(double));
+        }
+        // boxes: union of the member faces' boxes, inflated by far more than any rounding in the slab test
         double big = 0.0;
         for (int k = 0; k < 6; ++k) big = std::max(big, fabs(m->bbox[k]));
         const double margin = m->tol + 1e-6 * (1.0 + big);
-        d.NG = (d.NP + NK_GROUP_PLANES - 1) / NK_GROUP_PLANES;
-        const int NS = (d.NG + NK_SUPER_GROUPS - 1) / NK_SUPER_GROUPS;
-        std::vector<double> groups((size_t)(d.NG + NS) * NK_GROUP_DOUBLES, 0.0);
-        for (int g = 0; g < d.NG; ++g) {
-            double *G = &groups[(size_t)g * NK_GROUP_DOUBLES];
-            const int p0 = g * NK_GROUP_PLANES, p1 = std::min(d.NP, p0 + NK_GROUP_PLANES);
-            for (int k = 0; k < 3; ++k) { G[k] = 1e300; G[3 + k] = -1e300; }
-            for (int pl = p0; pl < p1; ++pl)
-                for (int f : members[pl])
-                    for (int k = 0; k < 3; ++k) {
-                        G[k] = std::min(G[k], m->bounds_lo[3 * f + k] - margin);
-                        G[3 + k] = std::max(G[3 + k], m->bounds_hi[3 * f + k] + margin);
+        std::vector<double> boxes;
+        int count = NL, level = 0, prev_base = 0;
+        for (;;) {
+            const int padded = (count + 3) / 4 * 4, base = (int)(boxes.size() / 6);
+            d.tree_base[level] = base;
+            boxes.resize(boxes.size() + (size_t)padded * 6, 0.0);
+            for (int i = 0; i < count; ++i) {
+                double *B = &boxes[(size_t)(base + i) * 6];
+                for (int k = 0; k < 3; ++k) { B[k] = 1e300; B[3 + k] = -1e300; }
+                if (level == 0) {
+                    for (int c = 4 * i; c < std::min(F, 4 * i + 4); ++c) {
+                        const int f = order[c];
+                        for (int k = 0; k < 3; ++k) {
+                            B[k] = std::min(B[k], m->bounds_lo[3 * f + k] - margin);
+                            B[3 + k] = std::max(B[3 + k], m->bounds_hi[3 * f + k] + margin);
+                        }
                     }
-            int32_t rng[2] = {p0, p1};
-            memcpy(G + 6, rng, 8);
-        }
-        for (int sg = 0; sg < NS; ++sg) {                   // super-groups: unions of NK_SUPER_GROUPS consecutive groups
-            double *SG = &groups[(size_t)(d.NG + sg) * NK_GROUP_DOUBLES];
-            const int g0 = sg * NK_SUPER_GROUPS, g1 = std::min(d.NG, g0 + NK_SUPER_GROUPS);
-            for (int k = 0; k < 3; ++k) { SG[k] = 1e300; SG[3 + k] = -1e300; }
-            for (int g = g0; g < g1; ++g) {
-                const double *G = &groups[(size_t)g * NK_GROUP_DOUBLES];
-                for (int k = 0; k < 3; ++k) { SG[k] = std::min(SG[k], G[k]); SG[3 + k] = std::max(SG[3 + k], G[3 + k]); }
+                } else {
+                    const int below = (int)((size_t)(base - prev_base));   // nodes stored for the level below (padded)
+                    for (int c = 4 * i; c < 4 * i + 4 && c < below; ++c) {
+                        const double *C = &boxes[(size_t)(prev_base + c) * 6];
+                        if (C[0] > C[3]) continue;                          // padding node
+                        for (int k = 0; k < 3; ++k) { B[k] = std::min(B[k], C[k]); B[3 + k] = std::max(B[3 + k], C[3 + k]); }
+                    }
+                }
             }
-            int32_t rng[2] = {g0, g1};
-            memcpy(SG + 6, rng, 8);
+            for (int i = count; i < padded; ++i) {                          // padding nodes: never entered (index >= count)
+                double *B = &boxes[(size_t)(base + i) * 6];
+                for (int k = 0; k < 3; ++k) { B[k] = 1e300; B[3 + k] = -1e300; }
+            }
+            if (count <= 4) break;
+            prev_base = base;
+            count = (count + 3) / 4;
+            ++level;
         }
-        NK_UP(groups.data(), groups.size(), &d.pgroups);
+        d.tree_top = level;
+        d.tree_leaves = NL;
+        d.NG = 1;
+        NK_UP(boxes.data(), boxes.size(), &d.tree_boxes);
+        NK_UP(tf.data(), tf.size(), &d.tree_faces);
     }
     NK_UP(planes.data(), planes.size(), &d.planes);
     NK_UP(faces.data(), faces.size(), &d.faces);

@@ -194,7 +194,7 @@ __device__ __forceinline__ void nk_sample_res_face(const int *off, const double 
 // Ray cast as the kernels call it: grouped sweep for meshes whose tables stay in global memory, plain sweep over LDS.
 #define NK_RAY(GEOM, d, L, x, y, z, vx, vy, vz, tc, fc)                                                              \
     do {                                                                                                              \
-        if ((GEOM) == 2 && (d).NG > 0) nk_find_boundary_grouped((d).pgroups, (d).NG, (L).planes, (L).faces, (d).tol, x, y, z, vx, vy, vz, tc, fc); \
+        if ((GEOM) == 2 && (d).NG > 0) nk_find_boundary_tree(d, x, y, z, vx, vy, vz, tc, fc);                            \
         else nk_find_boundary((L).planes, (L).faces, (d).NP, (d).tol, x, y, z, vx, vy, vz, tc, fc);                   \
     } while (0)
 
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     const double4 ra = first ? pre : *reinterpret_cast<const double4 *>(d.modetab + p.mode);
                     p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                     p.alive = true;
-                    st = nk_event_one<ROUGH, RBF>(d, d.pgroups, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, cts, evc, ppid, step);
+                    st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, cts, evc, ppid, step);
                 }
                 first = false;
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
