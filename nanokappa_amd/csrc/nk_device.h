@@ -468,8 +468,14 @@ __device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, double x, 
     int l = top, fam = 0;
     uint32_t todo = 0;                  // bits 4l .. 4l + 3: siblings of the current family of level l still to visit
     bool enter = true;
+#ifdef NK_TREE_STATS
+    int n_enter = 0, n_leaf = 0;
+#endif
     for (;;) {
         if (enter) {                    // the four boxes of family `fam` of level l, requested together
+#ifdef NK_TREE_STATS
+            ++n_enter;
+#endif
             int base = d.tree_base[0];
 #pragma unroll
             for (int k = 1; k < NK_TREE_LEVELS; ++k) base = (l == k) ? d.tree_base[k] : base;
@@ -496,10 +502,19 @@ __device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, double x, 
         todo &= ~(1u << (4 * l + c));
         const int node = 4 * fam + c;
         if (l > 0) { --l; fam = node; enter = true; }
-        else nk_tree_leaf(d.tree_faces, node, d.tol, x, y, z, vx, vy, vz, h);
+        else {
+            nk_tree_leaf(d.tree_faces, node, d.tol, x, y, z, vx, vy, vz, h);
+#ifdef NK_TREE_STATS
+            ++n_leaf;
+#endif
+        }
     }
     tc = h.t;
     fc = h.facet;
+#ifdef NK_TREE_STATS
+    tc = (double)n_enter;       // developer probe (make stats): visits instead of the hit
+    fc = n_leaf;
+#endif
 }
 
 // ---------------------------------------------------------------------------------- rough reflection

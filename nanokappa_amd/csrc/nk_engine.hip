@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -246,6 +247,55 @@ int nk_set_material(nk_ctx *ctx, const nk_material *m) {
     return NK_OK;
 }
 
+// One reference of the face tree: a face and the box of the piece of it this reference stands for.
+struct NkFaceRef { int face; double lo[3], hi[3]; };
+// Cuts the (convex, planar) polygon P at the plane x_axis = c; keeps the side `upper`.
+static int nk_clip_polygon(const double (*P)[3], int n, int axis, double c, bool upper, double (*out)[3]) {
+    int no = 0;
+    for (int i = 0; i < n; ++i) {
+        const double *A = P[i], *B = P[(i + 1) % n];
+        const bool ina = upper ? A[axis] >= c : A[axis] <= c, inb = upper ? B[axis] >= c : B[axis] <= c;
+        if (ina) { for (int k = 0; k < 3; ++k) out[no][k] = A[k]; ++no; }
+        if (ina != inb) {
+            const double t = (c - A[axis]) / (B[axis] - A[axis]);
+            for (int k = 0; k < 3; ++k) out[no][k] = A[k] + t * (B[k] - A[k]);
+            out[no][axis] = c;
+            ++no;
+        }
+    }
+    return no;
+}
+static void nk_split_polygon(const double (*P)[3], int n, int face, int depth, std::vector<NkFaceRef> &refs) {
+    NkFaceRef r;
+    r.face = face;
+    for (int k = 0; k < 3; ++k) { r.lo[k] = 1e300; r.hi[k] = -1e300; }
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < 3; ++k) { r.lo[k] = std::min(r.lo[k], P[i][k]); r.hi[k] = std::max(r.hi[k], P[i][k]); }
+    double area2[3] = {0, 0, 0};                        // twice the polygon's vector area
+    for (int i = 1; i + 1 < n; ++i) {
+        double a[3], b[3];
+        for (int k = 0; k < 3; ++k) { a[k] = P[i][k] - P[0][k]; b[k] = P[i + 1][k] - P[0][k]; }
+        area2[0] += a[1] * b[2] - a[2] * b[1]; area2[1] += a[2] * b[0] - a[0] * b[2]; area2[2] += a[0] * b[1] - a[1] * b[0];
+    }
+    const double area = 0.5 * sqrt(area2[0] * area2[0] + area2[1] * area2[1] + area2[2] * area2[2]);
+    const double e[3] = {r.hi[0] - r.lo[0], r.hi[1] - r.lo[1], r.hi[2] - r.lo[2]};
+    const double box_area = e[0] * e[1] + e[1] * e[2] + e[0] * e[2];      // half the box's surface
+    int axis = 0;
+    for (int k = 1; k < 3; ++k) if (e[k] > e[axis]) axis = k;
+    if (depth <= 0 || n < 3 || n > 12 || !(box_area > 3.0 * area) || !(e[axis] > 0.0)) { refs.push_back(r); return; }
+    const double c = 0.5 * (r.lo[axis] + r.hi[axis]);
+    double lo[16][3], hi[16][3];
+    const int nl = nk_clip_polygon(P, n, axis, c, false, lo), nh = nk_clip_polygon(P, n, axis, c, true, hi);
+    if (nl < 3 || nh < 3) { refs.push_back(r); return; }
+    nk_split_polygon(lo, nl, face, depth - 1, refs);
+    nk_split_polygon(hi, nh, face, depth - 1, refs);
+}
+static void nk_split_face(const double *V, int face, int max_depth, std::vector<NkFaceRef> &refs) {
+    double P[16][3];
+    for (int a = 0; a < 3; ++a) for (int k = 0; k < 3; ++k) P[a][k] = V[3 * a + k];
+    nk_split_polygon(P, 3, face, max_depth, refs);
+}
+
 int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
     NK_ARG(ctx && m, "nk_set_mesh: NULL argument");
     NK_ARG(m->F > 0 && m->Fc > 0, "nk_set_mesh: empty mesh");
@@ -298,33 +348,78 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
     d.NG = 0;
     d.tree_top = 0; d.tree_leaves = 0;
     for (int k = 0; k < NK_TREE_LEVELS; ++k) d.tree_base[k] = 0;
-    const bool use_tree = !(m->F <= NK_LDS_FACES && m->Fc <= NK_LDS_FACES) && !getenv("NK_NO_TREE") &&   // env: developer probe
-                          m->F <= 4 * (1 << (2 * NK_TREE_LEVELS));
+    bool use_tree = !(m->F <= NK_LDS_FACES && m->Fc <= NK_LDS_FACES) && !getenv("NK_NO_TREE");   // env: developer probe
+    std::vector<NkFaceRef> refs;
     if (use_tree) {
-        const int F = m->F;
-        std::vector<uint64_t> key((size_t)F);
-        double ext[3];
-        for (int k = 0; k < 3; ++k) ext[k] = std::max(m->bbox[3 + k] - m->bbox[k], 1e-300);
-        for (int f = 0; f < F; ++f) {
-            uint32_t q[3];
-            for (int k = 0; k < 3; ++k) {
-                double u = (0.5 * (m->bounds_lo[3 * f + k] + m->bounds_hi[3 * f + k]) - m->bbox[k]) / ext[k];
-                u = u < 0 ? 0 : (u > 1 ? 1 : u);
-                q[k] = (uint32_t)(u * 1023.0);
-            }
-            uint64_t code = 0;
-            for (int b = 9; b >= 0; --b) for (int k = 0; k < 3; ++k) code = (code << 1) | ((q[k] >> b) & 1u);
-            key[f] = code;
+        // A sliver lying diagonally has a box far larger than itself (the 1250 fan triangles of a wire's cap each cover an
+        // eighth of the cap), so such faces enter the tree as several references, each with the box of one piece of the
+        // triangle.  The face test itself is unchanged: a face met twice gives the same answer twice.
+        const int max_depth = getenv("NK_TREE_SPLIT") ? atoi(getenv("NK_TREE_SPLIT")) : 4;
+        for (int f = 0; f < m->F; ++f) nk_split_face(m->vertices + 9 * (size_t)f, f, max_depth, refs);
+        if (refs.size() > (size_t)4 * (1 << (2 * NK_TREE_LEVELS))) {      // too many for the implicit tree: whole faces
+            refs.clear();
+            for (int f = 0; f < m->F; ++f) nk_split_face(m->vertices + 9 * (size_t)f, f, 0, refs);
         }
-        std::vector<int> order((size_t)F);
+        use_tree = refs.size() <= (size_t)4 * (1 << (2 * NK_TREE_LEVELS));
+    }
+    if (use_tree) {
+        const int F = (int)refs.size();
+        // Shape: `top` levels of 4 below a top family of c = 2..4 nodes, every node present, so that the walk's index
+        // arithmetic needs no child pointers; leaves hold 2 to 4 references.  Contents: top-down, every node's references
+        // dealt evenly to its children after ordering them along the longest axis of their centres (median cuts) --
+        // consecutive Morton codes cut at fixed counts gave boxes that a ray entered 35-45 times per cast.
+        int top = 0;
+        while ((int64_t)4 << (2 * top) < (int64_t)(F + 3) / 4) ++top;
+        const int per_top = 1 << (2 * top);                                    // leaves below one node of the top family
+        const int c_top = std::max(1, (int)(((int64_t)(F + 3) / 4 + per_top - 1) / per_top));
+        const int NL = c_top * per_top;
+        std::vector<int> order((size_t)F), slot((size_t)NL * 4, -1);
         for (int i = 0; i < F; ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return key[a] < key[b]; });
-        const int NL = (F + 3) / 4;
+        std::vector<double> cen((size_t)F * 3);
+        for (int i = 0; i < F; ++i) for (int k = 0; k < 3; ++k) cen[3 * (size_t)i + k] = 0.5 * (refs[i].lo[k] + refs[i].hi[k]);
+        // cut [a, b) into parts of the given sizes along the longest axis of the centres, two groups at a time
+        std::function<void(int, int, const int *, int)> cut = [&](int a, int b, const int *sizes, int n) {
+            if (n <= 1 || b - a <= 1) return;
+            double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+            for (int i = a; i < b; ++i)
+                for (int k = 0; k < 3; ++k) { lo[k] = std::min(lo[k], cen[3 * (size_t)order[i] + k]); hi[k] = std::max(hi[k], cen[3 * (size_t)order[i] + k]); }
+            int axis = 0;
+            for (int k = 1; k < 3; ++k) if (hi[k] - lo[k] > hi[axis] - lo[axis]) axis = k;
+            const int nl = n / 2;
+            int left = 0;
+            for (int i = 0; i < nl; ++i) left += sizes[i];
+            if (left > 0 && left < b - a)
+                std::nth_element(order.begin() + a, order.begin() + a + left, order.begin() + b, [&](int p, int q) {
+                    const double cp = cen[3 * (size_t)p + axis], cq = cen[3 * (size_t)q + axis];
+                    return cp < cq || (cp == cq && p < q);
+                });
+            cut(a, a + left, sizes, nl);
+            cut(a + left, b, sizes + nl, n - nl);
+        };
+        std::function<void(int, int, int, int)> deal = [&](int a, int b, int level, int node) {   // node of `level` gets [a, b)
+            if (level == 0) {
+                for (int i = a; i < b; ++i) slot[(size_t)4 * node + (i - a)] = order[i];
+                return;
+            }
+            int sizes[4];
+            for (int k = 0; k < 4; ++k) sizes[k] = (b - a) / 4 + (k < (b - a) % 4 ? 1 : 0);
+            cut(a, b, sizes, 4);
+            int pos = a;
+            for (int k = 0; k < 4; ++k) { deal(pos, pos + sizes[k], level - 1, 4 * node + k); pos += sizes[k]; }
+        };
+        {
+            int sizes[4] = {0, 0, 0, 0};
+            for (int k = 0; k < c_top; ++k) sizes[k] = F / c_top + (k < F % c_top ? 1 : 0);
+            cut(0, F, sizes, c_top);
+            int pos = 0;
+            for (int k = 0; k < c_top; ++k) { deal(pos, pos + sizes[k], top, k); pos += sizes[k]; }
+        }
         // leaf records: plane, box, barycentric rows; the padding faces keep n = k = 0 and can never be hit
         std::vector<double> tf((size_t)NL * 4 * NK_TREE_FACE_DOUBLES, 0.0);
-        for (int i = 0; i < F; ++i) {
-            const int f = order[i];
-            double *q = &tf[(size_t)i * NK_TREE_FACE_DOUBLES];
+        for (size_t i = 0; i < slot.size(); ++i) {
+            if (slot[i] < 0) continue;
+            const int f = refs[slot[i]].face;
+            double *q = &tf[i * NK_TREE_FACE_DOUBLES];
             const double *src = &faces[(size_t)face_pos[f] * NK_FACE_DOUBLES];
             q[0] = m->normals[3 * f]; q[1] = m->normals[3 * f + 1]; q[2] = m->normals[3 * f + 2]; q[3] = m->k[f];
             memcpy(q + 4, src, NK_FACE_DOUBLES * sizeof(double));
@@ -332,7 +427,17 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         // boxes: union of the member faces' boxes, inflated by far more than any rounding in the slab test
         double big = 0.0;
         for (int k = 0; k < 6; ++k) big = std::max(big, fabs(m->bbox[k]));
+        // ... and, for a piece of a face, by the slack of the barycentric test (a point accepted with u = -tol lies
+        // tol * |edge| outside the triangle)
         const double margin = m->tol + 1e-6 * (1.0 + big);
+        std::vector<double> slack((size_t)m->F);
+        for (int f = 0; f < m->F; ++f) {
+            const double *V = m->vertices + 9 * (size_t)f;
+            double e = 0.0;
+            for (int a = 0; a < 3; ++a)
+                for (int k = 0; k < 3; ++k) e = std::max(e, fabs(V[3 * a + k] - V[3 * ((a + 1) % 3) + k]));
+            slack[f] = margin + 8.0 * m->tol * e;
+        }
         std::vector<double> boxes;
         int count = NL, level = 0, prev_base = 0;
         for (;;) {
@@ -343,11 +448,12 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
                 double *B = &boxes[(size_t)(base + i) * 6];
                 for (int k = 0; k < 3; ++k) { B[k] = 1e300; B[3 + k] = -1e300; }
                 if (level == 0) {
-                    for (int c = 4 * i; c < std::min(F, 4 * i + 4); ++c) {
-                        const int f = order[c];
+                    for (int c = 4 * i; c < 4 * i + 4; ++c) {
+                        if (slot[c] < 0) continue;
+                        const NkFaceRef &r = refs[slot[c]];
                         for (int k = 0; k < 3; ++k) {
-                            B[k] = std::min(B[k], m->bounds_lo[3 * f + k] - margin);
-                            B[3 + k] = std::max(B[3 + k], m->bounds_hi[3 * f + k] + margin);
+                            B[k] = std::min(B[k], r.lo[k] - slack[r.face]);
+                            B[3 + k] = std::max(B[3 + k], r.hi[k] + slack[r.face]);
                         }
                     }
                 } else {
@@ -1078,9 +1184,19 @@ int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x, const double *v, d
     NK_DEV_IN(double, dx, x, n * 3); NK_DEV_IN(double, dv, v, n * 3);
     NK_DEV_IN(double, dxc, (double *)nullptr, n * 3); NK_DEV_IN(double, dtc, (double *)nullptr, n);
     NK_DEV_IN(int32_t, dfc, (int32_t *)nullptr, n);
+    const bool verbose = getenv("NK_VERBOSE") != nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (verbose) { NK_HIP(hipEventCreate(&e0)); NK_HIP(hipEventCreate(&e1)); NK_HIP(hipEventRecord(e0, ctx->stream)); }
     NK_GEOM_LAUNCH(k_tap_find_boundary, (int)((n + NK_WG - 1) / NK_WG), nk_lds(ctx, true), d, n, dx, dv, dxc, dtc, dfc);
     NK_HIP(hipGetLastError());
+    if (verbose) NK_HIP(hipEventRecord(e1, ctx->stream));
     NK_HIP(hipStreamSynchronize(ctx->stream));
+    if (verbose) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, e0, e1);
+        fprintf(stderr, "[nanokappa_hip] find_boundary: %lld rays in %.3f ms\n", (long long)n, ms);
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
     NK_DEV_OUT(double, dxc, xc, n * 3); NK_DEV_OUT(double, dtc, tc, n); NK_DEV_OUT(int32_t, dfc, fc, n);
     hipFree(dx); hipFree(dv);
     return NK_OK;

@@ -191,7 +191,11 @@ class Mesh(object):
         v = np.atleast_2d(np.asarray(v, dtype=float))
         n, k, tol = self.face_normals, self.face_k, self.tol
         with np.errstate(divide='ignore', invalid='ignore', over='ignore'):
-            t = -(x @ n.T + k) / (v @ n.T)
+            # products summed in the order of the reference's np.sum(..., axis=2) and without fused multiply-adds (a BLAS
+            # product may fuse): x.n + k cancels near a face, so the rounding shows in t
+            xn = (x[:, 0:1] * n[:, 0] + x[:, 1:2] * n[:, 1]) + x[:, 2:3] * n[:, 2]
+            vn = (v[:, 0:1] * n[:, 0] + v[:, 1:2] * n[:, 1]) + v[:, 2:3] * n[:, 2]
+            t = -(xn + k) / vn
         ok = (t >= tol) & np.isfinite(t)
         ip, jf = np.nonzero(ok)
         c = x[ip] + t[ip, jf][:, None] * v[ip]

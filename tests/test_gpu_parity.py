@@ -36,27 +36,35 @@ def test_find_boundary(name):
     assert np.allclose(xc[hit], g['ray_xc'][hit], rtol=1e-12, atol=1e-9)
 
 
-def test_find_boundary_large_mesh_grouped():
-    """1600-face wire: the tables stay in global memory and the ray caster visits bounding-box groups of planes.
+LARGE_MESHES = {
+    'wire1600': ['--geometry', 'cylinder', '--dimensions', '2000', '200', '400', '--subvolumes', 'slice', '20', '2'],
+    # diagonal slivers everywhere: the star's flanks and cap fans are split into several tree references each
+    'star': ['--geometry', 'star', '--dimensions', '600', '200', '90', '72', '--subvolumes', 'slice', '4', '2'],
+}
+
+
+@pytest.mark.parametrize('name', sorted(LARGE_MESHES))
+def test_find_boundary_large_mesh_tree(name):
+    """Meshes whose tables stay in global memory: every lane walks the 4-ary box tree over the (split) faces.
     Must equal the plain all-faces evaluation (this package's NumPy Mesh.find_boundary, itself checked against the
-    reference goldens in test_host_geometry) ray by ray, including rays that start outside or run along an axis."""
+    reference goldens in test_host_geometry) ray by ray, including rays that start on the surface, outside, or run
+    along an axis."""
     from nanokappa_amd.argument_parser import initialise_parser
     from nanokappa_amd.geometry import Geometry
     from nanokappa_amd.engine import Engine
-    argv = ['--geometry', 'cylinder', '--dimensions', '2000', '200', '400', '--subvolumes', 'slice', '20', '2',
-            '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
-            '--bound_values', '302', '298', '5'] + COMMON_ARGS
+    argv = LARGE_MESHES[name] + ['--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+                                 '--bound_values', '302', '298', '5'] + COMMON_ARGS
     args = initialise_parser().parse_args(argv)
     args.results_folder = ''
     geo = Geometry(args)
-    assert geo.mesh.n_of_faces == 1600
+    assert geo.mesh.n_of_faces > 256
     ph = golden_phonon()
     eng = Engine(0, 1)
     eng.set_material(ph.tables())
     eng.set_mesh(geo.tables())
     eng.set_subvolumes(geo.subvol_center, geo.subvol_volume, 0, geo.slice_axis, 1, np.full(geo.n_of_subvols, 300.0))
     rng = np.random.default_rng(5)
-    n = 3000
+    n = 4000
     b = geo.mesh.bounds
     x = geo.mesh.sample_volume(n, rng)
     v = rng.normal(size=(n, 3)) * 40.0
@@ -64,6 +72,11 @@ def test_find_boundary_large_mesh_grouped():
     v[50:100, 2] = 0.0                                        # in the cross-section
     x[100:150] = b[1] + 7.0                                   # outside: mostly misses
     x[150:200, 2] = b[0, 2]                                   # on an end cap
+    # from points of the surface itself (where reflected and entering particles start): first hits of other rays
+    x0, t0, f0 = geo.mesh.find_boundary(x[1000:3000].copy(), v[1000:3000].copy())
+    ok = np.isfinite(t0)
+    x[1000:3000][ok] = x0[ok]
+    v[1000:3000] = rng.normal(size=(2000, 3)) * 40.0
     xr, tr, fr = geo.mesh.find_boundary(x.copy(), v.copy())
     xc, tc, fc = eng.find_boundary(x, v)
     assert np.array_equal(fc, fr)
