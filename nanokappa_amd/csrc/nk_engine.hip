@@ -885,6 +885,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
     d.nseg = (int32_t)nseg;
     d.segcap = (int32_t)segcap;
     d.cap = nseg * segcap;
+    ctx->timing.slots = d.cap;
     const double *pd; const int32_t *pi; const uint64_t *pu;
 #define NK_PALLOC(T, field, ptr, count)                                                                \
     do { int rc_ = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (rc_) return rc_; d.field = (T *)ptr; } while (0)
@@ -906,7 +907,41 @@ int nk_reserve(nk_ctx *ctx, int64_t capacity) {
     if (capacity <= d.cap) return NK_OK;
     NkHostParticles h;
     const bool had = d.cap > 0;
-    if (had) { int rc = nk_gather_live(ctx, h, true); if (rc) return rc; }
+    if (had) {
+        // Same number of segments before and after (every large ensemble: one segment per resident wave): the segments
+        // grow in place on the device.  Otherwise the particles are re-dealt through the host.
+        NK_HIP(hipStreamSynchronize(ctx->stream));
+        const NkDev old = d;
+        std::vector<void *> old_allocs;
+        old_allocs.swap(ctx->pallocs);
+        int rc = nk_alloc_particles(ctx, capacity);
+        if (rc) { for (void *p : old_allocs) hipFree(p); return rc; }
+        if (d.nseg == old.nseg && d.segcap >= old.segcap) {
+            k_regrow<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(old, d);
+            NK_HIP(hipGetLastError());
+            std::vector<int32_t> cnt((size_t)d.nseg);
+            NK_HIP(hipMemcpy(cnt.data(), old.seg_count, (size_t)d.nseg * 4, hipMemcpyDeviceToHost));
+            NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
+            std::vector<int64_t> fp((size_t)d.nseg + 1, 0);
+            for (int sgm = 0; sgm < d.nseg; ++sgm) {              // same rule as nk_update_body
+                const int fs = d.segcap - cnt[sgm];
+                fp[sgm + 1] = fp[sgm] + ((d.segcap < NK_QUANT_SEGCAP || fs >= NK_MIN_FREE) ? fs : 0);
+            }
+            NK_HIP(hipMemcpy(d.seg_free_prefix, fp.data(), fp.size() * 8, hipMemcpyHostToDevice));
+            NK_HIP(hipStreamSynchronize(ctx->stream));
+            for (void *p : old_allocs) hipFree(p);
+            ctx->h_seg_count = cnt;
+            return NK_OK;
+        }
+        // different segmentation: back to the old store for the gather, then allocate again
+        std::vector<void *> new_allocs;
+        new_allocs.swap(ctx->pallocs);
+        for (void *p : new_allocs) hipFree(p);
+        ctx->pallocs.swap(old_allocs);
+        d = old;
+        rc = nk_gather_live(ctx, h, true);
+        if (rc) return rc;
+    }
     int rc = nk_alloc_particles(ctx, capacity);
     if (rc) return rc;
     if (had && !h.x.empty())

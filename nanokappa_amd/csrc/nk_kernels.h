@@ -544,6 +544,19 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
     nk_lds_flush(d, L, blockIdx.x);
 }
 
+// nk_reserve with an unchanged number of segments: every segment's particles move to the start of its longer successor.
+__global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkDev n) {
+    for (int seg = blockIdx.x; seg < o.nseg; seg += gridDim.x) {
+        const int cnt = o.seg_count[seg];
+        const int64_t a = (int64_t)seg * o.segcap, b = (int64_t)seg * n.segcap;
+        for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+            n.x[b + i] = o.x[a + i]; n.y[b + i] = o.y[a + i]; n.z[b + i] = o.z[a + i];
+            n.occ[b + i] = o.occ[a + i]; n.nts[b + i] = o.nts[a + i];
+            n.mode[b + i] = o.mode[a + i]; n.facet[b + i] = o.facet[a + i]; n.pid[b + i] = o.pid[a + i];
+        }
+    }
+}
+
 // Normalise, invert E(T), publish the new subvolume temperatures, history row: calculate_energy (Population.py:719-728)
 // + refresh_temperatures (:692), run by ONE workgroup.
 // History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, 0, 0, overflow

@@ -153,7 +153,7 @@ class Population(Constants):
         if comm is not None and self.nranks > 1:
             self.engine.comm_init(comm[0], self.rank, self.nranks)
         J = phonon.number_of_branches
-        self.engine.reserve(int(1.3 * pos.shape[0]) + 65536)
+        self.engine.reserve(int(1.5 * pos.shape[0]) + 65536)
         self.engine.upload(pos, (modes[:, 0] * J + modes[:, 1]).astype(np.int32), occ, pid_offset=self.pid_lo)
         print('Getting first boundary collisions...')
         self.engine.init_boundaries()
@@ -465,7 +465,7 @@ class Population(Constants):
             # before it can fill up (this rank's share of N_p against the engine's slots)
             tm = self.engine.timing()
             local = self.N_p / max(self.nranks, 1)
-            if tm['slots'] > 0 and local > 0.7 * tm['slots']:
+            if tm['slots'] > 0 and local > 0.8 * tm['slots']:
                 self.engine.reserve(int(2.0 * local) + 65536)
             t = self.engine.step(chunk)
             s0 = 0

@@ -365,15 +365,20 @@ def test_specular_pairs_on_device_equal_host_builder():
     eng.close()
 
 
-def test_reserve_mid_run_preserves_state():
-    """nk_reserve between steps re-lays the particle store out (new segment count, mode-sorted): the deferred
-    relaxation and the prepared emission of the next step must survive, i.e. the run continues exactly like the oracle."""
-    ct = case_tables('ttrrp')
-    pos, mode, occ, counter = random_population(ct, 30000, seed=15)
+@pytest.mark.parametrize('case,n,new_cap', [('ttrrp', 30000, 400000), ('ttp', 1100000, 3000000)])
+def test_reserve_mid_run_preserves_state(case, n, new_cap):
+    """nk_reserve between steps re-lays the particle store out -- through the host when the number of segments changes
+    (new segment count, mode-sorted), on the device when it does not (1.1e6 particles: one segment per resident wave
+    before and after, every segment grows in place): the deferred relaxation and the prepared emission of the next
+    step must survive, i.e. the run continues exactly like the oracle."""
+    ct = case_tables(case)
+    pos, mode, occ, counter = random_population(ct, n, seed=15)
     sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=8)
     eng = make_engine(ct, pos, mode, occ, counter, seed=8)
     t1 = eng.step(7)
-    eng.reserve(400000)
+    slots0 = eng.timing()['slots']
+    eng.reserve(new_cap)
+    assert eng.timing()['slots'] >= new_cap > slots0
     t2 = eng.step(8)
     T = np.concatenate((t1['T_sv'], t2['T_sv']))
     N = np.concatenate((t1['N_sv'], t2['N_sv']))
