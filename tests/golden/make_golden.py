@@ -513,7 +513,7 @@ def run_stats(case, seed, particles=100000, steps=1000, extra=()):
         if pop.current_timestep % 10 == 0:
             if geo.subvol_type == 'slice':
                 rows.append(np.concatenate(([pop.current_timestep, pop.N_p, pop.kappa],
-                                            pop.subvol_temperature, pop.subvol_heat_flux[:, 0],
+                                            pop.subvol_temperature, pop.subvol_heat_flux[:, geo.slice_axis],
                                             pop.subvol_N_p, pop.subvol_kappa)))
             else:       # step, N_p, T[S], phi[S*3], Np[S], connection kappas[C]
                 rows.append(np.concatenate(([pop.current_timestep, pop.N_p], pop.subvol_temperature,
@@ -524,11 +524,12 @@ def run_stats(case, seed, particles=100000, steps=1000, extra=()):
 
 # statistical cases that are a base BC set + extra reference flags
 CASE_EXTRA = {'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one'])}
+CASE_PARTICLES = {'wire': 50000}       # the reference does 1e5 phonon-steps/s on the 400-face wire; others run 1e5 particles
 
 
 def gen_stats_one(case, seed):
     base, extra = CASE_EXTRA.get(case, (case, []))
-    rows, wall, nsum = run_stats(base, seed, extra=extra)
+    rows, wall, nsum = run_stats(base, seed, particles=CASE_PARTICLES.get(case, 100000), extra=extra)
     np.savez_compressed(os.path.join(HERE, '_stats_%s_%d.npz' % (case, seed)),
                         rows=rows, wall=np.array(wall), phonon_steps=np.array(nsum))
     print(case, seed, 'wall', wall, 'phonon-steps/s', nsum / wall)
@@ -536,7 +537,7 @@ def gen_stats_one(case, seed):
 
 def gen_stats_merge():
     import glob
-    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332', 'film', 'box_grid332_rbf'):
+    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332', 'film', 'box_grid332_rbf', 'wire'):
         files = sorted(glob.glob(os.path.join(HERE, '_stats_%s_[0-9]*.npz' % case)))
         if not files:
             continue

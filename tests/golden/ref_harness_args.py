@@ -22,6 +22,14 @@ FILM_TTP = ['--geometry', 'box', '--dimensions', '2000', '500', '500',
             '--connect_pos', 'relative', '.5', '0', '.5', '.5', '1', '.5', '.5', '.5', '0', '.5', '.5', '1',
             '--bound_values', '302', '298']
 
+# BASELINE config 4 in small: wire along z with 100 sides (400 triangles: the engine keeps such a mesh in global memory and
+# walks the face tree), caps at 302 / 298 K, rough side wall (eta = 5 A)
+WIRE = ['--geometry', 'cylinder', '--dimensions', '600', '100', '100',
+        '--subvolumes', 'slice', '20', '2',
+        '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1',
+        '--bound_cond', 'T', 'T', 'R',
+        '--bound_values', '302', '298', '5']
+
 COMMON = ['--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
           '--reference_temp', 'local', '--temp_dist', 'cold', '--temp_interp', 'linear',
           '--part_dist', 'random_subvol', '--timestep', '1', '--n_mean', '10',
@@ -30,6 +38,6 @@ COMMON = ['--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
 
 
 def argv_for(case, particles, iterations=1000, extra=()):
-    base = {'ttp': BOX_TTP, 'ttrrp': BOX_TTRRP, 'film': FILM_TTP}[case]
+    base = {'ttp': BOX_TTP, 'ttrrp': BOX_TTRRP, 'film': FILM_TTP, 'wire': WIRE}[case]
     return list(base) + list(COMMON) + ['--particles', 'total', str(particles),
                                         '--iterations', str(iterations)] + list(extra)

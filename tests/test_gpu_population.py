@@ -38,13 +38,15 @@ def window_stats(rows, lo=50):
     return T, phi, kap, Np
 
 
-STAT_CASES = {'ttp': ('ttp', []), 'ttrrp': ('ttrrp', []), 'film': ('film', []),
+STAT_CASES = {'ttp': ('ttp', []), 'ttrrp': ('ttrrp', []), 'film': ('film', []), 'wire': ('wire', []),
               'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one'])}      # same table as make_golden.CASE_EXTRA
+STAT_PARTICLES = {'wire': 50000}                                          # make_golden.CASE_PARTICLES
 
 
-@pytest.mark.parametrize('case', ['ttp', 'ttrrp', 'ttp_o2o', 'film'])
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp', 'ttp_o2o', 'film', 'wire'])
 def test_statistical_parity_with_reference(case, tmp_path):
-    """Same configuration as the reference goldens (C1a / C1b of SURVEY 8d, 729 x 6 synthetic Si): per-subvolume
+    """Same configuration as the reference goldens (C1a / C1b of SURVEY 8d, 729 x 6 synthetic Si; 'film' and 'wire' are
+    BASELINE configs 3 and 4 in small -- the wire's 400 triangles go through the face-tree ray caster): per-subvolume
     temperature, heat flux, kappa and particle count, averaged over steps 500-1000, must lie within the
     reference's seed-to-seed scatter (criterion of SURVEY 8d: 2 sigma on T / phi / kappa, 1 % on N_p)."""
     g = golden('stats_' + case)
@@ -53,12 +55,12 @@ def test_statistical_parity_with_reference(case, tmp_path):
     rows = []
     for s in seeds:
         base, extra = STAT_CASES[case]
-        pop, geo, ph = build_population(base, 100000, s, None, extra=extra)
+        pop, geo, ph = build_population(base, STAT_PARTICLES.get(case, 100000), s, None, extra=extra)
         rec = []
         for _ in range(100):
             pop.run(10, geo, ph)
             rec.append(np.concatenate(([pop.current_timestep, pop.N_p, pop.kappa], pop.subvol_temperature,
-                                       pop.subvol_heat_flux[:, 0], pop.subvol_N_p, pop.subvol_kappa)))
+                                       pop.subvol_heat_flux[:, geo.slice_axis], pop.subvol_N_p, pop.subvol_kappa)))
         rows.append(np.array(rec))
         pop.engine.close()
     rows = np.array(rows)
