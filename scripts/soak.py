@@ -19,6 +19,12 @@ GRID = ['--geometry', 'box', '--dimensions', '200', '200', '200', '--subvolumes'
 WIRE = ['--geometry', 'cylinder', '--dimensions', '500', '100', '16', '--subvolumes', 'slice', '10', '2',
         '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
         '--bound_values', '302', '298', '5']
+WIRE400 = ['--geometry', 'cylinder', '--dimensions', '600', '100', '100', '--subvolumes', 'slice', '20', '2',
+           '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+           '--bound_values', '302', '298', '5']            # 400 triangles: tables in global memory, face-tree ray caster
+STAR = ['--geometry', 'star', '--dimensions', '600', '200', '90', '72', '--subvolumes', 'slice', '8', '2',
+        '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+        '--bound_values', '302', '298', '5']               # 576 triangles, diagonal slivers (split tree references)
 CASTLE = ['--geometry', 'castle', '--dimensions', '90', '40', '70', '45', '8', '5', '1', '--subvolumes', 'slice', '8', '2',
           '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
           '--bound_values', '302', '298', '5']
@@ -39,6 +45,8 @@ CASES = {
     'grid_rbf': (GRID + common('radial'), 300000, 2000),
     'wire': (WIRE + common('linear'), 300000, 3000),
     'castle': (CASTLE + common('linear'), 200000, 2000),
+    'wire400': (WIRE400 + common('linear'), 500000, 3000),
+    'star': (STAR + common('linear'), 500000, 2000),
     'hot_start': (A.BOX_TTP + common('linear') + ['--temp_dist', 'hot'], 300000, 2000),
 }
 which = sys.argv[1:] or list(CASES)
