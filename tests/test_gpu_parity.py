@@ -335,6 +335,34 @@ def test_grid_subvolumes_vs_oracle(interp):
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
+@pytest.mark.parametrize('interp', [2, 3])
+def test_large_mesh_grid_subvolumes_vs_oracle(interp):
+    """The remaining sweep variants: tables in global memory (288-face wire, face-tree ray caster), rough facets AND
+    grid subvolumes with nearest-centre / cubic-RBF particle temperatures -- k_sweep<2, true, false / true>."""
+    from util import case_from_args, population_in_mesh
+    argv = ['--geometry', 'cylinder', '--dimensions', '500', '100', '72', '--subvolumes', 'grid', '2', '2', '4',
+            '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+            '--bound_values', '302', '298', '5', '--poscar_file', 'POSCAR', '--hdf_file', 'synthetic', '--temp_interp', 'nearest',
+            '--timestep', '1', '--energy_normal', 'mean', '--particles', 'total', '30000']
+    ct = case_from_args(argv, 'Si')
+    assert ct['kind'] == 1 and ct['mesh']['face_normals'].shape[0] == 288
+    pos, mode, occ, counter = population_in_mesh(ct, 30000, seed=23)
+    nsteps = 12
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=6, interp=interp, cap=120000)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=6, interp=interp)
+    t = eng.step(nsteps)
+    for s in range(nsteps):
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+    p = eng.download()
+    n = sim.P.N
+    o1, o2 = np.argsort(p['pid']), np.argsort(sim.P.pid[:n])
+    assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
+    assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+
+
 def test_specular_pairs_on_device_equal_host_builder():
     """nk_specular_pairs (find_specular_correspondences 'velocity', Population.py:1241-1454, one thread per in-mode)
     returns exactly the pair set of the NumPy builder, which test_host_geometry pins to the reference's goldens --
