@@ -335,17 +335,18 @@ def test_grid_subvolumes_vs_oracle(interp):
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
-@pytest.mark.parametrize('interp', [2, 3])
-def test_large_mesh_grid_subvolumes_vs_oracle(interp):
-    """The remaining sweep variants: tables in global memory (288-face wire, face-tree ray caster), rough facets AND
-    grid subvolumes with nearest-centre / cubic-RBF particle temperatures -- k_sweep<2, true, false / true>."""
+@pytest.mark.parametrize('sides,interp', [(72, 2), (72, 3), (16, 3)])
+def test_rough_wire_grid_subvolumes_vs_oracle(sides, interp):
+    """The remaining sweep variants: rough facets AND grid subvolumes with nearest-centre / cubic-RBF particle
+    temperatures, on a 288-face wire (tables in global memory, face-tree ray caster: k_sweep<2, true, false / true>) and
+    on a 64-face wire (tables in LDS: k_sweep<1, true, true>)."""
     from util import case_from_args, population_in_mesh
-    argv = ['--geometry', 'cylinder', '--dimensions', '500', '100', '72', '--subvolumes', 'grid', '2', '2', '4',
+    argv = ['--geometry', 'cylinder', '--dimensions', '500', '100', str(sides), '--subvolumes', 'grid', '2', '2', '4',
             '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
             '--bound_values', '302', '298', '5', '--poscar_file', 'POSCAR', '--hdf_file', 'synthetic', '--temp_interp', 'nearest',
             '--timestep', '1', '--energy_normal', 'mean', '--particles', 'total', '30000']
     ct = case_from_args(argv, 'Si')
-    assert ct['kind'] == 1 and ct['mesh']['face_normals'].shape[0] == 288
+    assert ct['kind'] == 1 and ct['mesh']['face_normals'].shape[0] == 4 * sides
     pos, mode, occ, counter = population_in_mesh(ct, 30000, seed=23)
     nsteps = 12
     sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=6, interp=interp, cap=120000)
