@@ -268,7 +268,19 @@ class Population(Constants):
                         have[i] += take.shape[0]
             pos = np.vstack([np.vstack(c) if c else np.zeros((0, 3)) for c in chunks])[:NL, :]
         elif key == 'center_subvol':
-            raise NotImplementedError('--part_dist center_subvol needs per-subvolume meshes (not built)')
+            # Population.py:248-267 puts every subvolume's share at the centre of mass of `geometry.subvol_meshes[i]`, an
+            # attribute the reference never creates (the option raises AttributeError there).  Here: at the subvolume's
+            # centre, the point the classifier is built from.
+            vol = np.asarray(geometry.subvol_volume, dtype=float)
+            filled = vol.sum() - vol[self.empty_subvols].sum()
+            chunks, counter = [], 0
+            for i in range(S):
+                if i in self.empty_subvols:
+                    continue
+                k = min(int(np.ceil(NL * vol[i] / filled)), NL - counter)
+                counter += k
+                chunks.append(np.ones((k, 3)) * np.asarray(geometry.subvol_center)[i])
+            pos = np.vstack(chunks)[:NL, :]
         else:
             data = np.loadtxt(key, delimiter=',', comments='#', dtype=float)        # resume file, Population.py:284-306
             modes = data[:, [0, 1]].astype(int)

@@ -76,6 +76,20 @@ def test_statistical_parity_with_reference(case, tmp_path):
     assert abs(Npm.mean() / Npr.mean() - 1) < 0.01
 
 
+def test_part_dist_center_subvol():
+    """--part_dist center_subvol: every subvolume's share of the particles starts at its centre."""
+    pop, geo, ph = build_population('ttp', 20000, 3, None, extra=['--part_dist', 'center_subvol'])
+    p = pop.engine.download()
+    x = p['positions']
+    assert x.shape[0] == 20000
+    cx = np.unique(np.round(x[:, 0], 9))
+    assert cx.shape[0] == 20 and np.allclose(cx, np.sort(np.asarray(geo.subvol_center)[:, 0]))
+    assert np.allclose(x[:, 1], 100.0) and np.allclose(x[:, 2], 100.0)
+    pop.run(5, geo, ph)
+    assert abs(pop.N_p - 20000) < 2000
+    pop.engine.close()
+
+
 def test_outputs_written(tmp_path):
     """convergence.txt / particle_data.txt / residue.txt in the reference's layout."""
     pop, geo, ph = build_population('ttrrp', 20000, 7, tmp_path)
