@@ -42,7 +42,9 @@ struct nk_ctx {
     int g_sweep_key = -1;              // which k_sweep instantiation g_sweep was sized for
     // set-up table builder state (nk_specular_*)
     int64_t spec_M = 0;
-    double *spec_v = nullptr, *spec_om = nullptr, *spec_dl = nullptr;
+    double *spec_v = nullptr, *spec_om = nullptr, *spec_dl = nullptr, *spec_svx = nullptr;
+    int32_t *spec_rank = nullptr;
+    double spec_vmax = 0.0;
     NkSpecMode *spec_modes = nullptr;
     int32_t *spec_in = nullptr, *spec_out = nullptr;
     unsigned long long *spec_count = nullptr;
@@ -1314,9 +1316,11 @@ int nk_uniform2(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double
 // ------------------------------------------------------------------------------ set-up table builder
 static void nk_specular_free(nk_ctx *ctx) {
     for (void *p : {(void *)ctx->spec_v, (void *)ctx->spec_om, (void *)ctx->spec_dl, (void *)ctx->spec_modes,
-                    (void *)ctx->spec_in, (void *)ctx->spec_out, (void *)ctx->spec_count})
+                    (void *)ctx->spec_in, (void *)ctx->spec_out, (void *)ctx->spec_count, (void *)ctx->spec_svx,
+                    (void *)ctx->spec_rank})
         if (p) hipFree(p);
-    ctx->spec_v = ctx->spec_om = ctx->spec_dl = nullptr;
+    ctx->spec_v = ctx->spec_om = ctx->spec_dl = ctx->spec_svx = nullptr;
+    ctx->spec_rank = nullptr;
     ctx->spec_modes = nullptr; ctx->spec_in = ctx->spec_out = nullptr; ctx->spec_count = nullptr;
     ctx->spec_M = 0; ctx->spec_cap = 0;
 }
@@ -1332,6 +1336,24 @@ int nk_specular_begin(nk_ctx *ctx, int64_t M, const double *group_vel, const dou
     NK_HIP(hipMemcpy(ctx->spec_v, group_vel, (size_t)M * 24, hipMemcpyHostToDevice));
     NK_HIP(hipMemcpy(ctx->spec_om, omega, (size_t)M * 8, hipMemcpyHostToDevice));
     NK_HIP(hipMemcpy(ctx->spec_dl, delta_omega, (size_t)M * 8, hipMemcpyHostToDevice));
+    // order of the x-velocities (the pair search only scans a window of it), rank of every mode in it, largest |v|
+    std::vector<int32_t> order((size_t)M), rank((size_t)M);
+    for (int64_t m = 0; m < M; ++m) order[(size_t)m] = (int32_t)m;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t p, int32_t q) { return group_vel[3 * (size_t)p] < group_vel[3 * (size_t)q]; });
+    std::vector<double> svx((size_t)M);
+    double vmax = 0.0;
+    for (int64_t k = 0; k < M; ++k) {
+        const size_t m = (size_t)order[(size_t)k];
+        rank[m] = (int32_t)k;
+        svx[(size_t)k] = group_vel[3 * m];
+        const double vx = group_vel[3 * m], vy = group_vel[3 * m + 1], vz = group_vel[3 * m + 2];
+        vmax = std::max(vmax, sqrt((vx * vx + vy * vy) + vz * vz));
+    }
+    NK_HIP(hipMalloc((void **)&ctx->spec_rank, (size_t)M * 4));
+    NK_HIP(hipMalloc((void **)&ctx->spec_svx, (size_t)M * 8));
+    NK_HIP(hipMemcpy(ctx->spec_rank, rank.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ctx->spec_svx, svx.data(), (size_t)M * 8, hipMemcpyHostToDevice));
+    ctx->spec_vmax = vmax;
     ctx->spec_M = M;
     return NK_OK;
 }
@@ -1351,10 +1373,10 @@ int nk_specular_pairs(nk_ctx *ctx, const double *normal, double crit, int64_t ca
     }
     const int blocks = (M + NK_WG - 1) / NK_WG;
     NK_HIP(hipMemsetAsync(ctx->spec_count, 0, 8, ctx->stream));
-    k_specular_prepare<<<blocks, NK_WG, 0, ctx->stream>>>(M, ctx->spec_v, ctx->spec_om, ctx->spec_dl, normal[0], normal[1],
-                                                          normal[2], ctx->spec_modes);
-    k_specular_pairs<<<blocks, NK_WG, 0, ctx->stream>>>(M, ctx->spec_modes, normal[0], normal[1], normal[2], crit, cap,
-                                                        ctx->spec_in, ctx->spec_out, ctx->spec_count);
+    k_specular_prepare<<<blocks, NK_WG, 0, ctx->stream>>>(M, ctx->spec_v, ctx->spec_om, ctx->spec_dl, ctx->spec_rank, normal[0],
+                                                          normal[1], normal[2], ctx->spec_modes);
+    k_specular_pairs<<<blocks, NK_WG, 0, ctx->stream>>>(M, ctx->spec_modes, ctx->spec_svx, ctx->spec_vmax, normal[0], normal[1],
+                                                        normal[2], crit, cap, ctx->spec_in, ctx->spec_out, ctx->spec_count);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
     unsigned long long n = 0;

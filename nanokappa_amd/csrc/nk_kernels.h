@@ -851,8 +851,11 @@ __global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32
 // multiply-adds, because the pair set depends on roundings (the angle test rejects a pair when the dot product of two
 // unit vectors rounds above 1: arccos -> NaN -> pi, :1357-1369).
 struct NkSpecMode { double vx, vy, vz, nrm, om, dl, vdn, pad; };     // 64 bytes per mode
+// The records go out in the order of the modes' x-velocity (`rank` = position of mode m in that order), the original mode
+// index in `pad`: a thread of k_specular_pairs then only looks at the window of that order that the first criterion
+// |v_ref.x - v_out.x| / max(|v_ref|, |v_out|) < crit can reach (|v| <= vmax), instead of at all M modes.
 __global__ __launch_bounds__(NK_WG) void k_specular_prepare(int M, const double *v, const double *omega, const double *delta,
-                                                            double nx, double ny, double nz, NkSpecMode *out) {
+                                                            const int32_t *rank, double nx, double ny, double nz, NkSpecMode *out) {
 #pragma clang fp contract(off)
     const int m = blockIdx.x * NK_WG + threadIdx.x;
     if (m >= M) return;
@@ -860,18 +863,17 @@ __global__ __launch_bounds__(NK_WG) void k_specular_prepare(int M, const double 
     r.vx = v[3 * m]; r.vy = v[3 * m + 1]; r.vz = v[3 * m + 2];
     r.vdn = (r.vx * nx + r.vy * ny) + r.vz * nz;                       // np.sum(v * n, axis=2)
     r.nrm = sqrt((r.vx * r.vx + r.vy * r.vy) + r.vz * r.vz);           // np.linalg.norm(v_out, axis=1)
-    r.om = omega[m]; r.dl = delta[m]; r.pad = 0.0;
-    out[m] = r;
+    r.om = omega[m]; r.dl = delta[m]; r.pad = (double)m;
+    out[rank[m]] = r;
 }
-__global__ __launch_bounds__(NK_WG) void k_specular_pairs(int M, const NkSpecMode *modes, double nx, double ny, double nz,
-                                                          double crit, int64_t cap, int32_t *pin, int32_t *pout,
-                                                          unsigned long long *count) {
+__global__ __launch_bounds__(NK_WG) void k_specular_pairs(int M, const NkSpecMode *modes, const double *sorted_vx, double vmax,
+                                                          double nx, double ny, double nz, double crit, int64_t cap,
+                                                          int32_t *pin, int32_t *pout, unsigned long long *count) {
 #pragma clang fp contract(off)
-    __shared__ NkSpecMode tile[NK_WG];
     const int a = blockIdx.x * NK_WG + threadIdx.x;
-    NkSpecMode me = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (a < M) me = modes[a];
-    const bool is_in = a < M && me.vdn < 0.0;
+    if (a >= M) return;
+    const NkSpecMode me = modes[a];
+    if (!(me.vdn < 0.0)) return;                                         // in-modes only
     // mirrored velocity and its norm (v_ref = v_in - 2 n (v_in . n)), unit in-velocity mirrored the same way
     const double t2x = 2.0 * nx, t2y = 2.0 * ny, t2z = 2.0 * nz;
     const double rx = me.vx - t2x * me.vdn, ry = me.vy - t2y * me.vdn, rz = me.vz - t2z * me.vdn;
@@ -880,25 +882,24 @@ __global__ __launch_bounds__(NK_WG) void k_specular_pairs(int M, const NkSpecMod
     const double ux = me.vx / vn, uy = me.vy / vn, uz = me.vz / vn;
     const double udn = (ux * nx + uy * ny) + uz * nz;
     const double tx = ux - t2x * udn, ty = uy - t2y * udn, tz = uz - t2z * udn;
-    for (int b0 = 0; b0 < M; b0 += NK_WG) {
-        __syncthreads();
-        if (b0 + (int)threadIdx.x < M) tile[threadIdx.x] = modes[b0 + threadIdx.x];
-        __syncthreads();
-        const int nb = M - b0 < NK_WG ? M - b0 : NK_WG;
-        if (!is_in) continue;
-        for (int k = 0; k < nb; ++k) {
-            const NkSpecMode &o = tile[k];
-            if (!(o.vdn > 0.0)) continue;
-            const double ref = fmax(nrm_in, o.nrm);
-            if (!(fabs(rx - o.vx) / ref < crit)) continue;
-            if (!(fabs(ry - o.vy) / ref < crit) || !(fabs(rz - o.vz) / ref < crit)) continue;
-            if (!(fabs(me.om - o.om) < me.dl + o.dl)) continue;
-            const double ox = o.vx / o.nrm, oy = o.vy / o.nrm, oz = o.vz / o.nrm;
-            const double dot = (tx * ox + ty * oy) + tz * oz;
-            const double ang = acos(dot);                               // NaN (dot rounded above 1) rejects the pair
-            if (!(ang < crit)) continue;
-            const unsigned long long at = atomicAdd(count, 1ull);
-            if ((int64_t)at < cap) { pin[at] = a; pout[at] = b0 + k; }
-        }
+    // window of the x-velocity order: everything the first criterion can accept, and a little more
+    const double h = crit * fmax(vmax, nrm_in) * (1.0 + 1e-6);
+    int lo = 0, hi = M;
+    { int l = 0, r = M; const double key = rx - h; while (l < r) { const int mid = (l + r) >> 1; if (sorted_vx[mid] < key) l = mid + 1; else r = mid; } lo = l; }
+    { int l = lo, r = M; const double key = rx + h; while (l < r) { const int mid = (l + r) >> 1; if (sorted_vx[mid] <= key) l = mid + 1; else r = mid; } hi = l; }
+    const int a_orig = (int)me.pad;
+    for (int k = lo; k < hi; ++k) {
+        const NkSpecMode o = modes[k];
+        if (!(o.vdn > 0.0)) continue;
+        const double ref = fmax(nrm_in, o.nrm);
+        if (!(fabs(rx - o.vx) / ref < crit)) continue;
+        if (!(fabs(ry - o.vy) / ref < crit) || !(fabs(rz - o.vz) / ref < crit)) continue;
+        if (!(fabs(me.om - o.om) < me.dl + o.dl)) continue;
+        const double ox = o.vx / o.nrm, oy = o.vy / o.nrm, oz = o.vz / o.nrm;
+        const double dot = (tx * ox + ty * oy) + tz * oz;
+        const double ang = acos(dot);                               // NaN (dot rounded above 1) rejects the pair
+        if (!(ang < crit)) continue;
+        const unsigned long long at = atomicAdd(count, 1ull);
+        if ((int64_t)at < cap) { pin[at] = a_orig; pout[at] = (int)o.pad; }
     }
 }

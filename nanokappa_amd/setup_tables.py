@@ -210,6 +210,21 @@ def specular_correspondences_k(geometry, phonon, rough_facets):
     return corr, true_spec
 
 
+def _corr_blocks(corr):
+    """{normal (tuple): slice of corr} -- the builders append one contiguous block of rows per distinct normal."""
+    if corr.shape[0] == 0:
+        return {}
+    chg = np.nonzero(np.any(corr[1:, :3] != corr[:-1, :3], axis=1))[0] + 1
+    starts = np.concatenate(([0], chg))
+    ends = np.concatenate((chg, [corr.shape[0]]))
+    blocks = {}
+    for a, b in zip(starts, ends):
+        key = tuple(corr[a, :3] + 0.0)          # + 0.0: -0.0 and 0.0 are the same key
+        assert key not in blocks, 'rows of one normal must be contiguous'
+        blocks[key] = slice(int(a), int(b))
+    return blocks
+
+
 def specular_map(corr, geometry, rough_facets, Q, J):
     """Flat out-mode per (rough facet, q, j), -1 where the mode has no specular partner.  When an in-mode has
     several partners the reference's nearest-neighbour lookup (Population.py:1457) returns one of them; here the
@@ -218,9 +233,12 @@ def specular_map(corr, geometry, rough_facets, Q, J):
     if corr.shape[0] == 0:
         return out
     normals = -np.round(geometry.facets_normal[rough_facets, :], decimals=10)
+    blocks = _corr_blocks(corr)
     for i, n in enumerate(normals):
-        sel = np.nonzero(np.linalg.norm(corr[:, :3] - n, axis=1) < 1e-9)[0]
-        c = corr[sel].astype(np.int64)
+        sl = blocks.get(tuple(n + 0.0))
+        if sl is None:
+            continue
+        c = corr[sl].astype(np.int64)
         order = np.lexsort((c[:, 6], c[:, 5]))[::-1]        # descending, so the smallest is written last
         c = c[order]
         out[i, c[:, 3], c[:, 4]] = c[:, 5] * J + c[:, 6]
@@ -240,8 +258,11 @@ def diffuse_roulette(geometry, phonon, rough_facets, specularity, corr, scat_mod
         out_q, out_j = corr[:, 5].astype(int), corr[:, 6].astype(int)
         un, inv_n = np.unique(n, axis=0, return_inverse=True)
         inv_n = np.asarray(inv_n).ravel()
+        blocks = _corr_blocks(corr)
         for i_n, u in enumerate(un):
-            sel = np.nonzero(np.linalg.norm(corr[:, :3] - u, axis=1) < 1e-10)[0]
+            sel = blocks.get(tuple(np.round(u, decimals=10) + 0.0))
+            if sel is None:
+                continue
             for f in np.nonzero(inv_n == i_n)[0]:
                 np.subtract.at(rate[f], (out_q[sel], out_j[sel]), specular_D[f, in_q[sel], in_j[sel]])
     if scat_model in ('k', 'wavevector', 'wave_vector') and degeneracies is not None:
