@@ -19,9 +19,19 @@ class SubvolClassifier(object):
     def __init__(self, n, xc):
         self.n = n
         self.xc = np.asarray(xc, dtype=float)
+        # centres in a row along one axis ('slice' subvolumes): the nearest one follows from the midpoints
+        self._axis = None
+        if self.xc.shape[0] > 1:
+            moving = [a for a in range(3) if np.ptp(self.xc[:, a]) > 0]
+            if len(moving) == 1 and np.all(np.diff(self.xc[:, moving[0]]) > 0):
+                self._axis = moving[0]
+                c = self.xc[:, self._axis]
+                self._mid = 0.5 * (c[1:] + c[:-1])
 
     def predict(self, x):
         x = np.atleast_2d(np.asarray(x, dtype=float))
+        if self._axis is not None:
+            return np.searchsorted(self._mid, x[:, self._axis], side='left').astype(int)   # an exact tie goes to the lower index
         out = np.empty(x.shape[0], dtype=int)
         for s in range(0, x.shape[0], 1 << 18):
             d = ((x[s:s + (1 << 18), None, :] - self.xc[None]) ** 2).sum(axis=2)
