@@ -50,23 +50,27 @@ class Mesh(object):
         self.faces[flip] = self.faces[flip][:, [1, 0, 2]]
 
     def _count_crossings(self, origins, dirs, skip_self=False):
-        """Number of triangles crossed by the open rays origin + t*dir, t > 0 (Moller-Trumbore, all pairs)."""
+        """Number of triangles crossed by the open rays origin + t*dir, t > 0 (Moller-Trumbore, all pairs, written out
+        by components: (rays, faces) planes instead of (rays, faces, 3) temporaries)."""
         v = self.vertices[self.faces]
         v0, e1, e2 = v[:, 0], v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
         counts = np.zeros(origins.shape[0], dtype=int)
         step = max(1, int(2e6 // max(1, v.shape[0])))
+        e1x, e1y, e1z = e1[:, 0][None], e1[:, 1][None], e1[:, 2][None]
+        e2x, e2y, e2z = e2[:, 0][None], e2[:, 1][None], e2[:, 2][None]
         for s in range(0, origins.shape[0], step):
-            o = origins[s:s + step, None, :]
-            d = dirs[s:s + step, None, :]
-            p = np.cross(d, e2[None])
-            det = np.sum(e1[None] * p, axis=2)
+            o = origins[s:s + step]
+            d = dirs[s:s + step]
+            dx, dy, dz = d[:, 0:1], d[:, 1:2], d[:, 2:3]
+            px, py, pz = dy * e2z - dz * e2y, dz * e2x - dx * e2z, dx * e2y - dy * e2x          # p = d x e2
+            det = e1x * px + e1y * py + e1z * pz
+            tx, ty, tz = o[:, 0:1] - v0[:, 0][None], o[:, 1:2] - v0[:, 1][None], o[:, 2:3] - v0[:, 2][None]
             with np.errstate(divide='ignore', invalid='ignore'):
                 inv = 1.0 / det
-                tv = o - v0[None]
-                u = np.sum(tv * p, axis=2) * inv
-                q = np.cross(tv, e1[None])
-                w = np.sum(d * q, axis=2) * inv
-                t = np.sum(e2[None] * q, axis=2) * inv
+                u = (tx * px + ty * py + tz * pz) * inv
+                qx, qy, qz = ty * e1z - tz * e1y, tz * e1x - tx * e1z, tx * e1y - ty * e1x      # q = tv x e1
+                w = (dx * qx + dy * qy + dz * qz) * inv
+                t = (e2x * qx + e2y * qy + e2z * qz) * inv
             eps = 1e-9
             with np.errstate(invalid='ignore'):
                 ok = (np.abs(det) > 1e-14) & (u >= -eps) & (w >= -eps) & (u + w <= 1 + eps) & (t > 1e-9)
@@ -74,9 +78,14 @@ class Mesh(object):
                 idx = np.arange(s, min(s + step, origins.shape[0]))
                 ok[np.arange(idx.shape[0]), idx] = False
             # a ray through a shared edge/vertex would be counted once per triangle: merge equal distances
-            for i in range(ok.shape[0]):
-                ts = np.unique(np.round(t[i, ok[i]], 8))
-                counts[s + i] = ts.shape[0]
+            rows, cols = np.nonzero(ok)
+            if rows.size:
+                tv = np.round(t[rows, cols], 8)
+                order = np.lexsort((tv, rows))
+                r_s, t_s = rows[order], tv[order]
+                first = np.ones(r_s.shape[0], dtype=bool)
+                first[1:] = (r_s[1:] != r_s[:-1]) | (t_s[1:] != t_s[:-1])
+                counts[s:s + ok.shape[0]] = np.bincount(r_s[first], minlength=ok.shape[0])
         return counts
 
     def _face_tables(self):
