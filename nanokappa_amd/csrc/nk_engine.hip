@@ -873,11 +873,13 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
     for (void *p : ctx->pallocs) hipFree(p);
     ctx->pallocs.clear();
     // segments: load-balance granularity of the persistent sweep (a few tiles of 256 each)
-    // Segments of at least 512 slots, and for large ensembles exactly ONE per resident wave of the sweep: measured on
+    // For large ensembles exactly ONE segment per resident wave of the sweep: measured on
     // 1e7 particles, 3072 segments (one per wave) 0.381 ms, 6144 0.397, 8192 0.39-0.40, 12288 0.401, and 4096 (a third
     // of the waves gets a second segment) 0.413 -- long segments amortise the per-segment costs (first-tile latency, the
     // partial last event batch and spawn tile), and a whole number per wave keeps the waves level.
-    int64_t nseg = capacity / 512;
+    // Small ensembles: more, shorter segments, down to 128 slots, until every resident wave has one -- a wave's serial
+    // chain (tiles, event passes, entering particles) is what a small sweep waits for: 1e5 particles 51 -> 39 us.
+    int64_t nseg = capacity / 128;
     const int64_t waves = (int64_t)nk_sweep_blocks(ctx) * (NK_WG / 64);
     if (const char *e = getenv("NK_SEGMENTS")) nseg = atoi(e) > 0 ? atoi(e) : nseg;          // developer probe
     else if (nseg >= waves) nseg = waves;
