@@ -1199,6 +1199,7 @@ int nk_comm_init(nk_ctx *ctx, const void *id128, int rank, int nranks) {
     ctx->d.rank = rank;
     ctx->d.nranks = nranks;
     if (nranks == 1 && !getenv("NK_FORCE_COMM")) return NK_OK;   // NK_FORCE_COMM: exercise RCCL with a 1-rank communicator
+    if (getenv("NK_COMM_DRYRUN")) return NK_OK;   // test hook: this rank's share of the emission, no communicator (tallies stay local)
     if (nk_load_rccl(ctx->rccl, ctx->err)) return NK_ERR_COMM;
     ncclUniqueId id;
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");

@@ -553,3 +553,35 @@ def test_rccl_path_single_rank(monkeypatch):
     t1 = eng.step(6)
     assert np.array_equal(t0['N_sv'], t1['N_sv'])
     assert np.allclose(t0['T_sv'], t1['T_sv'], rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
+def test_two_rank_sharding_on_one_gpu(case, monkeypatch):
+    """The engine's rank-dependent code -- particle ids offset by the shard, every rank advancing all reservoir counters
+    and keeping the entering particles it owns -- with two contexts on one GPU (NK_COMM_DRYRUN: no communicator, so the
+    tallies, hence the temperatures and occupations, stay local).  Trajectories do not depend on the temperatures
+    (in 'ttrrp': which mode a diffuse reflection draws does not, only its occupation), so the union of the two shards
+    must hold exactly the single-rank run's particles: same ids, modes and positions."""
+    from nanokappa_amd.sharding import shard_range
+    ct = case_tables(case)
+    n = 40000
+    pos, mode, occ, counter = random_population(ct, n, seed=3)
+    ref = make_engine(ct, pos, mode, occ, counter, seed=5)
+    t = ref.step(12)
+    p = ref.download()
+    ref.close()
+    monkeypatch.setenv('NK_COMM_DRYRUN', '1')
+    parts, emitted = [], 0
+    for r in (0, 1):
+        lo, hi = shard_range(n, r, 2)
+        e = make_engine(ct, pos[lo:hi], mode[lo:hi], occ[lo:hi], counter, seed=5, pid_offset=lo, comm=(bytes(128), r, 2))
+        tr = e.step(12)
+        emitted = emitted + tr['N_emitted']
+        parts.append(e.download())
+        e.close()
+    assert np.array_equal(emitted, t['N_emitted'])
+    pid = np.concatenate([q['pid'] for q in parts])
+    o1, o2 = np.argsort(p['pid']), np.argsort(pid)
+    assert np.array_equal(p['pid'][o1], pid[o2])
+    assert np.array_equal(p['mode'][o1], np.concatenate([q['mode'] for q in parts])[o2])
+    assert np.array_equal(p['positions'][o1], np.concatenate([q['positions'] for q in parts])[o2])
