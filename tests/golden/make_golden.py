@@ -523,7 +523,9 @@ def run_stats(case, seed, particles=100000, steps=1000, extra=()):
 
 
 # statistical cases that are a base BC set + extra reference flags
-CASE_EXTRA = {'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one'])}
+CASE_EXTRA = {'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one']),
+              'ttrrp_k': ('ttrrp', ['--bound_scat', 'k']),
+              'ttp_fixed': ('ttp', ['--reservoir_gen', 'fixed_rate'])}
 CASE_PARTICLES = {'wire': 50000}       # the reference does 1e5 phonon-steps/s on the 400-face wire; others run 1e5 particles
 
 
@@ -537,7 +539,7 @@ def gen_stats_one(case, seed):
 
 def gen_stats_merge():
     import glob
-    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332', 'film', 'box_grid332_rbf', 'wire'):
+    for case in ('ttp', 'ttrrp', 'ttp_o2o', 'box_grid332', 'film', 'box_grid332_rbf', 'wire', 'ttrrp_k', 'ttp_fixed'):
         files = sorted(glob.glob(os.path.join(HERE, '_stats_%s_[0-9]*.npz' % case)))
         if not files:
             continue

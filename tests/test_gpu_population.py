@@ -39,11 +39,12 @@ def window_stats(rows, lo=50):
 
 
 STAT_CASES = {'ttp': ('ttp', []), 'ttrrp': ('ttrrp', []), 'film': ('film', []), 'wire': ('wire', []),
-              'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one'])}      # same table as make_golden.CASE_EXTRA
+              'ttp_o2o': ('ttp', ['--reservoir_gen', 'one_to_one']), 'ttrrp_k': ('ttrrp', ['--bound_scat', 'k']),
+              'ttp_fixed': ('ttp', ['--reservoir_gen', 'fixed_rate'])}    # same table as make_golden.CASE_EXTRA
 STAT_PARTICLES = {'wire': 50000}                                          # make_golden.CASE_PARTICLES
 
 
-@pytest.mark.parametrize('case', ['ttp', 'ttrrp', 'ttp_o2o', 'film', 'wire'])
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp', 'ttp_o2o', 'film', 'wire', 'ttrrp_k', 'ttp_fixed'])
 def test_statistical_parity_with_reference(case, tmp_path):
     """Same configuration as the reference goldens (C1a / C1b of SURVEY 8d, 729 x 6 synthetic Si; 'film' and 'wire' are
     BASELINE configs 3 and 4 in small -- the wire's 400 triangles go through the face-tree ray caster): per-subvolume
