@@ -53,13 +53,12 @@ def quiet(fn, *a, **k):
         sys.stdout = old
 
 
-def cpu_baseline(geo, ph, mesh_n, seconds_target=15.0):
-    """The CPU oracle (oracle/nk_oracle.c, a scalar C port of the reference loop) timed on this host on a bounded
-    sample of the same workload: same box / BCs / material, 1e6 particles."""
+def _oracle_run(geo, ph, n, seed, seconds_target, max_steps, start=None):
+    """n particles of the bench workload through the CPU oracle (oracle/nk_oracle.c, a scalar C port of the reference
+    loop): same box / BCs / material.  Returns (phonon-steps, seconds, steps)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import nk_oracle as O
     from nanokappa_amd import setup_tables as ST
-    n = 1000000
     density = n / geo.volume
     mat = O.make_material(ph.tables())
     g = geo.tables()
@@ -68,30 +67,86 @@ def cpu_baseline(geo, ph, mesh_n, seconds_target=15.0):
     sv = O.make_subvols(geo.subvol_center, geo.subvol_volume, 0, geo.slice_axis, 1)
     Q, J = ph.omega.shape
     ep = ST.enter_probability(geo, ph, geo.res_facets, density, 1.0).reshape(-1, Q * J)
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(seed)
     res = O.make_reservoirs(geo.res_facets, geo.res_values, ep, rng.random(ep.shape))
     z = np.zeros(0)
     rough = O.make_rough(np.zeros(0, dtype=np.int32), z, np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32), z)
-    par = O.make_params(dt=1.0, particle_density=density, seed=1)
+    par = O.make_params(dt=1.0, particle_density=density, seed=seed)
     pos = geo.mesh.sample_volume(n, rng)
     active = np.nonzero(~ph.inactive_modes_mask.ravel())[0]
     mode = active[np.arange(n) % active.shape[0]].astype(np.int32)
     occ = ph.calculate_occupation(298.0, ph.omega.ravel()[mode])
-    store = O.ParticleStore(int(1.3 * n))
+    store = O.ParticleStore(int(1.3 * n) + 4096)
     store.load(pos, mode, occ)
     sim = O.OracleSim(mat, mesh, sv, res, rough, par, store, np.full(geo.n_of_subvols, 298.0))
     sim.init_boundaries()
     sim.run_timestep()                       # warm-up step
+    if start is not None:
+        start.wait()                         # all workers set up: measure while all of them run
     t0 = time.time()
     steps, psteps = 0, 0
-    while time.time() - t0 < seconds_target and steps < 200:
+    while time.time() - t0 < seconds_target and steps < max_steps:
         sim.run_timestep()
         psteps += int(sim.N_sv.sum())
         steps += 1
-    dt = time.time() - t0
+    return psteps, time.time() - t0, steps
+
+
+def cpu_baseline(geo, ph, mesh_n, seconds_target=15.0):
+    """The CPU oracle timed on this host on a bounded sample of the same workload: 1e6 particles, one thread."""
+    n = 1000000
+    psteps, dt, steps = _oracle_run(geo, ph, n, 1, seconds_target, 200)
     return dict(value=psteps / dt, unit='phonon-steps/s', cores=1, kind='port',
                 sample='%d particles x %d steps of the same workload (box 200 A, T T P, %d^3 x 6 modes), oracle/nk_oracle.c, 1 thread'
                        % (n, steps, mesh_n))
+
+
+def _all_cores_worker(geo, ph, n, seed, seconds_target, start, out):
+    try:
+        out.put(_oracle_run(geo, ph, n, seed, seconds_target, 100000, start))
+    except Exception as e:                   # the parent reports the failure; never hang the barrier
+        try:
+            start.abort()
+        except Exception:
+            pass
+        out.put(('error', repr(e), 0))
+
+
+def cpu_baseline_all_cores(geo, ph, mesh_n, seconds_target=8.0):
+    """The same oracle on every core this process may use: one worker process per core (forked BEFORE anything touches
+    the GPU), each with its own share of 1e6 particles -- the particle shards of the multi-rank scheme, without the
+    exchange of tallies.  Sum of the workers' rates while all of them run.  None if it cannot be measured."""
+    import multiprocessing as mp
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))          # a one-GPU box's share of the host
+    if cores < 2:
+        return None
+    ctx = mp.get_context('fork')
+    n = 1000000 // cores
+    start, out = ctx.Barrier(cores), ctx.Queue()
+    procs = [ctx.Process(target=_all_cores_worker, args=(geo, ph, n, 100 + i, seconds_target, start, out), daemon=True)
+             for i in range(cores)]
+    for p in procs:
+        p.start()
+    res = []
+    try:
+        for _ in procs:
+            res.append(out.get(timeout=180))
+    except Exception:
+        res = []
+    for p in procs:
+        p.join(timeout=5)
+        if p.is_alive():
+            p.kill()
+    if len(res) != cores or any(r[0] == 'error' for r in res):
+        return None
+    rate = sum(r[0] / r[1] for r in res)
+    return dict(value=rate, unit='phonon-steps/s', cores=cores, kind='port',
+                sample='%d worker processes x %d particles x %d-%d steps of the same workload, oracle/nk_oracle.c, one thread each, '
+                       'tallies not exchanged' % (cores, n, min(r[2] for r in res), max(r[2] for r in res)))
 
 
 def main():
@@ -131,6 +186,9 @@ def main():
     geo = quiet(Geometry, args)
     ph = Phonon(args, 0, material=synthetic.make_material(a.mesh_n, 'Si', temperatures=np.arange(200.0, 401.0, 10.0)))
 
+    all_cores = None
+    if world == 1 and not a.no_cpu_baseline:
+        all_cores = cpu_baseline_all_cores(geo, ph, a.mesh_n)      # forks: must come before the GPU is touched
     comm = None
     if world > 1:
         import torch
@@ -193,6 +251,8 @@ def main():
         }
         if world == 1 and not a.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(geo, ph, a.mesh_n)
+            if all_cores is not None:
+                out['cpu_baseline_all_cores'] = all_cores
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()
