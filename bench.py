@@ -12,6 +12,9 @@ A "step" is one Population.run_timestep: relax -> drift -> reservoir emission ->
 (kernels k_sweep -- which also prepares the next step's emission -- and k_reduce with the fused update; with RCCL the
 all-reduce sits between k_reduce and k_update).
 Particles are resident in HBM before the timed region.  One JSON line is printed by rank 0.
+At N = 1 the line also carries the CPU legs, measured on this host with the oracle (a C port of the reference loop):
+`cpu_baseline` (one thread, 1e6 particles, after the GPU part) and `cpu_baseline_all_cores` (one worker process per core,
+forked before anything touches the GPU).  --no-cpu-baseline skips both.
 
 torch is used only as plumbing when WORLD_SIZE > 1 (gloo rendezvous: unique-id broadcast, barriers, max of the
 elapsed times); the compute path is libnanokappa_hip.so + RCCL.
