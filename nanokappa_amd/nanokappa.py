@@ -18,7 +18,10 @@ def main(argv=None):
     args = read_args(False, argv)
     args = generate_results_folder(args)
     out = None
-    if args.output == 'file':                                   # nanokappa.py:34-36
+    # nanokappa.py:34-36 compares the parsed value with 'file'; an explicit `--output file` arrives as the list ['file'] and
+    # goes to the screen there (only the default writes output.txt).  Fixed here: both spellings write the file.
+    mode = args.output[0] if isinstance(args.output, (list, tuple)) else args.output
+    if mode == 'file':
         out = open(os.path.join(args.results_folder, 'output.txt'), 'a')
         sys.stdout = out
     with open(os.path.join(args.results_folder, 'arguments.txt'), 'w') as f:   # nanokappa.py:38-50
