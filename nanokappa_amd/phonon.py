@@ -41,11 +41,12 @@ class _Interp1dLinear(object):
         return out.reshape(shape)
 
 
-def material_from_phono3py(data, poscar_path):
+def material_from_phono3py(data, poscar_path, isotope=False):
     """phono3py kappa file contents (datasets mesh, qpoint, weight, frequency, group_velocity, temperature, gamma;
     Phonon.py:158-187) + POSCAR -> the FBZ-expanded tables of Phonon.load_base_properties (Phonon.py:66-113): the
     irreducible q-points are expanded with the crystal's reciprocal point-group operations (expand_FBZ :515-564),
-    negative frequencies are clipped (:163), group velocities rounded to 10 decimals (:102)."""
+    negative frequencies are clipped (:163), group velocities rounded to 10 decimals (:102).  With `isotope`
+    (--isotope_scat lists this material) the dataset gamma_isotope is added to gamma (load_gamma, Phonon.py:316-323)."""
     from . import crystal
     if poscar_path is None or not os.path.exists(poscar_path):
         raise IOError('material: POSCAR file %r not found (it fixes the lattice and the symmetry of the expansion)' % poscar_path)
@@ -59,7 +60,12 @@ def material_from_phono3py(data, poscar_path):
     freq = np.where(freq < 0, 0, freq)
     q_fbz, freq = crystal.expand_FBZ(w, q, freq, 0, 0, rot, rec)
     _, vg = crystal.expand_FBZ(w, q, np.array(data['group_velocity'], dtype=float), 0, 1, rot, rec)
-    _, gamma = crystal.expand_FBZ(w, q, np.array(data['gamma'], dtype=float), 1, 0, rot, rec)
+    g_ibz = np.array(data['gamma'], dtype=float)
+    if isotope:
+        if 'gamma_isotope' not in data:
+            raise Exception('hdf file does not contain the field "gamma_isotope".')
+        g_ibz = g_ibz + np.array(data['gamma_isotope'], dtype=float)
+    _, gamma = crystal.expand_FBZ(w, q, g_ibz, 1, 0, rot, rec)
     return dict(data_mesh=np.array(data['mesh']), q_points=q_fbz, frequency=freq, omega=freq * 2 * np.pi,
                 group_vel=np.around(vg, decimals=10), temperature=np.array(data['temperature'], dtype=float), gamma=gamma,
                 lattice=lattice, reciprocal_lattice=np.around(rec, decimals=6),
@@ -100,11 +106,16 @@ class Phonon(Constants):
             return synthetic.make_material(n, species)
         path = os.path.join(folder, name)
         poscar = os.path.join(folder, self.args.poscar_file[self.mat_index]) if len(getattr(self.args, 'poscar_file', [])) > self.mat_index else None
+        iso = self.mat_index in [int(i) for i in getattr(self.args, 'isotope_scat', [])]     # Phonon.py:319
         if path.endswith('.npz'):
             with np.load(path) as z:
                 data = {k: z[k] for k in z.files}
             if 'qpoint' in data:                     # phono3py datasets kept as .npz (irreducible wedge + weights)
-                return material_from_phono3py(data, poscar)
+                return material_from_phono3py(data, poscar, iso)
+            if iso:                                  # FBZ-expanded tables: the isotope part is expanded already
+                if 'gamma_isotope' not in data:
+                    raise Exception('material file does not contain the field "gamma_isotope".')
+                data['gamma'] = np.array(data['gamma'], dtype=float) + np.array(data['gamma_isotope'], dtype=float)
             return data                              # FBZ-expanded tables (Phonon.save_npz, synthetic.make_material)
         if path.endswith('.hdf5') or path.endswith('.h5'):
             try:
@@ -115,7 +126,9 @@ class Phonon(Constants):
             with h5py.File(path, 'r') as f:
                 data = {k: np.array(f[k]) for k in ('mesh', 'qpoint', 'weight', 'frequency', 'group_velocity',
                                                      'temperature', 'gamma')}
-            return material_from_phono3py(data, poscar)
+                if iso and 'gamma_isotope' in f:
+                    data['gamma_isotope'] = np.array(f['gamma_isotope'])
+            return material_from_phono3py(data, poscar, iso)
         raise ValueError('unknown material source %r' % name)
 
     def _ingest(self, m):

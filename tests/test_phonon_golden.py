@@ -1,5 +1,6 @@
 """Host-side material tables vs the reference's Phonon (golden: tests/golden/phonon.npz)."""
 import numpy as np
+import pytest
 
 from util import golden, golden_phonon, rel_err
 
@@ -112,3 +113,34 @@ def test_irreducible_wedge_round_trip(tmp_path):
     interior = dv < 1e-8
     assert interior.mean() > 0.9
     assert np.allclose(np.linalg.norm(m['group_vel'][o1], axis=2), np.linalg.norm(full['group_vel'][o2], axis=2), atol=1e-8)
+
+
+def test_isotope_scattering_option(tmp_path):
+    """--isotope_scat adds the dataset gamma_isotope to gamma for the listed materials (load_gamma, Phonon.py:316-323)
+    and fails loudly when the file has none."""
+    from nanokappa_amd import crystal, synthetic
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.phonon import Phonon, material_from_phono3py
+    poscar = diamond_poscar(tmp_path / 'POSCAR')
+    full = synthetic.make_material(5, 'Si', temperatures=np.arange(250.0, 351.0, 50.0))
+    cell = crystal.read_poscar(poscar)
+    rot = crystal.reciprocal_operations(cell['lattice'], cell['numbers'], cell['positions'])
+    reps, weights = crystal.reduce_to_IBZ(full['q_points'], rot)
+    g = full['gamma'][:, reps, :]
+    iso = np.where(g > 0, 0.25 * g + 1e-4, 0.0)            # the synthetic table marks modes without scattering with -1
+    data = dict(mesh=np.array([5, 5, 5]), qpoint=full['q_points'][reps], weight=weights,
+                frequency=full['frequency'][reps], group_velocity=full['group_vel'][reps],
+                temperature=full['temperature'], gamma=full['gamma'][:, reps, :], gamma_isotope=iso)
+    np.savez(tmp_path / 'kappa.npz', **data)
+    base = ['--mat_folder', str(tmp_path), '--hdf_file', 'kappa.npz', '--poscar_file', 'POSCAR']
+    plain = Phonon(initialise_parser().parse_args(base), 0)
+    with_iso = Phonon(initialise_parser().parse_args(base + ['--isotope_scat', '0']), 0)
+    other = Phonon(initialise_parser().parse_args(base + ['--isotope_scat', '1']), 0)       # another material's index
+    assert np.array_equal(other.gamma, plain.gamma)
+    ref = material_from_phono3py(dict(data, gamma=data['gamma'] + iso), poscar)['gamma']
+    assert np.allclose(with_iso.gamma, ref, rtol=0, atol=1e-15) and np.all(with_iso.gamma >= plain.gamma)
+    assert np.all(with_iso.lifetime[plain.lifetime > 0] < plain.lifetime[plain.lifetime > 0])
+    del data['gamma_isotope']
+    np.savez(tmp_path / 'kappa.npz', **data)
+    with pytest.raises(Exception, match='gamma_isotope'):
+        Phonon(initialise_parser().parse_args(base + ['--isotope_scat', '0']), 0)
