@@ -64,7 +64,8 @@ struct NkDev {
     double active_modes;
     // ---- mesh
     int32_t F, Fc, NP;                // faces, facets, distinct planes
-    const double *tree_boxes;         // large meshes: node boxes (6 doubles) of the face tree, level by level; or NG = 0
+    const float *tree_boxes;          // large meshes: node boxes (6 floats, rounded outwards) of the face tree, level by level; or NG = 0
+    double tree_bound;                // largest |coordinate| of a box (error bound of the single-precision slab test)
     const double *tree_faces;         // [tree_leaves * 4 * NK_TREE_FACE_DOUBLES] leaf face records (padded with null faces)
     int32_t tree_base[8];             // first node of each level in tree_boxes
     int32_t tree_top, tree_leaves;
@@ -416,17 +417,32 @@ __device__ __forceinline__ void nk_find_boundary(const double *planes, const dou
 // planes) made a wave visit the union of its 64 rays' groups -- on a 5000-face wire nearly the whole mesh per batch.
 #define NK_TREE_LEVELS 8            // 4^8 leaves x 4 faces: meshes up to 262 144 faces
 #define NK_TREE_FACE_DOUBLES 20     // n(3) k | lo(3) hi(3) | o(3) iu(3) iw(3) {face, facet}
-// Does the ray x + t v, 0 <= t <= tmax, cross the box record B = lo.x lo.y | lo.z hi.x | hi.y hi.z ?  (inv = 1 / v)
-__device__ __forceinline__ bool nk_ray_box(const double2 b0, const double2 b1, const double2 b2, double x, double y, double z,
-                                           double vx, double vy, double vz, double ix, double iy, double iz, double tmax) {
-    double t0 = 0.0, t1 = tmax;
+// The boxes are single precision, rounded outwards on the host: a family of four is 96 bytes instead of 192 and the slab
+// test runs at twice the FP64 rate.  The test stays conservative: a slab's entry and exit distances are widened by a bound
+// of their rounding error, e = (|x| + B) 2^-20 |1 / v| per axis (B = largest box coordinate; the error proper is below
+// (|x| + B) 2^-21 |1 / v|: conversion of x and 1 / v, one subtraction, one product).  A box that is entered although the
+// exact ray misses it costs time, never a hit: the faces themselves are tested in FP64 as before.
+struct NkRayF { float x, y, z, ix, iy, iz, ex, ey, ez, cx, cy, cz; bool px, py, pz; };
+__device__ __forceinline__ NkRayF nk_ray_f32(double x, double y, double z, double vx, double vy, double vz, double B) {
+    NkRayF r;
+    r.x = (float)x; r.y = (float)y; r.z = (float)z;
+    r.ix = (float)(1.0 / vx); r.iy = (float)(1.0 / vy); r.iz = (float)(1.0 / vz);     // +-inf for an axis-parallel ray: not used then
+    r.px = vx != 0.0; r.py = vy != 0.0; r.pz = vz != 0.0;
+    const float k = 9.5367431640625e-07f;                                               // 2^-20
+    r.cx = ((float)fabs(x) + (float)B) * k; r.cy = ((float)fabs(y) + (float)B) * k; r.cz = ((float)fabs(z) + (float)B) * k;
+    r.ex = r.cx * fabsf(r.ix); r.ey = r.cy * fabsf(r.iy); r.ez = r.cz * fabsf(r.iz);
+    return r;
+}
+// Does the ray cross the box lo = (b0.x, b0.y, b0.z), hi = (b0.w, b1.x, b1.y) before tmax ?
+__device__ __forceinline__ bool nk_ray_box(float lx, float ly, float lz, float hx, float hy, float hz, const NkRayF &r, float tmax) {
+    float t0 = 0.0f, t1 = tmax;
     bool miss = false;
-    if (vx != 0.0) { const double a = (b0.x - x) * ix, b = (b1.y - x) * ix; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
-    else miss |= (x < b0.x) | (x > b1.y);
-    if (vy != 0.0) { const double a = (b0.y - y) * iy, b = (b2.x - y) * iy; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
-    else miss |= (y < b0.y) | (y > b2.x);
-    if (vz != 0.0) { const double a = (b1.x - z) * iz, b = (b2.y - z) * iz; t0 = fmax(t0, fmin(a, b)); t1 = fmin(t1, fmax(a, b)); }
-    else miss |= (z < b1.x) | (z > b2.y);
+    if (r.px) { const float a = (lx - r.x) * r.ix, b = (hx - r.x) * r.ix; t0 = fmaxf(t0, fminf(a, b) - r.ex); t1 = fminf(t1, fmaxf(a, b) + r.ex); }
+    else miss |= (r.x < lx - r.cx) | (r.x > hx + r.cx);
+    if (r.py) { const float a = (ly - r.y) * r.iy, b = (hy - r.y) * r.iy; t0 = fmaxf(t0, fminf(a, b) - r.ey); t1 = fminf(t1, fmaxf(a, b) + r.ey); }
+    else miss |= (r.y < ly - r.cy) | (r.y > hy + r.cy);
+    if (r.pz) { const float a = (lz - r.z) * r.iz, b = (hz - r.z) * r.iz; t0 = fmaxf(t0, fminf(a, b) - r.ez); t1 = fminf(t1, fmaxf(a, b) + r.ez); }
+    else miss |= (r.z < lz - r.cz) | (r.z > hz + r.cz);
     return !miss && t0 <= t1;
 }
 // The four faces of one leaf against one ray (same arithmetic and the same rounding as nk_fb_planes).
@@ -463,7 +479,7 @@ __device__ __forceinline__ void nk_tree_leaf(const double *tree_faces, int leaf,
 __device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, double x, double y, double z, double vx, double vy,
                                                       double vz, double &tc, int &fc) {
     NkHit h = {__builtin_inf(), 0x7fffffff, -1};
-    const double ix = 1.0 / vx, iy = 1.0 / vy, iz = 1.0 / vz;         // +-inf for an axis-parallel ray: not used then
+    const NkRayF rf = nk_ray_f32(x, y, z, vx, vy, vz, d.tree_bound);
     const int top = d.tree_top, NL = d.tree_leaves;
     int l = top, fam = 0;
     uint32_t todo = 0;                  // bits 4l .. 4l + 3: siblings of the current family of level l still to visit
@@ -480,14 +496,18 @@ __device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, double x, 
 #pragma unroll
             for (int k = 1; k < NK_TREE_LEVELS; ++k) base = (l == k) ? d.tree_base[k] : base;
             const int cnt = (NL + (1 << (2 * l)) - 1) >> (2 * l);
-            const double2 *B = reinterpret_cast<const double2 *>(d.tree_boxes + (size_t)(base + 4 * fam) * 6);
-            double2 b[12];
+            const float4 *B = reinterpret_cast<const float4 *>(d.tree_boxes + (size_t)(base + 4 * fam) * 6);
+            float4 b[6];
 #pragma unroll
-            for (int k = 0; k < 12; ++k) b[k] = B[k];
+            for (int k = 0; k < 6; ++k) b[k] = B[k];
+            // the best hit so far as a float that is not below it
+            float tmax = (float)h.t;                       // inf stays inf
+            tmax += tmax * 1.1920929e-07f;
             uint32_t m = 0;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (4 * fam + c < cnt && nk_ray_box(b[3 * c], b[3 * c + 1], b[3 * c + 2], x, y, z, vx, vy, vz, ix, iy, iz, h.t)) m |= 1u << c;
+            if (4 * fam + 0 < cnt && nk_ray_box(b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, rf, tmax)) m |= 1u;
+            if (4 * fam + 1 < cnt && nk_ray_box(b[1].z, b[1].w, b[2].x, b[2].y, b[2].z, b[2].w, rf, tmax)) m |= 2u;
+            if (4 * fam + 2 < cnt && nk_ray_box(b[3].x, b[3].y, b[3].z, b[3].w, b[4].x, b[4].y, rf, tmax)) m |= 4u;
+            if (4 * fam + 3 < cnt && nk_ray_box(b[4].z, b[4].w, b[5].x, b[5].y, b[5].z, b[5].w, rf, tmax)) m |= 8u;
             todo = (todo & ~(0xFu << (4 * l))) | (m << (4 * l));
             enter = false;
         }

@@ -479,7 +479,19 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         d.tree_top = level;
         d.tree_leaves = NL;
         d.NG = 1;
-        NK_UP(boxes.data(), boxes.size(), &d.tree_boxes);
+        // single precision, rounded outwards (one ulp further than the nearest float: cheap and safe)
+        std::vector<float> fboxes(boxes.size());
+        double bound = 0.0;
+        for (size_t i = 0; i < boxes.size(); ++i) {
+            const bool is_lo = (i % 6) < 3;
+            double v = boxes[i];
+            if (v > 3.0e38) v = 3.0e38;                     // padding nodes (never entered)
+            if (v < -3.0e38) v = -3.0e38;
+            fboxes[i] = nextafterf((float)v, is_lo ? -INFINITY : INFINITY);
+            if (fabs(v) < 1e37) bound = std::max(bound, fabs(v));
+        }
+        d.tree_bound = bound;
+        NK_UP(fboxes.data(), fboxes.size(), &d.tree_boxes);
         NK_UP(tf.data(), tf.size(), &d.tree_faces);
     }
     NK_UP(planes.data(), planes.size(), &d.planes);
