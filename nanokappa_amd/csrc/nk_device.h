@@ -21,7 +21,6 @@
 #define NK_LDS_FACES 256     // meshes up to this many faces keep their plane/face tables in LDS
 #define NK_LDS_RESFACES 64   // reservoir facets with up to this many faces in total keep their sampling tables in LDS
 #define NK_TAU_ROWS 4        // lifetime rows packed into each mode record
-#define NK_ROUL_LUT 1024      // buckets of the diffuse-roulette search index
 #define NK_MAX_SEGMENTS 12288 // upper bound of nseg = 4 x 3072 = 6 x 2048 = 12 x 1024: a whole number of segments per
                               // resident wave at 3, 2 or 1 workgroups per CU (the update keeps 48 per thread in registers)
 #define NK_EVCAP 512         // entries of the per-workgroup LDS event buffer (< NK_WG pending + NK_WG new)
@@ -115,7 +114,8 @@ struct NkDev {
     const uint8_t *true_spec;         // [Fr*M]
     const int32_t *spec_map;          // [Fr*M]
     const double *roulette;           // [Fr*M]
-    const int32_t *roul_lut;          // [Fr*(NK_ROUL_LUT+1)] roul_lut[f][k] = searchsorted(roulette[f], k/NK_ROUL_LUT * last)
+    const int32_t *roul_lut;          // [Fr*(roul_nlut+1)] roul_lut[f][k] = searchsorted(roulette[f], k/roul_nlut * last)
+    int32_t roul_nlut;                // buckets of that index: a power of two near M / 4 (1024 .. 65536)
     const int32_t *degen_j2;          // [M] or null
     // ---- parameters
     double dt;
@@ -555,12 +555,14 @@ __device__ __forceinline__ void nk_reflect(const NkDev &d, const double *cen, co
     } else {
         const double *roul = d.roulette + (int64_t)rough_idx * d.M;
         double r = r_diff * roul[d.M - 1];
-        // np.searchsorted(roulette, r) (Population.py:1005) through a bucket index: r_diff in [k, k+1) / NK_ROUL_LUT
-        // brackets the answer between two precomputed positions, so the bisection runs over M / 1024 entries instead of M
-        // (a chain of ~8 dependent global loads instead of ~18); same result
-        int kb = (int)(r_diff * (double)NK_ROUL_LUT);
-        kb = kb < 0 ? 0 : (kb > NK_ROUL_LUT - 1 ? NK_ROUL_LUT - 1 : kb);
-        const int32_t *lut = d.roul_lut + (int64_t)rough_idx * (NK_ROUL_LUT + 1);
+        // np.searchsorted(roulette, r) (Population.py:1005) through a bucket index: r_diff in [k, k+1) / roul_nlut brackets
+        // the answer between two precomputed positions about four entries apart, so the bisection is a chain of ~2
+        // dependent global loads instead of ~18 over the whole table (and ~8 with the 1024 buckets this started with);
+        // same result
+        const int nlut = d.roul_nlut;
+        int kb = (int)(r_diff * (double)nlut);
+        kb = kb < 0 ? 0 : (kb > nlut - 1 ? nlut - 1 : kb);
+        const int32_t *lut = d.roul_lut + (int64_t)rough_idx * (nlut + 1);
         const int lo = lut[kb], hi = lut[kb + 1];
         int flat = lo + nk_ss_left(roul + lo, hi - lo, r);
         if (flat > d.M - 1) flat = d.M - 1;

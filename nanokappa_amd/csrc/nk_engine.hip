@@ -711,16 +711,21 @@ int nk_set_rough(nk_ctx *ctx, const nk_rough *r) {
         NK_UP(r->true_spec, n, &d.true_spec);
         NK_UP(r->spec_map, n, &d.spec_map);
         NK_UP(r->roulette, n, &d.roulette);
-        {   // bucket index of the roulette search (nk_reflect): first position with roulette >= k / NK_ROUL_LUT * last
-            std::vector<int32_t> lut((size_t)r->Fr * (NK_ROUL_LUT + 1));
+        {   // bucket index of the roulette search (nk_reflect): first position with roulette >= k / nlut * last
+            int nlut = 1024;
+            while (nlut < 65536 && (int64_t)nlut * 4 < d.M) nlut *= 2;
+            d.roul_nlut = nlut;
+            std::vector<int32_t> lut((size_t)r->Fr * (nlut + 1));
             for (int f = 0; f < r->Fr; ++f) {
                 const double *ro = r->roulette + (size_t)f * d.M;
                 const double last = ro[d.M - 1];
-                for (int k = 0; k <= NK_ROUL_LUT; ++k) {
-                    const double thr = ((double)k / (double)NK_ROUL_LUT) * last;
-                    lut[(size_t)f * (NK_ROUL_LUT + 1) + k] = (int32_t)(std::lower_bound(ro, ro + d.M, thr) - ro);
+                int pos = 0;                                     // thresholds ascend: one merge pass per facet
+                for (int k = 0; k < nlut; ++k) {
+                    const double thr = ((double)k / (double)nlut) * last;
+                    while (pos < d.M && ro[pos] < thr) ++pos;
+                    lut[(size_t)f * (nlut + 1) + k] = pos;
                 }
-                lut[(size_t)f * (NK_ROUL_LUT + 1) + NK_ROUL_LUT] = d.M;        // everything is below the end of the last bucket
+                lut[(size_t)f * (nlut + 1) + nlut] = d.M;        // everything is below the end of the last bucket
             }
             NK_UP(lut.data(), lut.size(), &d.roul_lut);
         }
