@@ -477,21 +477,46 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
             ++level;
         }
         d.tree_top = level;
+        auto tree_base_of = [&](int lv) { return (int)d.tree_base[lv]; };
         d.tree_leaves = NL;
         d.NG = 1;
-        // single precision, rounded outwards (one ulp further than the nearest float: cheap and safe)
-        std::vector<float> fboxes(boxes.size());
+        // facet tags: the facet of a node whose faces all belong to one facet, else -1 (nk_tree_skip)
+        std::vector<int32_t> tags(boxes.size() / 6, -1);
+        {
+            const int nlev = level + 1;
+            int cnt = NL;
+            for (int lv = 0; lv < nlev; ++lv) {
+                const int b0 = tree_base_of(lv);
+                for (int i = 0; i < cnt; ++i) {
+                    int tag = -3;                               // -3: nothing seen yet
+                    for (int c = 4 * i; c < 4 * i + 4; ++c) {
+                        int t;
+                        if (lv == 0) { if (slot[c] < 0) continue; t = m->face_facet[refs[slot[c]].face]; }
+                        else { const int below = tree_base_of(lv) - tree_base_of(lv - 1); if (c >= below) continue; t = tags[(size_t)tree_base_of(lv - 1) + c]; if (t == -3) continue; }
+                        tag = (tag == -3) ? t : (tag == t ? tag : -1);
+                    }
+                    tags[(size_t)b0 + i] = tag == -3 ? -1 : tag;
+                }
+                cnt = (cnt + 3) / 4;
+            }
+        }
+        // families of four: single-precision boxes rounded outwards (one ulp further than the nearest float: cheap and safe)
+        const size_t nfam = boxes.size() / 24;
+        std::vector<float> fboxes(nfam * NK_TREE_FAMILY_FLOATS);
         double bound = 0.0;
-        for (size_t i = 0; i < boxes.size(); ++i) {
-            const bool is_lo = (i % 6) < 3;
-            double v = boxes[i];
-            if (v > 3.0e38) v = 3.0e38;                     // padding nodes (never entered)
-            if (v < -3.0e38) v = -3.0e38;
-            fboxes[i] = nextafterf((float)v, is_lo ? -INFINITY : INFINITY);
-            if (fabs(v) < 1e37) bound = std::max(bound, fabs(v));
+        for (size_t f = 0; f < nfam; ++f) {
+            for (int j = 0; j < 24; ++j) {
+                const bool is_lo = (j % 6) < 3;
+                double v = boxes[f * 24 + j];
+                if (v > 3.0e38) v = 3.0e38;                     // padding nodes (never entered)
+                if (v < -3.0e38) v = -3.0e38;
+                fboxes[f * NK_TREE_FAMILY_FLOATS + j] = nextafterf((float)v, is_lo ? -INFINITY : INFINITY);
+                if (fabs(v) < 1e37) bound = std::max(bound, fabs(v));
+            }
         }
         d.tree_bound = bound;
         NK_UP(fboxes.data(), fboxes.size(), &d.tree_boxes);
+        NK_UP(tags.data(), tags.size(), &d.tree_tags);
         NK_UP(tf.data(), tf.size(), &d.tree_faces);
     }
     NK_UP(planes.data(), planes.size(), &d.planes);
@@ -529,6 +554,25 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
     }
     ctx->host_facets = fct;
     NK_UP(fct.data(), fct.size(), &d.facets);
+    {   // how far a facet's faces are from its own plane (nk_tree_skip): largest component of n_face - n_facet, and the
+        // largest |n_face . centroid + k_face|
+        std::vector<double> fs((size_t)m->Fc * 2, 0.0);
+        for (int f = 0; f < m->F; ++f) {
+            const int fc = m->face_facet[f];
+            if (fc < 0 || fc >= m->Fc) continue;
+            const NkFacet &q = fct[fc];
+            const double nx = m->normals[3 * f], ny = m->normals[3 * f + 1], nz = m->normals[3 * f + 2];
+            const double dn = std::max(fabs(nx - q.nx), std::max(fabs(ny - q.ny), fabs(nz - q.nz)));
+            const double dk = fabs(nx * q.cx + ny * q.cy + nz * q.cz + m->k[f]);
+            fs[2 * (size_t)fc] = std::max(fs[2 * (size_t)fc], dn);
+            fs[2 * (size_t)fc + 1] = std::max(fs[2 * (size_t)fc + 1], dk);
+        }
+        // only facets of many faces are worth it (a cap, a flat side of an imported mesh): the others say "never"
+        std::vector<int> nfaces((size_t)m->Fc, 0);
+        for (int f = 0; f < m->F; ++f) if (m->face_facet[f] >= 0 && m->face_facet[f] < m->Fc) ++nfaces[m->face_facet[f]];
+        for (int fc = 0; fc < m->Fc; ++fc) if (nfaces[fc] < 16) fs[2 * (size_t)fc] = 1e300;
+        NK_UP(fs.data(), fs.size(), &d.facet_skip);
+    }
     d.nS = m->nS;
     if (m->nS > 0) {
         NK_UP(m->simplex_pts, (size_t)m->nS * 12, &d.simplex_pts);

@@ -192,9 +192,9 @@ __device__ __forceinline__ void nk_sample_res_face(const int *off, const double 
 }
 
 // Ray cast as the kernels call it: grouped sweep for meshes whose tables stay in global memory, plain sweep over LDS.
-#define NK_RAY(GEOM, d, L, x, y, z, vx, vy, vz, tc, fc)                                                              \
+#define NK_RAY(GEOM, d, L, skip, x, y, z, vx, vy, vz, tc, fc)                                                        \
     do {                                                                                                              \
-        if ((GEOM) == 2 && (d).NG > 0) nk_find_boundary_tree(d, x, y, z, vx, vy, vz, tc, fc);                            \
+        if ((GEOM) == 2 && (d).NG > 0) nk_find_boundary_tree(d, skip, x, y, z, vx, vy, vz, tc, fc);                      \
         else nk_find_boundary((L).planes, (L).faces, (d).NP, (d).tol, x, y, z, vx, vy, vz, tc, fc);                   \
     } while (0)
 
@@ -455,7 +455,13 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w;
                     occ = nk_occupation(d, L.resT[r], omega);                        // Population.py:506
                     double tc;
-                    NK_RAY(GEOM, d, L, x0, y0, z0, vx, vy, vz, tc, facet);
+                    int skip = NK_TREE_NO_SKIP;               // the particle starts on its reservoir's facet
+                    if (GEOM == 2 && d.NG > 0) {
+                        const int rf = d.res_facet[r];
+                        const NkFacet &fq = d.facets[rf];
+                        skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
+                    }
+                    NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
                     nts = tc / d.dt - dt_in / d.dt;                                  // :535
                     x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;   // :536
                 }
@@ -723,7 +729,7 @@ __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
             const int64_t i = base + k;
             const NkMode *rec = d.modetab + d.mode[i];
             double tc; int fc;
-            NK_RAY(GEOM, d, L, d.x[i], d.y[i], d.z[i], rec->vx, rec->vy, rec->vz, tc, fc);
+            NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, d.x[i], d.y[i], d.z[i], rec->vx, rec->vy, rec->vz, tc, fc);
             d.nts[i] = tc / d.dt;
             d.facet[i] = fc;
         }
@@ -759,7 +765,7 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
             for (int q = 0; q < 4; ++q) { double wq = a[q] / asum; x += wq * sp[3 * q]; y += wq * sp[3 * q + 1]; z += wq * sp[3 * q + 2]; }
             const NkMode *rec = d.modetab + d.mode[i];
             double tc; int fc;
-            NK_RAY(GEOM, d, L, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
+            NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
             d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = tc / d.dt; d.facet[i] = fc;
         }
     }
@@ -789,7 +795,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n,
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
     double t; int f;
-    NK_RAY(GEOM, d, L, x[3 * i], x[3 * i + 1], x[3 * i + 2], v[3 * i], v[3 * i + 1], v[3 * i + 2], t, f);
+    NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, x[3 * i], x[3 * i + 1], x[3 * i + 2], v[3 * i], v[3 * i + 1], v[3 * i + 2], t, f);
     tc[i] = t; fc[i] = f;
     for (int k = 0; k < 3; ++k) xc[3 * i + k] = x[3 * i + k] + t * v[3 * i + k];
 }
