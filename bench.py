@@ -200,6 +200,10 @@ def main():
             buf = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
         dist.broadcast(buf, 0)
         comm = (bytes(buf.numpy().tobytes()), rank, world)
+    from nanokappa_amd.engine import device_count
+    nd = device_count()                     # a launcher may show every rank one device only: index modulo what is visible
+    if nd > 0:
+        args.device = [local_rank % nd]
     pop = quiet(Population, args, geo, ph, None, comm)
     eng = pop.engine
 

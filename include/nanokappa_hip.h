@@ -156,6 +156,7 @@ typedef struct {
 } nk_timing;
 
 /* lifetime: `Population.__init__` / end of run */
+int nk_device_count(void);                            /* HIP devices this process sees (0 if none) */
 int nk_create(nk_ctx **out, int device_id, uint64_t seed);
 void nk_destroy(nk_ctx *ctx);
 const char *nk_last_error(const nk_ctx *ctx);        /* ctx may be NULL: error of a failed nk_create */

@@ -152,6 +152,11 @@ extern "C" {
 
 const char *nk_last_error(const nk_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
+int nk_device_count(void) {
+    int ndev = 0;
+    return hipGetDeviceCount(&ndev) == hipSuccess ? ndev : 0;
+}
+
 int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     if (!out) { g_create_error = "nk_create: out is NULL"; return NK_ERR_ARG; }
     *out = nullptr;

@@ -72,7 +72,7 @@ class nk_timing(C.Structure):
                 ('slots', C.c_int64), ('live', C.c_int64)]
 
 
-EXPORTS = ['nk_create', 'nk_destroy', 'nk_last_error', 'nk_set_material', 'nk_set_mesh', 'nk_set_subvolumes',
+EXPORTS = ['nk_device_count', 'nk_create', 'nk_destroy', 'nk_last_error', 'nk_set_material', 'nk_set_mesh', 'nk_set_subvolumes',
            'nk_set_reservoirs', 'nk_set_rough', 'nk_set_params', 'nk_reserve', 'nk_upload_particles',
            'nk_init_boundaries', 'nk_step', 'nk_download_particles', 'nk_get_subvol_temperature',
            'nk_set_subvol_temperature', 'nk_get_step', 'nk_get_timing', 'nk_comm_unique_id', 'nk_comm_init',
@@ -143,6 +143,11 @@ def bc_codes(bound_cond):
     if a.dtype.kind in 'US':
         return np.array([ord(str(c)[0]) for c in a], dtype=np.int8)
     return np.ascontiguousarray(a, dtype=np.int8)
+
+
+def device_count():
+    """HIP devices this process sees."""
+    return int(load_library().nk_device_count())
 
 
 def comm_unique_id():
