@@ -86,6 +86,35 @@ def test_find_boundary_large_mesh_tree(name):
     assert np.all(np.isinf(tc[~hit]))
 
 
+def test_find_boundary_large_mesh_without_tree(monkeypatch):
+    """The fallback of large meshes (NK_NO_TREE, also taken beyond 262 144 faces): all planes swept from global memory.
+    Same answers as the tree walk, ray by ray."""
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.engine import Engine
+    argv = LARGE_MESHES['star'] + ['--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+                                   '--bound_values', '302', '298', '5'] + COMMON_ARGS
+    args = initialise_parser().parse_args(argv)
+    args.results_folder = ''
+    geo = Geometry(args)
+    ph = golden_phonon()
+    rng = np.random.default_rng(12)
+    x = geo.mesh.sample_volume(3000, rng)
+    v = rng.normal(size=(3000, 3)) * 40.0
+    out = []
+    for no_tree in (False, True):
+        if no_tree:
+            monkeypatch.setenv('NK_NO_TREE', '1')
+        eng = Engine(0, 1)
+        eng.set_material(ph.tables())
+        eng.set_mesh(geo.tables())
+        eng.set_subvolumes(geo.subvol_center, geo.subvol_volume, 0, geo.slice_axis, 1, np.full(geo.n_of_subvols, 300.0))
+        out.append(eng.find_boundary(x, v))
+        eng.close()
+    assert np.array_equal(out[0][2], out[1][2]) and np.array_equal(out[0][1], out[1][1])
+    assert np.all(out[0][2] >= 0)
+
+
 @pytest.mark.parametrize('name', ['box200', 'box5000', 'cyl'])
 def test_classifier(name):
     eng, g, ph = base_engine(name)
