@@ -2,22 +2,27 @@
 """bench.py -- phonon-steps/s of the Population timestep loop on N MI355X GPUs of one node.
 
     python bench.py --gpus 1 --steps 50 --warmup 10
+    python bench.py --gpus N ...                     # starts the N rank processes itself (before anything touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W       # or under a launcher that sets RANK / LOCAL_RANK / WORLD_SIZE
 
 Workload (BASELINE.json configs[1], SURVEY.md 8d "C2"): synthetic Si (31^3 q-points x 6 branches), box
 200 x 200 x 200 angstrom, 20 slices along x, BCs T T P (302 K / 298 K reservoirs on +-x, periodic sides), dt = 1 ps,
 1e7 particles PER GPU (weak scaling: the ensemble grows with N, the per-step tally is all-reduced over RCCL).
+`--config` selects the other BASELINE workloads (c1b rough box, c3 Ge film, c4 STL wire, c5 the 1000 A box's share of
+one GPU); the default line is c2.
 A "step" is one Population.run_timestep: relax -> drift -> reservoir emission -> boundary events -> tally -> T update
-(kernels k_sweep -- which also prepares the next step's emission -- and k_reduce with the fused update; with RCCL the
-all-reduce sits between k_reduce and k_update).
-Particles are resident in HBM before the timed region.  One JSON line is printed by rank 0.
-At N = 1 the line also carries the CPU legs, measured on this host with the oracle (a C port of the reference loop):
-`cpu_baseline` (one thread, 1e6 particles, after the GPU part) and `cpu_baseline_all_cores` (one worker process per core,
-forked before anything touches the GPU).  --no-cpu-baseline skips both.
+(kernels k_sweep and k_reduce with the fused update; with RCCL the all-reduce sits between k_reduce and k_update).
+Particles are resident in HBM before the timed region.  The timed region (exactly --steps steps between barriers, the
+stream drained on both sides) is repeated --repeats times; the line reports the MEDIAN repeat and the spread.
+One JSON line is printed by rank 0.  At N = 1 the line also carries the CPU legs, measured on this host with the oracle
+(a C port of the reference loop): `cpu_baseline` (one thread, 1e6 particles, after the GPU part) and
+`cpu_baseline_all_cores` (one worker process per core, forked before anything touches the GPU), plus
+`cpu_reference_numpy`, the reference's own NumPy loop as measured in the build container (a labelled constant: the
+reference cannot travel to the GPU box).  --no-cpu-baseline skips the measured legs.
 
-torch is used only as plumbing when WORLD_SIZE > 1 (gloo rendezvous: unique-id broadcast, barriers, max of the
-elapsed times); the compute path is libnanokappa_hip.so + RCCL.
+No PyTorch anywhere: the ranks meet on a UNIX socket (nanokappa_amd.sharding.NodeRendezvous) to hand round the RCCL
+unique id, for the barriers and for the max of the elapsed times; the compute path is libnanokappa_hip.so + RCCL.
 """
 import argparse
 import json
@@ -152,29 +157,108 @@ def cpu_baseline_all_cores(geo, ph, mesh_n, seconds_target=8.0):
                        'tallies not exchanged' % (cores, n, min(r[2] for r in res), max(r[2] for r in res)))
 
 
+CONFIGS = ('c2', 'c1b', 'c3', 'c4', 'c5')
+
+# The reference's own NumPy loop cannot run on the GPU box (it does not travel); measured in the build container
+# (SURVEY.md section 6 probes; tests/golden/stats_*.npz 'rate'): /opt/conda/bin/python3.9, numpy 1.26.4, plots stubbed.
+CPU_REFERENCE_NUMPY = dict(value=3.65e5, unit='phonon-steps/s', cores=1, kind='reference',
+                           host='build container (Xeon 2.1 GHz, 8 vCPU, 1 core effective), NOT this host',
+                           sample='reference Population.run_timestep, synthetic 9^3 x 6 modes, box 200 A, T T P, 1e6 particles '
+                                  'x 10 steps (4.1e5 at 1e5 particles x 20 steps)')
+
+
+def config_argv(cfg, total, box):
+    """Argument list (Nano-kappa flags) of a BASELINE workload; returns (argv, species, description)."""
+    argv = workload_argv(total, box)
+    if cfg == 'c2':
+        return argv, 'Si', 'box %gx%gx%g A, slice 20 subvols, BCs T T P' % (box, box, box)
+    if cfg == 'c5':
+        argv = workload_argv(total, 1000.0)
+        return argv, 'Si', 'box 1000x1000x1000 A, slice 20 subvols, BCs T T P'
+    if cfg == 'c3':
+        i = argv.index('--dimensions')
+        argv[i + 1:i + 4] = ['2000', '500', '500']
+        return argv, 'Ge', 'film 2000 A thick, 500x500 A periodic cell, slice 20 subvols, BCs T T P'
+    if cfg == 'c1b':
+        i, j = argv.index('--bound_pos'), argv.index('--bound_values')
+        argv[i:j + 3] = ['--bound_pos', 'relative', '-0.1', '0.5', '0.5', '1.1', '0.5', '0.5', '0.5', '0.5', '-0.1', '0.5', '0.5', '1.1',
+                         '--bound_cond', 'T', 'T', 'R', 'R', 'P', '--connect_pos', 'relative', '0.5', '-0.1', '0.5', '0.5', '1.1', '0.5',
+                         '--bound_values', '302', '298', '5', '5']
+        return argv, 'Si', 'box %gx%gx%g A, slice 20 subvols, BCs T T R R P (eta 5 A)' % (box, box, box)
+    raise SystemExit('unknown --config %r' % cfg)
+
+
+def wire_geometry(total):
+    """BASELINE config 4: cylinder primitive (1250 sides = 5000 triangles, L 2000 A, R 200 A) written as ASCII STL and
+    imported again; caps T 302 / 298 K, rough side wall (eta 5 A), 20 slices along the axis."""
+    import tempfile
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    tail = ['--subvolumes', 'slice', '20', '2', '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1',
+            '--bound_cond', 'T', 'T', 'R', '--bound_values', '302', '298', '5', '--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
+            '--temp_interp', 'linear', '--timestep', '1', '--energy_normal', 'mean', '--particles', 'total', str(int(total)),
+            '--seed', '2025']
+    prim = initialise_parser().parse_args(['--geometry', 'cylinder', '--dimensions', '2000', '200', '1250'] + tail)
+    prim.results_folder = ''
+    g0 = quiet(Geometry, prim)
+    tmp = tempfile.mkdtemp()
+    g0.mesh.export_stl('wire', tmp)
+    args = initialise_parser().parse_args(['--geometry', os.path.join(tmp, 'wire.stl'), '--dimensions', '1', '1', '1'] + tail)
+    args.results_folder = ''
+    return args, quiet(Geometry, args)
+
+
+def launch_ranks(n):
+    """`bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) BEFORE anything touches a GPU,
+    relay rank 0's JSON line, fail if any rank fails."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), NK_RDV_KEY='%d_%d' % (os.getpid(), port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL)))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        raise SystemExit('bench.py: rank(s) failed: %s' % ', '.join('rank %d rc %d' % b for b in bad))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--particles', type=float, default=1e7, help='particles per GPU')
+    ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median is reported')
+    ap.add_argument('--config', default='c2', choices=CONFIGS)
+    ap.add_argument('--particles', type=float, default=None, help='particles per GPU (default: the config\'s own)')
     ap.add_argument('--mesh-n', type=int, default=31, help='q-mesh of the synthetic material (31 -> 29791 q-points)')
     ap.add_argument('--box', type=float, default=200.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--calibrate', action='store_true',
                     help='after the timed region run 3 known-traffic sweeps (k_cal_stream) for PMC calibration')
     a = ap.parse_args()
+    if a.gpus < 1 or a.steps < 1 or a.repeats < 1:
+        raise SystemExit('--gpus, --steps and --repeats must be positive')
 
+    if 'RANK' not in os.environ and a.gpus > 1:
+        return launch_ranks(a.gpus)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != a.gpus and world > 1:
+    local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
+    if world != a.gpus:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (a.gpus, world))
-    dist = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-        dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nanokappa_amd.sharding import NodeRendezvous
+    rdv = NodeRendezvous(rank, world, os.environ.get('NK_RDV_KEY', os.environ.get('MASTER_PORT', 'solo')))
 
     from nanokappa_amd import synthetic
     from nanokappa_amd.argument_parser import initialise_parser
@@ -183,23 +267,27 @@ def main():
     from nanokappa_amd.phonon import Phonon
     from nanokappa_amd.population import Population
 
-    total = int(a.particles) * world
-    args = initialise_parser().parse_args(workload_argv(total, a.box) + ['--seed', '2025', '--device', str(local_rank)])
-    args.results_folder = ''
-    geo = quiet(Geometry, args)
-    ph = Phonon(args, 0, material=synthetic.make_material(a.mesh_n, 'Si', temperatures=np.arange(200.0, 401.0, 10.0)))
+    per_gpu = a.particles if a.particles is not None else {'c4': 5e7, 'c5': 1.25e7}.get(a.config, 1e7)
+    total = int(per_gpu) * world
+    if a.config == 'c4':
+        args, geo = wire_geometry(total)
+        species, desc = 'Si', 'STL-imported wire, 5000 triangles, L 2000 A, R 200 A, caps T, rough side (eta 5 A), slice 20 subvols'
+        args.seed, args.device = [2025], [local_rank]
+    else:
+        argv, species, desc = config_argv(a.config, total, a.box)
+        args = initialise_parser().parse_args(argv + ['--seed', '2025', '--device', str(local_rank)])
+        args.results_folder = ''
+        geo = quiet(Geometry, args)
+    ph = Phonon(args, 0, material=synthetic.make_material(a.mesh_n, species, temperatures=np.arange(200.0, 401.0, 10.0)))
 
+    cpu_legs = world == 1 and not a.no_cpu_baseline and a.config == 'c2'
     all_cores = None
-    if world == 1 and not a.no_cpu_baseline:
+    if cpu_legs:
         all_cores = cpu_baseline_all_cores(geo, ph, a.mesh_n)      # forks: must come before the GPU is touched
     comm = None
     if world > 1:
-        import torch
-        buf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = torch.frombuffer(bytearray(comm_unique_id()), dtype=torch.uint8).clone()
-        dist.broadcast(buf, 0)
-        comm = (bytes(buf.numpy().tobytes()), rank, world)
+        uid = rdv.broadcast(comm_unique_id() if rank == 0 else b'')
+        comm = (uid, rank, world)
     from nanokappa_amd.engine import device_count
     nd = device_count()                     # a launcher may show every rank one device only: index modulo what is visible
     if nd > 0:
@@ -207,47 +295,47 @@ def main():
     pop = quiet(Population, args, geo, ph, None, comm)
     eng = pop.engine
 
-    def barrier():
-        if dist is not None:
-            dist.barrier()
-
     if a.warmup > 0:
         eng.step(a.warmup)                 # nk_step returns after the stream has drained (hipStreamSynchronize)
-    barrier()
-    t0 = time.perf_counter()
-    t = eng.step(a.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        import torch
-        te = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te[0])
-    tm = eng.timing()
+    runs = []
+    for _ in range(a.repeats):
+        rdv.barrier()
+        t0 = time.perf_counter()
+        t = eng.step(a.steps)              # enqueues the steps, drains the stream, copies the tallies back
+        rdv.barrier()
+        elapsed = rdv.max(time.perf_counter() - t0)
+        tm = eng.timing()
+        runs.append(dict(elapsed=elapsed, psteps=float(t['N_sv'].sum()), tm=tm))   # N_sv: all ranks (all-reduced)
     if a.calibrate:
         cal = eng.calibrate_stream(3)
         if rank == 0:
             sys.stderr.write('calibration: k_cal_stream reads %d B and writes %d B per launch\n' % cal)
-    psteps = float(t['N_sv'].sum())        # sum over steps of N_p(step), all ranks (tallies are all-reduced)
+    order = sorted(range(len(runs)), key=lambda i: runs[i]['elapsed'])
+    med = runs[order[len(order) // 2]]
+    elapsed, psteps, tm = med['elapsed'], med['psteps'], med['tm']
     value = psteps / elapsed
 
     if rank == 0:
         live_rank = tm['live'] / world if world > 1 else tm['live']
-        k_ms = tm['step_kernel_ms']
+        k_ms = float(np.median([r['tm']['step_kernel_ms'] for r in runs]))
         achieved = BYTES_PER_PHONON_STEP * live_rank / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         traffic = None
-        tf = os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.json')
-        if os.path.exists(tf) and world == 1 and int(a.particles) == 10000000 and a.mesh_n == 31:
+        tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # written by scripts/profile_round.sh from a PMC pass
+        if os.path.exists(tf) and world == 1 and a.config == 'c2' and int(per_gpu) == 10000000 and a.mesh_n == 31:
             try:
                 traffic = json.load(open(tf)).get('k_sweep_hbm_bytes_per_launch')
             except Exception:
                 traffic = None
+        ms = [1e3 * r['elapsed'] / a.steps for r in runs]
         out = {
             'metric': 'phonon-steps/sec (whole node)', 'value': value, 'unit': 'phonon-steps/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'Si-like synthetic %d^3x6 modes, box %gx%gx%g A, slice 20 subvols, BCs T T P, dt 1 ps, '
-                                   '%.0e particles per GPU (BASELINE configs[1])' % (a.mesh_n, a.box, a.box, a.box, a.particles),
+            'repeats': a.repeats, 'ms_per_step_min': min(ms), 'ms_per_step_max': max(ms),
+            'timing': 'median of %d timed regions of %d steps each (barrier + drained stream on both sides, max over ranks)'
+                      % (a.repeats, a.steps),
+            'config': {'workload': '%s-like synthetic %d^3x6 modes, %s, dt 1 ps, %.3g particles per GPU (BASELINE config %s)'
+                                   % (species, a.mesh_n, desc, per_gpu, a.config),
                        'particles_total': total, 'live_particles_end': tm['live'], 'parallelism': 'particle-shard x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
@@ -256,14 +344,15 @@ def main():
                          'frac_whole_step': BYTES_PER_PHONON_STEP * value / 1e9 / HBM_PEAK_GBS / max(world, 1),
                          'algorithmic_bytes_per_launch': BYTES_PER_PHONON_STEP * live_rank},
         }
-        if world == 1 and not a.no_cpu_baseline:
+        if cpu_legs:
             out['cpu_baseline'] = cpu_baseline(geo, ph, a.mesh_n)
             if all_cores is not None:
                 out['cpu_baseline_all_cores'] = all_cores
+        out['cpu_reference_numpy'] = CPU_REFERENCE_NUMPY
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+        sys.stdout.flush()
+    rdv.barrier()
+    rdv.close()
 
 
 if __name__ == '__main__':

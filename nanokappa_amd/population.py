@@ -10,6 +10,7 @@ listed in SURVEY.md section 8b are read.  The particle state lives in HBM inside
 keeps the tallies (subvolume temperatures, energies, fluxes, reservoir balances), the convergence bookkeeping
 and the text outputs.  There is no CPU fallback: without the library / a GPU the constructor raises.
 """
+import inspect
 import os
 import sys
 from datetime import datetime
@@ -150,7 +151,7 @@ class Population(Constants):
         pos, modes, occ = self.initialise_all_particles(geometry, phonon)
 
         self._configure_engine(geometry, phonon)
-        if comm is not None and self.nranks > 1:
+        if comm is not None:               # nk_comm_init decides what one rank needs (rank / nranks; NK_FORCE_COMM)
             self.engine.comm_init(comm[0], self.rank, self.nranks)
         J = phonon.number_of_branches
         self.engine.reserve(int(1.5 * pos.shape[0]) + 65536)
@@ -198,7 +199,8 @@ class Population(Constants):
             self.correspondent_modes, self.true_specular = ST.specular_correspondences_k(geometry, phonon, self.rough_facets)
         elif self.scat_model in ('v', 'vel', 'velocity', 'groupvel', 'group_vel'):
             self.correspondent_modes, self.true_specular = ST.specular_correspondences_velocity(
-                geometry, phonon, self.rough_facets, engine=self.engine)        # pair search on the GPU
+                geometry, phonon, self.rough_facets,
+                engine=(self.engine if hasattr(self.engine, 'specular_begin') else None))   # pair search on the GPU
         else:
             raise Exception('Invalid --bound_scat')
         self.specularity = self.true_specular.astype(int) * spec0                  # Population.py:1459
@@ -237,13 +239,22 @@ class Population(Constants):
             modes = self.unique_modes[self.prng.integers(0, phonon.number_of_active_modes, size=self.N_local), :]
         return modes.astype(int)
 
+    def _sample_volume(self, mesh, n):
+        """Uniform points of the volume.  This package's Mesh takes the generator (reproducible per rank); the
+        reference's `Mesh.sample_volume(self, n)` (Mesh.py:890) draws from NumPy's global state."""
+        try:
+            takes_rng = len(inspect.signature(mesh.sample_volume).parameters) >= 2
+        except (TypeError, ValueError):
+            takes_rng = False
+        return np.asarray(mesh.sample_volume(n, self.prng) if takes_rng else mesh.sample_volume(n), dtype=float)
+
     def initialise_all_particles(self, geometry, phonon):
         """Positions, modes, temperatures, occupations (Population.py:186-321)."""
         key = self.args.part_dist[0]
         S = self.n_of_subvols
         NL = self.N_local
         if key == 'random_domain':
-            pos = geometry.mesh.sample_volume(NL, self.prng)
+            pos = self._sample_volume(geometry.mesh, NL)
         elif key == 'center_domain':
             pos = np.ones((NL, 3)) * geometry.mesh.center_mass
         elif key == 'random_subvol':
@@ -255,7 +266,7 @@ class Population(Constants):
             have = np.zeros(S, dtype=int)
             while np.any(have < n):
                 batch = int(min(max((n - have).sum() * 1.2, 1e4), 4e6))
-                x_new = geometry.mesh.sample_volume(batch, self.prng)
+                x_new = self._sample_volume(geometry.mesh, batch)
                 sv = geometry.subvol_classifier.predict(x_new) if S > 1 else np.zeros(batch, dtype=int)
                 order = np.argsort(sv, kind='stable')
                 counts = np.bincount(sv, minlength=S)

@@ -214,3 +214,20 @@ def population_in_mesh(ct, n, seed, T0=298.0):
     occ = ph.calculate_occupation(T0, ph.omega.ravel()[mode])
     counter = rng.random(ct['enter_prob'].shape)
     return pos, mode, occ, counter
+
+
+def case_from_dropin(case):
+    """The tables nanokappa_amd.Population uploaded when it was constructed from the REFERENCE's own Geometry / Phonon
+    objects (tests/golden/make_dropin.py), in the shape of case_tables(); plus the particles it created."""
+    g = sub(golden('dropin'), case)
+    mat, mesh, sv, res, par, prt = (sub(g, k) for k in ('material', 'mesh', 'subvols', 'res', 'params', 'particles'))
+    Q, J = mat['omega'].shape
+    ct = dict(ph=None, J=J, M=Q * J, mesh=mesh, tables=mat, centers=sv['centers'], volumes=sv['volumes'], axis=int(sv['axis']),
+              kind=int(sv['kind']), interp=int(sv['interp']), T_sv=sv['T_sv'], res_facets=res['facets'], res_T=res['T'],
+              enter_prob=res['enter_prob'], counter=res['counter'], particle_density=float(par['particle_density']),
+              positions=prt['positions'], mode=prt['mode'], occ=prt['occ'], rough=None)
+    r = sub(g, 'rough')
+    if r:
+        ct['rough'] = dict(facets=r['facets'], specularity=r['specularity'], true_spec=r['true_spec'], spec_map=r['spec_map'],
+                           roulette=r['roulette'])
+    return ct
