@@ -128,6 +128,10 @@ typedef struct {
     double T_ref;
     int32_t flux_every;       /* tally the subvolume heat flux every this many steps (n_dt_to_conv = 10) */
     int32_t contains_every;   /* contains_check period (100, Population.py:1729-1734); 0 = never */
+    int32_t track_ids;        /* 0: 64-bit particle ids are stored only when the configuration draws random numbers per
+                               *    particle (rough facets) -- 44 instead of 52 bytes of state per particle; downloads then
+                               *    return pid = 0.  1: always stored (ids as uploaded / as nk_upload_particles numbers them).
+                               *    The reference has no particle ids; they only key the counter-based RNG. */
 } nk_params;
 
 /* Per-step results of nk_step; every pointer may be NULL.  Row r describes the r-th step of the call.
@@ -148,7 +152,7 @@ typedef struct {
 /* Kernel timing of the last nk_step call, from HIP events on the library's stream. */
 typedef struct {
     double step_kernel_ms;   /* mean duration of k_sweep: relax + drift + boundary events + emission + tally */
-    double emit_kernel_ms;   /* mean duration of k_emit_count (reservoir counters, spawn list) */
+    double emit_kernel_ms;   /* mean duration of k_emit_one_to_one ('one_to_one' reservoirs only; else the sweep emits) */
     double events_kernel_ms; /* mean duration of the step's tail: k_reduce (+ all-reduce) + k_update */
     double total_ms;         /* wall time of the whole call on the stream */
     int64_t slots;           /* particle capacity (nseg * segcap) */
@@ -178,7 +182,9 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
                         const uint64_t *pid, uint64_t pid_offset);
 /* Population.timesteps_to_boundary for the whole population (Population.py:310-314) */
 int nk_init_boundaries(nk_ctx *ctx);
-/* Population.run_timestep x nsteps (Population.py:1724-1769) without the file output */
+/* Population.run_timestep x nsteps (Population.py:1724-1769) without the file output.  The particle store grows by
+ * itself (on the device, nothing is dropped) when the ensemble outgrows it, like the reference's arrays do; NK_ERR_CAPACITY
+ * only if that growth fails (out of memory), with the state of the last completed step intact. */
 int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out);
 /* live particles, in slot order; arrays may be NULL; *N_out receives the count (call with capacity 0 to query) */
 int nk_download_particles(nk_ctx *ctx, int64_t capacity, double *x, double *y, double *z, int32_t *mode,
@@ -198,7 +204,8 @@ int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x /* [n*3] */, const 
 int nk_classify(nk_ctx *ctx, int64_t n, const double *x, int32_t *id);           /* Geometry.py:1212 */
 int nk_eval(nk_ctx *ctx, int32_t what, int64_t n, const double *a, const int32_t *mode, double *out);
 /* what: 0 occupation(T=a[i], omega[mode[i]]) Phonon.py:338; 1 lifetime(T=a[i], mode[i]) Phonon.py:336;
- *       2 T(E=a[i]) Phonon.py:387; 3 E(T=a[i]) Phonon.py:390; 4 per-particle T at x=a[3i..] Population.py:696 */
+ *       2 T(E=a[i]) Phonon.py:387; 3 E(T=a[i]) Phonon.py:390; 4 per-particle T at x=a[3i..] Population.py:696;
+ *       5 the kernels' own exp(a[i]) */
 int nk_reflect(nk_ctx *ctx, int64_t n, const int32_t *facet, const int32_t *mode_in, const double *col_pos,
                const double *n_in, const double *omega_in, const double *r_spec, const double *r_deg,
                const double *r_diff, int32_t *mode_out, double *n_out, double *omega_out); /* Population.py:941-1015 */

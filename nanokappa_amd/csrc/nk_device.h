@@ -1,11 +1,16 @@
 // nk_device.h -- device-side data model and per-particle physics of the MI355X engine.
 //
-// One particle = one lane.  Particle state is SoA in HBM (x, y, z, occupation, time-to-boundary as doubles; mode and
-// next facet as int32; a 64-bit particle id that keys the counter-based RNG), split into `nseg` equal segments; a
-// segment holds its live particles contiguously from its start and is owned by one wave at a time.  Small
-// read-only tables (planes, faces, facets, slice centres, subvolume temperatures), the tally bins and the per-workgroup
-// event buffer live in LDS; per-mode records (64 B: omega, group velocity and the four lifetime rows around the live
-// temperature range) are gathered through L2 (particles of one segment come in runs of neighbouring modes).
+// One particle = one lane.  Particle state is SoA in HBM: x, y, z, occupation, time-to-boundary (doubles), ONE packed
+// 32-bit word {next facet + 1 | mode index} and -- only when something draws random numbers per particle (rough facets)
+// or the caller asks for it -- a 64-bit particle id that keys the counter-based RNG: 44 or 52 bytes per particle.
+// The store is split into `nseg` equal segments; a segment holds its live particles contiguously from its start and is
+// owned by one wave at a time.
+// Modes are PARTITIONED over the segments: mode m belongs to segment m % nseg and is stored as the local index m / nseg
+// (a few bits).  A segment therefore only ever touches its own few dozen 64-byte mode records (they sit contiguously in a
+// permuted copy of the mode table and stay in L1/L2), and it emits the reservoir particles of its own modes itself: no
+// spawn list, no global atomics, no gathers across an 11 MB table.  (With rough facets a reflection changes the mode, so
+// those configurations store the global mode index and gather from the plain table, as before; emission is still local.)
+// Small read-only tables (planes, faces, facets, per-slice {centre, T, slope, 1/T}) and the tally bins live in LDS.
 //
 // Reference semantics cited as file:line under the reference checkout (classes/Population.py etc.).
 #pragma once
@@ -20,10 +25,9 @@
 #define NK_FACE_DOUBLES 16   // lo(3) hi(3) o(3) iu(3) iw(3) {orig_face, facet}
 #define NK_LDS_FACES 256     // meshes up to this many faces keep their plane/face tables in LDS
 #define NK_LDS_RESFACES 64   // reservoir facets with up to this many faces in total keep their sampling tables in LDS
-#define NK_TAU_ROWS 4        // lifetime rows packed into each mode record
-#define NK_MAX_SEGMENTS 12288 // upper bound of nseg = 4 x 3072 = 6 x 2048 = 12 x 1024: a whole number of segments per
-                              // resident wave at 3, 2 or 1 workgroups per CU (the update keeps 48 per thread in registers)
-#define NK_EVCAP 512         // entries of the per-workgroup LDS event buffer (< NK_WG pending + NK_WG new)
+#define NK_TAU_ROWS 3        // lifetime rows packed into each mode record (two intervals of the temperature grid)
+#define NK_MAX_SEGMENTS 16384 // upper bound of nseg
+#define NK_EMIT_CHUNK 128    // (reservoir, mode) entries a wave evaluates at a time (two per lane)
 
 // RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")
 #define NK_TAG_REFLECT 0x00000u
@@ -42,18 +46,23 @@ struct __attribute__((aligned(16))) NkFacet {   // 96 bytes
     int32_t pad[2];
 };
 
-struct __attribute__((aligned(64))) NkMode {   // one gather per particle
+struct __attribute__((aligned(64))) NkMode {   // 64 bytes, read as two 32-byte halves
     double omega, vx, vy, vz;
-    double tau[NK_TAU_ROWS];                   // lifetime at T_grid[tau_row0 .. tau_row0+3]
+    double E0;                                 // exp(hbar omega / (kB T0)) at the window's reference temperature T0
+    double tau[NK_TAU_ROWS];                   // lifetime at T_grid[tau_row0 .. tau_row0+2]
 };
 
 // Everything a kernel needs, passed by value (pointers are device pointers).
 struct NkDev {
     // ---- material
     int32_t Q, J, NT, M;              // M = Q*J
-    const NkMode *modetab;            // [M]
+    const NkMode *modetab;            // [M] by mode index
+    const NkMode *modetab_p;          // [nseg * nlmax] permuted copy: record of mode m at (m % nseg) * nlmax + m / nseg
     int32_t tau_row0;                 // first T_grid row held in NkMode::tau
-    double tau_g[NK_TAU_ROWS];        // T_grid[tau_row0 .. tau_row0+3] by value (scalar registers, no loads)
+    double tau_g[NK_TAU_ROWS];        // T_grid[tau_row0 .. tau_row0+2] by value (scalar registers, no loads)
+    double tau_ig[NK_TAU_ROWS - 1];   // 1 / (g[k+1] - g[k]) of the two packed intervals
+    double T0, invT0;                 // reference temperature of NkMode::E0 (middle of the live temperature range)
+    double c_hk;                      // hbar / kB
     const double *tau;                // [NT*M] full table (fallback outside the packed window)
     const double *Tgrid;              // [NT]
     int32_t nE;
@@ -106,10 +115,9 @@ struct NkDev {
     double *res_counter;              // [R*M]
     const double *res_roulette;       // [R*M] 'one_to_one': cumulative enter_prob per reservoir, last = 1 (Population.py:467-468)
     int32_t *nleave_prev;             // [R] 'one_to_one': particles that left at the previous step, all ranks (Population.py:466)
-    double *res_cval[2];              // [R*M] counter / dice value used by the level-1 entry time (buffer = step & 1)
-    uint64_t *spawn_list[2];          // [spawn_cap] (rm << 12 | level) of every particle entering at step k: buffer k & 1.
-    int64_t spawn_cap;                //   The sweep of step k consumes buffer k & 1 and, in its tail, fills buffer
-                                      //   (k+1) & 1 for the next step (k_emit_count primes the first step).
+    uint64_t *sp_inbox;               // 'one_to_one': [nseg * sp_icap] spawn records (i << 40 | rm << 12) routed to the owner
+    int32_t *sp_inbox_n;              //   segment of their mode by k_emit_one_to_one; [nseg] counts (reset by the sweep)
+    int32_t sp_icap;
     // ---- rough facets
     int32_t Fr;
     const double *specularity;        // [Fr*M]
@@ -129,15 +137,17 @@ struct NkDev {
     int64_t cap;
     int32_t nseg, segcap;
     int32_t *seg_count;               // [nseg] live particles per segment (contiguous from the segment start)
-    int64_t *seg_free_prefix;         // [nseg+1] exclusive prefix of the free slots per segment (after the last step):
-                                      // entering particles are dealt to segments in proportion to their free space
     double *x, *y, *z, *occ, *nts;
-    int32_t *mode, *facet;
-    uint64_t *pid;
+    uint32_t *w0;                     // (facet + 1) << lb | idx;  idx = mode / nseg (part) or the mode itself
+    uint64_t *pid;                    // null: particle ids are not tracked (no per-particle random draws in this configuration)
+    int32_t part;                     // 1: idx is the local index of a mode of the owning segment; 0: the global mode index
+    int32_t lb;                       // bits of idx in w0
+    int32_t nlmax;                    // modes per segment, rounded up: ceil(M / nseg)
     // ---- bookkeeping words in device memory
-    int32_t *alloc_count;             // [2] particles entering at step k (this rank) = length of spawn_list[k & 1]
     int32_t *ticket;                  // arrival counter of k_reduce's workgroups (the last one runs the update)
     int32_t *overflow;                // set when a particle had to be dropped for lack of capacity
+    int32_t *halt;                    // set by a sweep whose segments could overflow at the NEXT step: later steps of the same
+                                      // nk_step call do nothing, so the host can grow the store with the state intact
     double *partials;                 // [rows][NB] per-workgroup tally rows
     int32_t NB;                       // bins per row = 5*S + 5*R + 1
     int32_t dbg;                      // developer ablation mask (env NK_DEBUG; only read by the NK_ABLATE build, nk_kernels.h)
@@ -208,10 +218,74 @@ __device__ __forceinline__ double nk_interp_lin_hint(const double *xs, const dou
     double xlo = xs[idx - 1], xhi = xs[idx], ylo = ys[idx - 1], yhi = ys[idx];
     return (yhi - ylo) / (xhi - xlo) * (x - xlo) + ylo;
 }
-// Bose-Einstein occupation, Phonon.py:338-345
-__device__ __forceinline__ double nk_occupation(const NkDev &d, double T, double omega) {
+// ---------------------------------------------------------------------------- lean FP64 arithmetic
+// The hot loop is bound by FP64 issue as much as by HBM (three exponentials and seven divides per phonon-step in the
+// reference's formulas), so the per-particle functions avoid the library exp and the IEEE division sequence:
+//   * 1/x by v_rcp_f64 and two Newton steps (<= 1 ulp; never used where the reference's rounding decides a hit);
+//   * exp(x) by Cody-Waite reduction and a degree-13 Taylor polynomial (|r| <= ln2/2: truncation 4e-18);
+//   * Bose-Einstein occupations from the per-mode E0 = exp(a / T0) of the mode record: exp(a / T) = E0 exp(a (1/T - 1/T0)),
+//     the second factor a degree-10 polynomial while |a (1/T - 1/T0)| < 1/8 (temperatures within ~5 % of T0 for every
+//     mode of Si/Ge), the general exponential otherwise.
+__device__ __forceinline__ double nk_rcp(double x) {
+    double y = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-x, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double nk_exp(double x) {
+    const double k = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
+    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
+    double p = 1.6059043836821613e-10;
+    p = __builtin_fma(p, r, 2.08767569878681e-09);
+    p = __builtin_fma(p, r, 2.505210838544172e-08);
+    p = __builtin_fma(p, r, 2.755731922398589e-07);
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);
+    p = __builtin_fma(p, r, 2.48015873015873e-05);
+    p = __builtin_fma(p, r, 1.984126984126984e-04);
+    p = __builtin_fma(p, r, 0.001388888888888889);
+    p = __builtin_fma(p, r, 0.008333333333333333);
+    p = __builtin_fma(p, r, 0.041666666666666664);
+    p = __builtin_fma(p, r, 0.16666666666666666);
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    const double kc = k < -2000.0 ? -2000.0 : (k > 2000.0 ? 2000.0 : k);
+    return __builtin_ldexp(p, (int)kc);
+}
+__device__ __forceinline__ double nk_exp_small(double dl) {      // exp(dl), |dl| < 1/8: dl^11 / 11! < 3e-18
+    double p = 2.755731922398589e-07;
+    p = __builtin_fma(p, dl, 2.7557319223985893e-06);
+    p = __builtin_fma(p, dl, 2.48015873015873e-05);
+    p = __builtin_fma(p, dl, 1.984126984126984e-04);
+    p = __builtin_fma(p, dl, 0.001388888888888889);
+    p = __builtin_fma(p, dl, 0.008333333333333333);
+    p = __builtin_fma(p, dl, 0.041666666666666664);
+    p = __builtin_fma(p, dl, 0.16666666666666666);
+    p = __builtin_fma(p, dl, 0.5);
+    p = __builtin_fma(p, dl, 1.0);
+    p = __builtin_fma(p, dl, 1.0);
+    return p;
+}
+// Bose-Einstein occupation, Phonon.py:338-345: n0 = 1 / (exp(hbar omega / (kB T)) - 1), 0 where T <= 0 or omega <= 0.
+// a = hbar omega / kB, E0 = exp(a / T0) from the mode record, invT = 1 / T.
+__device__ __forceinline__ double nk_be(double a, double E0, double invT, double invT0) {
+    if (!(a > 0.0) || !(invT > 0.0)) return 0.0;
+    const double dl = a * (invT - invT0);
+    double em1;
+    if (fabs(dl) < 0.125) em1 = __builtin_fma(E0, nk_exp_small(dl), -1.0);
+    else {
+        const double xx = a * invT;
+        if (!(xx < 700.0)) return 0.0;               // T -> 0 (also invT = inf)
+        em1 = nk_exp(xx) - 1.0;
+    }
+    return nk_rcp(em1);
+}
+// the same from a temperature (taps, set-up paths)
+__device__ __forceinline__ double nk_occupation(const NkDev &d, double T, double omega, double E0) {
     if (!(T > 0.0) || !(omega > 0.0)) return 0.0;
-    return 1.0 / (exp(omega * d.hbar / (T * d.kb)) - 1.0);
+    return nk_be(omega * d.c_hk, E0, 1.0 / T, d.invT0);
 }
 // scipy interp1d(kind='linear') evaluation rule on a sorted table
 __device__ __forceinline__ double nk_interp_lin(const double *xs, const double *ys, int n, double x) {
@@ -232,19 +306,17 @@ __device__ __forceinline__ double nk_E_of_T(const NkDev &d, double T) {
     return nk_interp_lin(d.Tarr, d.Earr, d.nE, T);
 }
 // lifetime_function = RegularGridInterpolator((T,q,j), tau) at integer (q,j): linear in tau along T (Phonon.py:336).
-// Out-of-table T gives NaN (the reference raises ValueError there).  `rec` is the particle's mode record; its four
-// packed rows serve the live temperature range, anything else falls back to the full table.
-__device__ __forceinline__ double nk_lifetime(const NkDev &d, double tau0, double tau1, double tau2, double tau3, double T,
-                                              int mode) {
-    // Fast path: T strictly inside the packed window (g0, g3].  searchsorted-left - 1 puts T in (g_k, g_k+1] at
-    // interval k, so two compares select it; grid values come from scalar registers, lifetimes from the mode record.
-    if (T > d.tau_g[0] && T <= d.tau_g[3]) {
-        const bool b1 = T > d.tau_g[1], b2 = T > d.tau_g[2];
-        const double glo = b2 ? d.tau_g[2] : (b1 ? d.tau_g[1] : d.tau_g[0]);
-        const double ghi = b2 ? d.tau_g[3] : (b1 ? d.tau_g[2] : d.tau_g[1]);
-        const double t0 = b2 ? tau2 : (b1 ? tau1 : tau0);
-        const double t1 = b2 ? tau3 : (b1 ? tau2 : tau1);
-        const double y = (T - glo) / (ghi - glo);
+// Out-of-table T gives NaN (the reference raises ValueError there).  ta, tb, tc are the three rows packed into the
+// particle's mode record (two grid intervals around the live temperature range); anything else reads the full table.
+__device__ __forceinline__ double nk_lifetime(const NkDev &d, double ta, double tb, double tc, double T, int mode) {
+    // Fast path: T inside the packed window (g0, g2].  searchsorted-left - 1 puts T in (g_k, g_k+1] at interval k; grid
+    // values and reciprocal widths come from scalar registers, lifetimes from the mode record.
+    if (T > d.tau_g[0] && T <= d.tau_g[2]) {
+        const bool b = T > d.tau_g[1];
+        const double glo = b ? d.tau_g[1] : d.tau_g[0];
+        const double ig = b ? d.tau_ig[1] : d.tau_ig[0];
+        const double t0 = b ? tb : ta, t1 = b ? tc : tb;
+        const double y = (T - glo) * ig;
         return t0 * (1.0 - y) + t1 * y;
     }
     const int NT = d.NT;
@@ -257,29 +329,34 @@ __device__ __forceinline__ double nk_lifetime(const NkDev &d, double tau0, doubl
     i -= 1;
     i = i < 0 ? 0 : (i > NT - 2 ? NT - 2 : i);
     const double y = (T - g[i]) / (g[i + 1] - g[i]);
-    const int k = i - d.tau_row0;
-    double t0, t1;
-    if (k >= 0 && k < NK_TAU_ROWS - 1) {
-        t0 = k == 0 ? tau0 : (k == 1 ? tau1 : tau2);
-        t1 = k == 0 ? tau1 : (k == 1 ? tau2 : tau3);
-    } else {
-        t0 = d.tau[(int64_t)i * d.M + mode];
-        t1 = d.tau[(int64_t)(i + 1) * d.M + mode];
-    }
+    const double t0 = d.tau[(int64_t)i * d.M + mode];
+    const double t1 = d.tau[(int64_t)(i + 1) * d.M + mode];
     return t0 * (1.0 - y) + t1 * y;
 }
 
 // --------------------------------------------------------------------------------- subvolume lookups
-// `cen` points at the S*3 centres (LDS copy inside the hot kernels), `Tsv` at the S temperatures.
+// Per-subvolume record staged in LDS by the kernels (one 32-byte read pair per lookup): centre along the slice axis,
+// temperature, slope of the piecewise-linear profile towards the next centre, 1 / T.
+struct __attribute__((aligned(16))) NkSv { double c, T, slope, invT; };
+struct NkSvTab {
+    const double *cen;     // [3 S] centres
+    const double *Tsv;     // [S + rbf_P] temperatures, then the RBF coefficients
+    const NkSv *sv;        // [S]
+};
 // SubvolClassifier.predict, Geometry.py:1198-1213: nearest centre.
-__device__ __forceinline__ int nk_classify(const NkDev &d, const double *cen, double x, double y, double z) {
+__device__ __forceinline__ int nk_classify(const NkDev &d, const NkSvTab &tb, double x, double y, double z) {
     const int S = d.S;
+    const double *cen = tb.cen;
     if (d.sv_kind == 0) {
         const int a = d.sv_axis;
-        double xa = a == 0 ? x : (a == 1 ? y : z);
-        int s = (int)floor((xa - d.sv_lo) * d.sv_invL);
+        const double xa = a == 0 ? x : (a == 1 ? y : z);
+        const double t = (xa - d.sv_lo) * d.sv_invL, fl = floor(t);
+        int s = (int)fl;
         s = s < 0 ? 0 : (s > S - 1 ? S - 1 : s);
-        // the guess and both neighbours in one round of reads; the walks below only run when the guess was off
+        // well inside a slice the nearest centre is the slice's own (the margin is far above any rounding of t); only a
+        // point within 1e-9 of a slice edge takes the exact comparison below, where ties go to the lower index
+        const double f = t - fl;
+        if (f > 1e-9 && f < 1.0 - 1e-9) return s;
         const double cm = cen[3 * (s > 0 ? s - 1 : 0) + a], c0 = cen[3 * s + a], cp = cen[3 * (s + 1 < S ? s + 1 : S - 1) + a];
         const double d0 = fabs(xa - c0);
         if (s + 1 < S && fabs(xa - cp) < d0) {
@@ -300,17 +377,17 @@ __device__ __forceinline__ int nk_classify(const NkDev &d, const double *cen, do
     }
     return best;
 }
-// per-particle temperature, Population.py:570-571, :694-702
+// per-particle temperature, Population.py:570-571, :694-702; also returns 1 / T (from the table where T is a subvolume's)
 // RBF = false compiles the radial-basis branch out (the sweep is instantiated with and without it: inlined it costs
 // registers in every configuration, and it is a rarely used mode).
 template <bool RBF = true>
-__device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen, const double *Tsv, double x, double y,
-                                              double z, int sv_hint) {
+__device__ __forceinline__ double nk_interp_T(const NkDev &d, const NkSvTab &tb, double x, double y, double z, double &invT) {
     const int S = d.S;
+    const double *cen = tb.cen;
     if (RBF && d.sv_interp == 3) {
         // RBFInterpolator(kernel='cubic'): sum_i w_i |x - c_i|^3 + p_0 + sum_k p_k (x_k - shift_k) / scale_k; the
         // coefficients follow the temperatures in the same array (k_update refreshes them with every new T_sv)
-        const double *w = Tsv + S;
+        const double *w = tb.Tsv + S;
         double out = 0.0;
         for (int i = 0; i < S; ++i) {
             const double dx = d.rbf_used[0] ? x - cen[3 * i] : 0.0, dy = d.rbf_used[1] ? y - cen[3 * i + 1] : 0.0,
@@ -323,39 +400,36 @@ __device__ __forceinline__ double nk_interp_T(const NkDev &d, const double *cen,
         if (d.rbf_used[0]) out += w[q++] * ((x - d.rbf_shift[0]) / d.rbf_scale[0]);
         if (d.rbf_used[1]) out += w[q++] * ((y - d.rbf_shift[1]) / d.rbf_scale[1]);
         if (d.rbf_used[2]) out += w[q++] * ((z - d.rbf_shift[2]) / d.rbf_scale[2]);
+        invT = nk_rcp(out);
         return out;
     }
-    if (d.sv_interp == 2 || S == 1) return Tsv[sv_hint >= 0 ? sv_hint : nk_classify(d, cen, x, y, z)];
+    if (d.sv_interp == 2 || S == 1) { const NkSv q = tb.sv[S == 1 ? 0 : nk_classify(d, tb, x, y, z)]; invT = q.invT; return q.T; }
     const int a = d.sv_axis;
-    double xa = a == 0 ? x : (a == 1 ? y : z);
-    int g = (int)floor((xa - d.sv_lo) * d.sv_invL);
+    const double xa = a == 0 ? x : (a == 1 ? y : z);
+    const double t = (xa - d.sv_lo) * d.sv_invL, fl = floor(t);
+    int g = (int)fl;
     g = g < 0 ? 0 : (g > S - 1 ? S - 1 : g);
     if (d.sv_interp == 1) {
-        // searchsorted(centres, xa, 'left') lands on g or g+1 for slices; read both candidate brackets at once
-        {
-            const int gm = g > 0 ? g - 1 : 0, gp = g + 1 < S ? g + 1 : S - 1;
-            const double cm = cen[3 * gm + a], c0 = cen[3 * g + a], cp = cen[3 * gp + a];
-            const double Tm = Tsv[gm], T0 = Tsv[g], Tp = Tsv[gp];
-            if ((g == 0 || cm < xa) && (g + 1 >= S || !(cp < xa))) {
-                int idx = g + (c0 < xa ? 1 : 0);
-                idx = idx < 1 ? 1 : (idx > S - 1 ? S - 1 : idx);
-                const bool lower = idx == g;              // bracket (g-1, g), else (g, g+1)
-                const double xlo = lower ? cm : c0, xhi = lower ? c0 : cp, ylo = lower ? Tm : T0, yhi = lower ? T0 : Tp;
-                return (yhi - ylo) / (xhi - xlo) * (xa - xlo) + ylo;
-            }
-        }
-        int idx = g;
-        while (idx < S && cen[3 * idx + a] < xa) ++idx;
-        while (idx > 0 && cen[3 * (idx - 1) + a] >= xa) --idx;
+        // interp1d 'linear' with extrapolation: idx = searchsorted(centres, xa, 'left') clipped to [1, S-1], bracket
+        // (idx-1, idx).  The slice guess g is off by at most one (rounding of t at a slice edge), so xa lies between the
+        // centres g-1 and g+1 and one comparison with centre g decides: idx = g + (c_g < xa).
+        int idx = g + (tb.sv[g].c < xa ? 1 : 0);
         idx = idx < 1 ? 1 : (idx > S - 1 ? S - 1 : idx);
-        double xlo = cen[3 * (idx - 1) + a], xhi = cen[3 * idx + a], ylo = Tsv[idx - 1], yhi = Tsv[idx];
-        return (yhi - ylo) / (xhi - xlo) * (xa - xlo) + ylo;
+        const NkSv q = tb.sv[idx - 1];                // slope = (T[idx] - T[idx-1]) / (c[idx] - c[idx-1])
+        const double T = q.slope * (xa - q.c) + q.T;
+        invT = nk_rcp(T);
+        return T;
     }
-    // interp1d 'nearest': bounds b[i] = c[i+1]/2 + c[i]/2, idx = #(b < xa)
+    // interp1d 'nearest': bounds b[i] = c[i+1]/2 + c[i]/2, idx = #(b < xa); away from a slice edge that is the slice itself
     int idx = g;
-    while (idx < S - 1 && (cen[3 * (idx + 1) + a] / 2.0 + cen[3 * idx + a] / 2.0) < xa) ++idx;
-    while (idx > 0 && !((cen[3 * idx + a] / 2.0 + cen[3 * (idx - 1) + a] / 2.0) < xa)) --idx;
-    return Tsv[idx];
+    const double f = t - fl;
+    if (!(f > 1e-9 && f < 1.0 - 1e-9)) {
+        while (idx < S - 1 && (cen[3 * (idx + 1) + a] / 2.0 + cen[3 * idx + a] / 2.0) < xa) ++idx;
+        while (idx > 0 && !((cen[3 * idx + a] / 2.0 + cen[3 * (idx - 1) + a] / 2.0) < xa)) --idx;
+    }
+    const NkSv q = tb.sv[idx];
+    invT = q.invT;
+    return q.T;
 }
 
 // -------------------------------------------------------------------------------------- ray casting
@@ -562,11 +636,13 @@ __device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, int skip, 
 }
 
 // ---------------------------------------------------------------------------------- rough reflection
-// select_reflected_modes + pick_diffuse_modes, Population.py:941-1015.
+// select_reflected_modes + pick_diffuse_modes, Population.py:941-1015.  E0 travels with omega (a specular reflection keeps
+// both of the incoming mode).
 template <bool RBF = true>
-__device__ __forceinline__ void nk_reflect(const NkDev &d, const double *cen, const double *Tsv, int rough_idx, int mode_in,
-                                           double cx, double cy, double cz, double n_in, double omega_in, double r_spec,
-                                           double r_deg, double r_diff, int &mode_out, double &n_out, double &omega_out) {
+__device__ __forceinline__ void nk_reflect(const NkDev &d, const NkSvTab &tb, int rough_idx, int mode_in,
+                                           double cx, double cy, double cz, double n_in, double omega_in, double E0_in,
+                                           double r_spec, double r_deg, double r_diff, int &mode_out, double &n_out,
+                                           double &omega_out, double &E0_out) {
     int64_t idx = (int64_t)rough_idx * d.M + mode_in;
     bool spec = d.true_spec[idx] && (r_spec <= d.specularity[idx]);
     if (spec) {
@@ -575,14 +651,13 @@ __device__ __forceinline__ void nk_reflect(const NkDev &d, const double *cen, co
             int j2 = d.degen_j2[out];
             if (j2 > -1 && r_deg >= 0.5) out = (out / d.J) * d.J + j2;
         }
-        mode_out = out; n_out = n_in; omega_out = omega_in;         // keeps the incoming omega
+        mode_out = out; n_out = n_in; omega_out = omega_in; E0_out = E0_in;
     } else {
         const double *roul = d.roulette + (int64_t)rough_idx * d.M;
         double r = r_diff * roul[d.M - 1];
         // np.searchsorted(roulette, r) (Population.py:1005) through a bucket index: r_diff in [k, k+1) / roul_nlut brackets
         // the answer between two precomputed positions about four entries apart, so the bisection is a chain of ~2
-        // dependent global loads instead of ~18 over the whole table (and ~8 with the 1024 buckets this started with);
-        // same result
+        // dependent global loads instead of ~18 over the whole table; same result
         const int nlut = d.roul_nlut;
         int kb = (int)(r_diff * (double)nlut);
         kb = kb < 0 ? 0 : (kb > nlut - 1 ? nlut - 1 : kb);
@@ -592,8 +667,10 @@ __device__ __forceinline__ void nk_reflect(const NkDev &d, const double *cen, co
         if (flat > d.M - 1) flat = d.M - 1;
         mode_out = flat;
         omega_out = d.modetab[flat].omega;
-        double T = nk_interp_T<RBF>(d, cen, Tsv, cx, cy, cz, -1);
-        n_out = nk_occupation(d, T, omega_out);
+        E0_out = d.modetab[flat].E0;
+        double invT;
+        nk_interp_T<RBF>(d, tb, cx, cy, cz, invT);
+        n_out = nk_be(omega_out * d.c_hk, E0_out, invT, d.invT0);
     }
 }
 
@@ -606,16 +683,15 @@ struct NkBins {
 };
 
 struct NkParticle {
-    double x, y, z, occ, nts, omega, vx, vy, vz;
-    int mode, facet;
-    bool alive;
+    double x, y, z, occ, nts, omega, E0, vx, vy, vz;
+    int mode, facet;          // mode: the GLOBAL mode index
 };
 
 // Boundary events inside a timestep: Population.boundary_scattering (Population.py:1546-1683) restated per particle.
 // On entry (x,y,z) is the end-of-step position of the free drift and nts < 0 (first call: cts = 0, ev = 0).
 // ONE event per call: the reference loops "while any particle still has time left"; here a particle that needs another
-// event goes back to the event buffer and joins the next batch, so every pass of the wave runs 64 particles with
-// exactly one event each (a while-loop per lane would idle most lanes: few particles cross more than one wall).
+// event stays in the wave's carry registers and joins the next batch, so every pass of the wave runs up to 64 particles
+// with exactly one event each (a while-loop per lane would idle most lanes: few particles cross more than one wall).
 // Returns NK_EV_DONE (remainder drifted, particle final), NK_EV_DEAD (absorbed) or NK_EV_MORE (another event pending;
 // cts / ev carry the consumed fraction of the step and the event count, which also numbers the RNG draws).
 // ROUGH = false compiles the rough-facet branch out (meshes without 'R' facets): fewer registers in the sweep.
@@ -623,10 +699,9 @@ struct NkParticle {
 #define NK_EV_DEAD 1
 #define NK_EV_MORE 2
 template <bool ROUGH, bool RBF = true>
-__device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double *planes,
-                                            const double *faces, const NkFacet *facets, const double *cen, const double *Tsv,
-                                            const double *resT, NkBins &b, NkParticle &p, double &cts, uint32_t &ev,
-                                            uint64_t pid, uint32_t step) {
+__device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double *planes, const double *faces,
+                                            const NkFacet *facets, const NkSvTab &tb, const double *resT, NkBins &b,
+                                            NkParticle &p, double &cts, uint32_t &ev, uint64_t pid, uint32_t step) {
     const double dt = d.dt;
     {
         int fi = p.facet < 0 ? d.Fc - 1 : p.facet;          // a miss indexes the last facet
@@ -634,21 +709,16 @@ __device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double
         if (fc.bc == 'T' || fc.bc == 'F') {                 // I. absorbed by a reservoir, Population.py:1568-1608
             int r = p.facet < 0 ? -1 : fc.res;
             if (r >= 0) {
-                double Tr = d.T_ref_local ? resT[r] : d.T_ref;
-                double e = d.hbar * p.omega * (p.occ - nk_occupation(d, Tr, p.omega));
+                const double n0 = d.T_ref_local ? nk_be(p.omega * d.c_hk, p.E0, resT[2 * r + 1], d.invT0)
+                                                : nk_occupation(d, d.T_ref, p.omega, p.E0);
+                double e = d.hbar * p.omega * (p.occ - n0);
                 double vn = p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz;
-#ifdef NK_ABLATE
-                if (!(d.dbg & 64))
-#endif
-                {
                 atomicAdd(&b.nleave[r], 1u);
                 atomicAdd(&b.resb[4 * r + 0], -e);
                 atomicAdd(&b.resb[4 * r + 1], e * p.vx / vn);
                 atomicAdd(&b.resb[4 * r + 2], e * p.vy / vn);
                 atomicAdd(&b.resb[4 * r + 3], e * p.vz / vn);
-                }
             }
-            p.alive = false;
             return NK_EV_DEAD;
         }
         double tcol = p.nts * dt;
@@ -664,16 +734,13 @@ __device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double
             double r0, r1;
             nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);
             p.x = cx; p.y = cy; p.z = cz;
-            int mo; double no, oo;
-            nk_reflect<RBF>(d, cen, Tsv, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, r0, r1, r1, mo, no, oo);
-            p.mode = mo; p.occ = no; p.omega = oo;
+            int mo; double no, oo, eo;
+            nk_reflect<RBF>(d, tb, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, p.E0, r0, r1, r1, mo, no, oo, eo);
+            p.mode = mo; p.occ = no; p.omega = oo; p.E0 = eo;
             const NkMode *rec = d.modetab + mo;
             p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
         }
         double tc; int fcn;
-#ifdef NK_ABLATE
-        if (d.dbg & 32) { tc = 3.0 * dt; fcn = p.facet; } else
-#endif
         if (NG > 0) nk_find_boundary_tree(d, NK_TREE_NO_SKIP, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);   // (walls are small facets)
         else nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
         p.nts = tc / dt;
@@ -690,12 +757,12 @@ __device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double
 }
 
 // Population.calculate_energy's per-particle part (Population.py:704-717) + the heat-flux sum (:734-736).
-__device__ __forceinline__ void nk_tally_one(const NkDev &d, const double *cen, const double *Tsv, NkBins &b, double x,
-                                             double y, double z, double occ, double omega, double vx, double vy, double vz,
+__device__ __forceinline__ void nk_tally_one(const NkDev &d, const NkSvTab &tb, NkBins &b, double x, double y, double z,
+                                             double occ, double omega, double E0, double vx, double vy, double vz,
                                              bool do_flux, int rep) {
-    int s = nk_classify(d, cen, x, y, z);
-    double Tr = d.T_ref_local ? Tsv[s] : d.T_ref;
-    double e = d.hbar * omega * (occ - nk_occupation(d, Tr, omega));
+    const int s = nk_classify(d, tb, x, y, z);
+    const double n0 = d.T_ref_local ? nk_be(omega * d.c_hk, E0, tb.sv[s].invT, d.invT0) : nk_occupation(d, d.T_ref, omega, E0);
+    const double e = d.hbar * omega * (occ - n0);
     atomicAdd(&b.E[rep * d.S + s], e);
     atomicAdd(&b.N[rep * d.S + s], 1u);
     if (do_flux) {

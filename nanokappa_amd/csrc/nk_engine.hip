@@ -40,6 +40,8 @@ struct nk_ctx {
     std::vector<int32_t> h_seg_count;
     std::vector<hipEvent_t> evpool;
     int g_sweep_key = -1;              // which k_sweep instantiation g_sweep was sized for
+    int layout_key = -1;               // how the particle store was laid out: 1 modes partitioned | 2 ids tracked
+    std::vector<double> h_enter_prob;  // host copy of enter_prob (sizes the segments' head room)
     // set-up table builder state (nk_specular_*)
     int64_t spec_M = 0;
     double *spec_v = nullptr, *spec_om = nullptr, *spec_dl = nullptr, *spec_svx = nullptr;
@@ -49,8 +51,12 @@ struct nk_ctx {
     int32_t *spec_in = nullptr, *spec_out = nullptr;
     unsigned long long *spec_count = nullptr;
     int64_t spec_cap = 0;
-    bool spawn_ready = false;         // spawn_list[step & 1] already holds the particles entering at the next step
-    double *acc = nullptr;         // [NB]
+    int64_t o2o_first = 0;            // 'one_to_one': particles entering at the first step (sizes the spawn inboxes)
+    bool stepped = false;             // a timestep has run (the emission ownership of a rank is fixed from then on)
+    NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
+    int64_t modetab_p_len = 0;
+    void *inbox = nullptr, *inbox_n = nullptr;   // 'one_to_one' spawn inboxes (sized with nseg)
+    double *acc = nullptr;         // [NB + 1]
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
     nk_params params;
@@ -96,10 +102,10 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 
 // 1 = ray-casting tables fit LDS, 2 = they stay in global memory
 static inline int nk_geom_mode(const nk_ctx *ctx) { return (ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES) ? 1 : 2; }
-static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool evbuf = false) {
+static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool emit = false) {
     const NkDev &d = ctx->d;
     const int gm = geom ? nk_geom_mode(ctx) : 0;
-    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, evbuf, (gm == 1 && d.res_lds) ? d.res_nf : 0, d.rbf_P);
+    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, emit, (gm == 1 && d.res_lds) ? d.res_nf : 0, d.rbf_P);
 }
 #define NK_GEOM_LAUNCH(kernel, grid, lds, ...)                                                        \
     do {                                                                                               \
@@ -107,37 +113,59 @@ static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool evbuf = false) {
         else kernel<2><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);                                \
     } while (0)
 static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
-// The sweep is instantiated per (table placement, rough facets, RBF temperatures): run STMT with KERNEL bound to the one
-// that matches.
-#define NK_SWEEP_CASE(G, R, B, STMT) { auto KERNEL = k_sweep<G, R, B>; STMT; }
-#define NK_SWEEP_DISPATCH(gm, rough, rbf, STMT)                                                       \
+// The sweep is instantiated per (table placement, rough facets, RBF temperatures, particle ids): run STMT with KERNEL bound
+// to the one that matches.  Rough facets draw random numbers per particle, so they imply ids.
+#define NK_SWEEP_CASE(G, R, B, P, STMT) { auto KERNEL = k_sweep<G, R, B, P>; STMT; }
+#define NK_SWEEP_CASE_RP(G, B, rough, pid, STMT)                                                      \
+    { if (rough) NK_SWEEP_CASE(G, true, B, true, STMT) else if (pid) NK_SWEEP_CASE(G, false, B, true, STMT) else NK_SWEEP_CASE(G, false, B, false, STMT) }
+#define NK_SWEEP_DISPATCH(gm, rough, rbf, pid, STMT)                                                  \
     do {                                                                                               \
-        if ((gm) == 1) {                                                                               \
-            if (rough) { if (rbf) NK_SWEEP_CASE(1, true, true, STMT) else NK_SWEEP_CASE(1, true, false, STMT) }       \
-            else { if (rbf) NK_SWEEP_CASE(1, false, true, STMT) else NK_SWEEP_CASE(1, false, false, STMT) }            \
-        } else {                                                                                       \
-            if (rough) { if (rbf) NK_SWEEP_CASE(2, true, true, STMT) else NK_SWEEP_CASE(2, true, false, STMT) }       \
-            else { if (rbf) NK_SWEEP_CASE(2, false, true, STMT) else NK_SWEEP_CASE(2, false, false, STMT) }            \
-        }                                                                                              \
+        if ((gm) == 1) { if (rbf) NK_SWEEP_CASE_RP(1, true, rough, pid, STMT) else NK_SWEEP_CASE_RP(1, false, rough, pid, STMT) }   \
+        else { if (rbf) NK_SWEEP_CASE_RP(2, true, rough, pid, STMT) else NK_SWEEP_CASE_RP(2, false, rough, pid, STMT) }             \
     } while (0)
 
-// Choose the four lifetime rows packed into the mode records so that they bracket [T_lo, T_hi]; rebuild on change.
+// The mode records hold three lifetime rows (two grid intervals) around the live temperature range [T_lo, T_hi] and
+// E0 = exp(hbar omega / (kB T0)) at its middle T0 (nk_device.h "lean FP64 arithmetic"); rebuilt when the range leaves the
+// window or drifts away from T0, and whenever the segmentation (hence the permuted copy) changes.
 static int nk_update_tau_window(nk_ctx *ctx, bool force) {
     NkDev &d = ctx->d;
     if (!ctx->have_material) return NK_OK;
     const std::vector<double> &g = ctx->h_Tgrid;
-    int i = (int)(std::lower_bound(g.begin(), g.end(), ctx->T_lo) - g.begin()) - 1;   // bracket of T_lo
-    int row0 = i - 1;
+    const double Tm = 0.5 * (ctx->T_lo + ctx->T_hi);
+    int i = (int)(std::lower_bound(g.begin(), g.end(), Tm) - g.begin()) - 1;          // interval (g[i], g[i+1]] holds T_mid
+    if (i < 0) i = 0;
+    // the second interval on the side where the range reaches further
+    int row0 = (i + 1 < d.NT && ctx->T_hi - g[std::min(i + 1, d.NT - 1)] > g[i] - ctx->T_lo) ? i : i - 1;
     if (row0 > d.NT - NK_TAU_ROWS) row0 = d.NT - NK_TAU_ROWS;
     if (row0 < 0) row0 = 0;
-    const bool covered = d.tau_row0 >= 0 && ctx->T_lo >= g[d.tau_row0] &&
-                         ctx->T_hi <= g[std::min(d.tau_row0 + NK_TAU_ROWS - 1, d.NT - 1)];
-    if (!force && covered) return NK_OK;
-    k_build_modetab<<<(d.M + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_omega, ctx->d_vg, d.tau, d.M, d.NT, row0,
-                                                                  (NkMode *)d.modetab);
+    const bool window_ok = d.tau_row0 >= 0 && ctx->T_lo > g[d.tau_row0] &&
+                           ctx->T_hi <= g[std::min(d.tau_row0 + NK_TAU_ROWS - 1, d.NT - 1)];
+    const bool window_best = d.tau_row0 == row0;                   // a range wider than two intervals: keep the best window
+    const bool t0_ok = d.T0 > 0.0 && fabs(ctx->T_lo - d.T0) <= 0.02 * d.T0 && fabs(ctx->T_hi - d.T0) <= 0.02 * d.T0;
+    const bool t0_best = d.T0 > 0.0 && fabs(Tm - d.T0) <= 0.002 * d.T0;
+    if (!force && (window_ok || window_best) && (t0_ok || t0_best)) return NK_OK;
+    d.T0 = Tm > 0.0 ? Tm : 300.0;
+    d.invT0 = 1.0 / d.T0;
+    d.c_hk = d.hbar / d.kb;
+    NkMode *tp = nullptr;
+    if (d.part && d.nseg > 0) {
+        const int64_t need = (int64_t)d.nseg * d.nlmax;
+        if (need > ctx->modetab_p_len) {
+            if (ctx->modetab_p) hipFree(ctx->modetab_p);
+            ctx->modetab_p = nullptr; ctx->modetab_p_len = 0;
+            NK_HIP(hipMalloc((void **)&ctx->modetab_p, (size_t)need * sizeof(NkMode)));
+            NK_HIP(hipMemset(ctx->modetab_p, 0, (size_t)need * sizeof(NkMode)));
+            ctx->modetab_p_len = need;
+        }
+        tp = ctx->modetab_p;
+    }
+    d.modetab_p = tp;
+    k_build_modetab<<<(d.M + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_omega, ctx->d_vg, d.tau, d.M, d.NT, row0, d.c_hk, d.invT0,
+                                                                  d.nseg > 0 ? d.nseg : 1, d.nlmax, (NkMode *)d.modetab, tp);
     NK_HIP(hipGetLastError());
     d.tau_row0 = row0;
     for (int k = 0; k < NK_TAU_ROWS; ++k) d.tau_g[k] = (row0 + k < d.NT) ? g[row0 + k] : INFINITY;
+    for (int k = 0; k + 1 < NK_TAU_ROWS; ++k) d.tau_ig[k] = 1.0 / (d.tau_g[k + 1] - d.tau_g[k]);
     if (d.NT < NK_TAU_ROWS) d.tau_g[0] = INFINITY;     // no packed window: every lookup takes the full-table path
     return NK_OK;
 }
@@ -195,7 +223,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     { const char *dbg = getenv("NK_DEBUG"); ctx->d.dbg = dbg ? atoi(dbg) : 0; }
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
-    // bookkeeping words in device memory: alloc_count[2], overflow, ticket
+    // bookkeeping words in device memory: halt[2], overflow, ticket
     const int32_t *p32 = nullptr;
     int rc;
     if ((rc = nk_upload<int32_t>(ctx, nullptr, 8, &p32))) {
@@ -203,7 +231,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
         delete ctx;
         return rc;
     }
-    ctx->d.alloc_count = (int32_t *)p32;
+    ctx->d.halt = (int32_t *)p32;
     ctx->d.overflow = (int32_t *)p32 + 2;
     ctx->d.ticket = (int32_t *)p32 + 3;
     *out = ctx;
@@ -224,6 +252,9 @@ void nk_destroy(nk_ctx *ctx) {
     for (void *p : ctx->pallocs) hipFree(p);
     if (ctx->acc) hipFree(ctx->acc);
     if (ctx->hist) hipFree(ctx->hist);
+    if (ctx->modetab_p) hipFree(ctx->modetab_p);
+    if (ctx->inbox) hipFree(ctx->inbox);
+    if (ctx->inbox_n) hipFree(ctx->inbox_n);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -601,7 +632,10 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     NkDev &d = ctx->d;
     d.NB = 5 * d.S + 5 * d.R + 1;
     if (ctx->acc) { hipFree(ctx->acc); ctx->acc = nullptr; }
-    NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)d.NB * sizeof(double)));
+    if (ctx->hist) { hipFree(ctx->hist); ctx->hist = nullptr; }      // the history rows follow NB
+    ctx->hist_cap = 0;
+    NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)(d.NB + 1) * sizeof(double)));
+    NK_HIP(hipMemset(ctx->acc, 0, (size_t)(d.NB + 1) * sizeof(double)));
     const double *p;
     NK_UP((const double *)nullptr, (size_t)(ctx->num_cu * 8) * d.NB, &p);      // >= any persistent grid we launch
     d.partials = (double *)p;
@@ -669,7 +703,6 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     d.R = r->R; d.res_gen = r->gen;
-    ctx->spawn_ready = false;
     d.res_nf = 0; d.res_lds = 0;
     NK_ARG((int64_t)d.R * d.M < (1ll << 28), "nk_set_reservoirs: R*Q*J too large for the particle id layout");
     if (r->R > 0) {
@@ -679,16 +712,10 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
         const double *c;
         NK_UP(r->counter, (size_t)r->R * d.M, &c);
         d.res_counter = (double *)c;
-        NK_UP((const double *)nullptr, (size_t)r->R * d.M, &c);
-        d.res_cval[0] = (double *)c;
-        NK_UP((const double *)nullptr, (size_t)r->R * d.M, &c);
-        d.res_cval[1] = (double *)c;
         double pmax = 0.0;
-        int64_t most = 0;                               // upper bound of the particles entering in one step
-        for (size_t i = 0; i < (size_t)r->R * d.M; ++i) {
-            pmax = std::max(pmax, r->enter_prob[i]);
-            most += (int64_t)floor(r->enter_prob[i]) + 1;
-        }
+        for (size_t i = 0; i < (size_t)r->R * d.M; ++i) pmax = std::max(pmax, r->enter_prob[i]);
+        ctx->h_enter_prob.assign(r->enter_prob, r->enter_prob + (size_t)r->R * d.M);
+        ctx->o2o_first = 0;
         NK_ARG(r->gen >= 0 && r->gen <= 2, "nk_set_reservoirs: gen must be 0 (constant), 1 (fixed_rate) or 2 (one_to_one)");
         if (r->gen == 2) {
             // one_to_one: cumulative enter_prob per reservoir (np.cumsum, then / max: Population.py:467-468) and the
@@ -710,14 +737,8 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
             const int32_t *pn;
             NK_UP(nl.data(), nl.size(), &pn);
             d.nleave_prev = (int32_t *)pn;
-            most = std::max<int64_t>(4 * std::max(first, most) + 65536, most);
+            ctx->o2o_first = first;
         }
-        d.spawn_cap = most;
-        const uint64_t *pu;
-        NK_UP((const uint64_t *)nullptr, (size_t)most, &pu);
-        d.spawn_list[0] = (uint64_t *)pu;
-        NK_UP((const uint64_t *)nullptr, (size_t)most, &pu);
-        d.spawn_list[1] = (uint64_t *)pu;
         NK_ARG(pmax < 4094.0, "nk_set_reservoirs: more than 4094 particles of one mode per step (id layout)");
         for (int i = 0; i < r->R; ++i) {
             NK_ARG(r->facet[i] >= 0 && r->facet[i] < d.Fc, "nk_set_reservoirs: facet index");
@@ -799,21 +820,6 @@ int nk_set_params(nk_ctx *ctx, const nk_params *p) {
     return NK_OK;
 }
 
-static int nk_check_ready(nk_ctx *ctx) {
-    NK_ARG(ctx->have_material && ctx->have_mesh && ctx->have_sv && ctx->have_params,
-           "engine not configured: need material, mesh, subvolumes and params");
-    NkDev &d = ctx->d;
-    // every rough / reservoir facet must be backed by its table, otherwise a kernel would index garbage
-    for (int f = 0; f < d.Fc; ++f) {
-        const NkFacet &hf = ctx->host_facets[f];
-        NK_ARG(hf.bc != 'R' || hf.rough >= 0, "a facet has BC 'R' but nk_set_rough did not cover it");
-        NK_ARG(!(hf.bc == 'T' || hf.bc == 'F') || hf.res >= 0, "a facet has BC 'T' but nk_set_reservoirs did not cover it");
-    }
-    NK_ARG(d.cap > 0, "no particle storage: call nk_reserve / nk_upload_particles");
-    NK_ARG(nk_lds(ctx, true, true) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
-    return NK_OK;
-}
-
 // Host copy of the live particles, segment by segment (used by download and by re-layouts).
 struct NkHostParticles {
     std::vector<double> x, y, z, occ, nts;
@@ -842,32 +848,49 @@ static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
         return NK_OK;
     };
     h.x.resize(live); h.y.resize(live); h.z.resize(live); h.occ.resize(live); h.nts.resize(live);
-    h.mode.resize(live); h.facet.resize(live); h.pid.resize(live);
+    h.mode.resize(live); h.facet.resize(live); h.pid.assign(live, 0);
+    std::vector<uint32_t> w0((size_t)live);
     int rc;
     if ((rc = pack(d.x, 8, h.x.data())) || (rc = pack(d.y, 8, h.y.data())) || (rc = pack(d.z, 8, h.z.data())) ||
-        (rc = pack(d.occ, 8, h.occ.data())) || (rc = pack(d.nts, 8, h.nts.data())) || (rc = pack(d.mode, 4, h.mode.data())) ||
-        (rc = pack(d.facet, 4, h.facet.data())) || (rc = pack(d.pid, 8, h.pid.data())))
+        (rc = pack(d.occ, 8, h.occ.data())) || (rc = pack(d.nts, 8, h.nts.data())) || (rc = pack(d.w0, 4, w0.data())))
         return rc;
+    if (d.pid && (rc = pack(d.pid, 8, h.pid.data()))) return rc;
+    // packed word -> (mode, facet): mode = idx * nseg + segment when the modes are partitioned
+    const uint32_t lbmask = (1u << d.lb) - 1u;
+    int64_t k = 0;
+    for (int sgm = 0; sgm < d.nseg; ++sgm)
+        for (int j = 0; j < cnt[sgm]; ++j, ++k) {
+            const uint32_t idx = w0[(size_t)k] & lbmask;
+            h.mode[(size_t)k] = d.part ? (int32_t)((int64_t)idx * d.nseg + sgm) : (int32_t)idx;
+            h.facet[(size_t)k] = (int32_t)(w0[(size_t)k] >> d.lb) - 1;
+        }
     return NK_OK;
 }
 
-// Lay N particles out over the segments (equal shares), sorted by mode (stable): the particles of a 64-wide tile then
-// share a few mode records.  Later arrivals are appended in (reservoir, mode) runs, so segments stay piecewise sorted.
+// Lay N particles out over the segments.  Partitioned modes: every particle goes to the segment that owns its mode.
+// Global mode indices (rough facets): equal shares, sorted by mode (stable), so that a tile shares a few mode records.
 static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, const double *z, const int32_t *mode,
                       const double *occ, const double *n_ts, const int32_t *facet, const uint64_t *pid, uint64_t pid_offset) {
     NkDev &d = ctx->d;
     const int M = d.M;
     for (int64_t i = 0; i < N; ++i) NK_ARG(mode[i] >= 0 && mode[i] < M, "nk_upload_particles: mode index out of range");
-    std::vector<int64_t> mstart((size_t)M + 1, 0);               // counting sort by mode
-    for (int64_t i = 0; i < N; ++i) mstart[(size_t)mode[i] + 1] += 1;
-    for (int m = 0; m < M; ++m) mstart[(size_t)m + 1] += mstart[(size_t)m];
     std::vector<int64_t> order((size_t)N);
-    {
+    std::vector<int64_t> start((size_t)d.nseg + 1, 0);
+    if (d.part) {
+        for (int64_t i = 0; i < N; ++i) start[(size_t)(mode[i] % d.nseg) + 1] += 1;
+        for (int sgm = 0; sgm < d.nseg; ++sgm) start[(size_t)sgm + 1] += start[(size_t)sgm];
+        // inside a segment: by local mode index (stable), so that a tile shares a few records
+        std::vector<int64_t> key((size_t)N);
+        for (int64_t i = 0; i < N; ++i) { order[(size_t)i] = i; key[(size_t)i] = (int64_t)(mode[i] % d.nseg) * ((int64_t)d.nlmax + 1) + mode[i] / d.nseg; }
+        std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
+    } else {
+        std::vector<int64_t> mstart((size_t)M + 1, 0);               // counting sort by mode
+        for (int64_t i = 0; i < N; ++i) mstart[(size_t)mode[i] + 1] += 1;
+        for (int m = 0; m < M; ++m) mstart[(size_t)m + 1] += mstart[(size_t)m];
         std::vector<int64_t> cur(mstart.begin(), mstart.end() - 1);
         for (int64_t i = 0; i < N; ++i) order[(size_t)cur[(size_t)mode[i]]++] = i;
+        for (int sgm = 0; sgm <= d.nseg; ++sgm) start[(size_t)sgm] = (N * sgm) / d.nseg;
     }
-    std::vector<int64_t> start((size_t)d.nseg + 1, 0);
-    for (int sgm = 0; sgm <= d.nseg; ++sgm) start[(size_t)sgm] = (N * sgm) / d.nseg;
     std::vector<int32_t> cnt((size_t)d.nseg);
     for (int sgm = 0; sgm < d.nseg; ++sgm) {
         cnt[(size_t)sgm] = (int32_t)(start[(size_t)sgm + 1] - start[(size_t)sgm]);
@@ -875,7 +898,6 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
     }
     std::vector<double> bd((size_t)d.cap);
     auto put = [&](const void *src, size_t esz, void *dst) -> int {
-        if (!src) return NK_OK;
         for (int sgm = 0; sgm < d.nseg; ++sgm) {
             const int64_t lo = start[(size_t)sgm], n = cnt[(size_t)sgm];
             if (esz == 8) {
@@ -892,38 +914,49 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
         return NK_OK;
     };
     int rc;
-    if ((rc = put(x, 8, d.x)) || (rc = put(y, 8, d.y)) || (rc = put(z, 8, d.z)) || (rc = put(occ, 8, d.occ)) ||
-        (rc = put(n_ts, 8, d.nts)) || (rc = put(mode, 4, d.mode)) || (rc = put(facet, 4, d.facet)))
-        return rc;
-    if (pid) { if ((rc = put(pid, 8, d.pid))) return rc; }
-    else {
-        std::vector<uint64_t> ids((size_t)N);
-        for (int64_t i = 0; i < N; ++i) ids[(size_t)i] = pid_offset + (uint64_t)i;
-        if ((rc = put(ids.data(), 8, d.pid))) return rc;
+    if ((rc = put(x, 8, d.x)) || (rc = put(y, 8, d.y)) || (rc = put(z, 8, d.z)) || (rc = put(occ, 8, d.occ))) return rc;
+    if (n_ts && (rc = put(n_ts, 8, d.nts))) return rc;
+    {
+        std::vector<uint32_t> w0((size_t)N);
+        for (int64_t i = 0; i < N; ++i) {
+            const int32_t fc = facet ? facet[i] : -1;
+            NK_ARG(fc >= -1 && fc < d.Fc, "nk_upload_particles: facet index out of range");
+            const uint32_t idx = d.part ? (uint32_t)(mode[i] / d.nseg) : (uint32_t)mode[i];
+            w0[(size_t)i] = ((uint32_t)(fc + 1) << d.lb) | idx;
+        }
+        if ((rc = put(w0.data(), 4, d.w0))) return rc;
+    }
+    if (d.pid) {
+        if (pid) { if ((rc = put(pid, 8, d.pid))) return rc; }
+        else {
+            std::vector<uint64_t> ids((size_t)N);
+            for (int64_t i = 0; i < N; ++i) ids[(size_t)i] = pid_offset + (uint64_t)i;
+            if ((rc = put(ids.data(), 8, d.pid))) return rc;
+        }
     }
     NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
-    std::vector<int64_t> fp((size_t)d.nseg + 1, 0);
-    for (int sgm = 0; sgm < d.nseg; ++sgm) {              // same rule as nk_update_body
-        const int fs = d.segcap - cnt[sgm];
-        fp[sgm + 1] = fp[sgm] + ((d.segcap < NK_QUANT_SEGCAP || fs >= NK_MIN_FREE) ? fs : 0);
-    }
-    NK_HIP(hipMemcpy(d.seg_free_prefix, fp.data(), fp.size() * 8, hipMemcpyHostToDevice));
+    ctx->h_seg_count = cnt;
     return NK_OK;
 }
 
+// Does this configuration draw random numbers per particle (then ids are tracked), and does a particle's mode change
+// (then the modes cannot be partitioned over the segments)?
+static inline bool nk_want_pid(const nk_ctx *ctx) { return ctx->d.Fr > 0 || ctx->params.track_ids != 0; }
+static inline bool nk_want_part(const nk_ctx *ctx) { return ctx->d.Fr == 0 && !getenv("NK_NO_PARTITION"); }   // env: developer probe
+
 // Persistent grid of the sweep = what the device keeps resident of the instantiation this configuration uses (before the
-// tables are known: three workgroups per CU, the common case).
+// tables are known: four workgroups per CU, the common case).
 static int nk_sweep_blocks(nk_ctx *ctx) {
     NkDev &d = ctx->d;
-    if (!(ctx->have_material && ctx->have_mesh && ctx->have_sv)) return ctx->num_cu * 3;
+    if (!(ctx->have_material && ctx->have_mesh && ctx->have_sv)) return ctx->num_cu * NK_SWEEP_OCC;
     const int gm_ = nk_geom_mode(ctx);
-    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3;
-    const int key = gm_ | (rough_ << 2) | (rbf_ << 3);
+    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx);
+    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4);
     if (ctx->g_sweep == 0 || ctx->g_sweep_key != key) {
         const size_t lds_w = nk_lds(ctx, true, true);
         int per_cu = 0;
         hipError_t e_ = hipSuccess;
-        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
+        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
         if (e_ != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
         if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
@@ -934,38 +967,122 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     return ctx->g_sweep;
 }
 
-static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity) {
+// Upper bound of the particles that can enter one segment in one step (the sweep's halt criterion uses the same sum).
+static int64_t nk_spawn_bound(const nk_ctx *ctx, int nseg) {
+    const NkDev &d = ctx->d;
+    if (d.R <= 0) return 0;
+    if (d.res_gen == 2) return 4 * (ctx->o2o_first / std::max(nseg, 1) + 64);
+    std::vector<int64_t> per((size_t)nseg, 0);
+    for (int r = 0; r < d.R; ++r)
+        for (int m = 0; m < d.M; ++m) per[(size_t)(m % nseg)] += (int64_t)floor(ctx->h_enter_prob[(size_t)r * d.M + m]) + 1;
+    int64_t mx = 0;
+    for (int64_t v : per) mx = std::max(mx, v);
+    return (mx + d.nranks - 1) / d.nranks + d.R;
+}
+
+// (Re)allocate the particle store for `capacity` particles, `max_seg` of them at most in one segment when the modes are
+// partitioned (0 = unknown: even spread assumed).
+static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode = nullptr, int64_t N = 0) {
     NkDev &d = ctx->d;
     for (void *p : ctx->pallocs) hipFree(p);
     ctx->pallocs.clear();
-    // segments: load-balance granularity of the persistent sweep (a few tiles of 256 each)
-    // For large ensembles exactly ONE segment per resident wave of the sweep: measured on
-    // 1e7 particles, 3072 segments (one per wave) 0.381 ms, 6144 0.397, 8192 0.39-0.40, 12288 0.401, and 4096 (a third
-    // of the waves gets a second segment) 0.413 -- long segments amortise the per-segment costs (first-tile latency, the
-    // partial last event batch and spawn tile), and a whole number per wave keeps the waves level.
-    // Small ensembles: more, shorter segments, down to 128 slots, until every resident wave has one -- a wave's serial
-    // chain (tiles, event passes, entering particles) is what a small sweep waits for: 1e5 particles 51 -> 39 us.
+    // Segments = load-balance granularity of the persistent sweep.  For large ensembles exactly ONE segment per resident wave
+    // (long segments amortise the per-segment costs: first-tile latency, the partial last event batch and spawn tile, and
+    // a whole number per wave keeps the waves level).  Small ensembles: more, shorter segments, down to 128 slots, until
+    // every resident wave has one -- a wave's serial chain (tiles, event passes, entering particles) is what a small
+    // sweep waits for.
     int64_t nseg = capacity / 128;
     const int64_t waves = (int64_t)nk_sweep_blocks(ctx) * (NK_WG / 64);
     if (const char *e = getenv("NK_SEGMENTS")) nseg = atoi(e) > 0 ? atoi(e) : nseg;          // developer probe
     else if (nseg >= waves) nseg = waves;
     nseg = nseg < 64 ? 64 : (nseg > NK_MAX_SEGMENTS ? NK_MAX_SEGMENTS : nseg);
-    int64_t segcap = (capacity + nseg - 1) / nseg;
-    segcap = ((segcap + 63) / 64) * 64;
+    d.part = nk_want_part(ctx) ? 1 : 0;
     d.nseg = (int32_t)nseg;
+    d.nlmax = d.M > 0 ? (int32_t)((d.M + nseg - 1) / nseg) : 1;
+    {   // bits of the stored mode index; the rest of the 32-bit word holds facet + 1
+        const int64_t maxidx = d.part ? d.nlmax - 1 : (d.M > 0 ? d.M - 1 : 0);
+        int lb = 1;
+        while ((1ll << lb) <= maxidx) ++lb;
+        NK_ARG(lb < 31 && (int64_t)d.Fc + 1 < (1ll << (32 - lb)), "mesh has too many facets for the packed particle word (facets x modes)");
+        d.lb = lb;
+    }
+    int64_t segcap = (capacity + nseg - 1) / nseg;
+    if (d.part && mode && N > 0) {                       // room for the fullest segment of this population + a step's arrivals
+        std::vector<int64_t> per((size_t)nseg, 0);
+        for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0) per[(size_t)(mode[i] % nseg)] += 1;
+        int64_t mx = 0;
+        for (int64_t v : per) mx = std::max(mx, v);
+        segcap = std::max(segcap, mx + mx / 4 + 64);
+    }
+    if (ctx->have_material && d.R > 0 && !ctx->h_enter_prob.empty()) segcap = std::max(segcap, segcap / 8 * 9) + 2 * nk_spawn_bound(ctx, (int)nseg) + 2 * NK_TILE;
+    segcap = ((segcap + 63) / 64) * 64;
+    NK_ARG(nseg * segcap < (1ll << 31), "particle store too large for 32-bit slot arithmetic");
     d.segcap = (int32_t)segcap;
     d.cap = nseg * segcap;
     ctx->timing.slots = d.cap;
-    const double *pd; const int32_t *pi; const uint64_t *pu;
+    const double *pd; const uint32_t *pw; const int32_t *pi; const uint64_t *pu;
 #define NK_PALLOC(T, field, ptr, count)                                                                \
     do { int rc_ = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (rc_) return rc_; d.field = (T *)ptr; } while (0)
     NK_PALLOC(double, x, pd, d.cap); NK_PALLOC(double, y, pd, d.cap); NK_PALLOC(double, z, pd, d.cap);
     NK_PALLOC(double, occ, pd, d.cap); NK_PALLOC(double, nts, pd, d.cap);
-    NK_PALLOC(int32_t, mode, pi, d.cap); NK_PALLOC(int32_t, facet, pi, d.cap);
-    NK_PALLOC(uint64_t, pid, pu, d.cap);
+    NK_PALLOC(uint32_t, w0, pw, d.cap);
+    d.pid = nullptr;
+    if (nk_want_pid(ctx)) NK_PALLOC(uint64_t, pid, pu, d.cap);
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
-    { const int64_t *pl; int rc_ = nk_upload<int64_t>(ctx, nullptr, (size_t)d.nseg + 1, &pl, true); if (rc_) return rc_; d.seg_free_prefix = (int64_t *)pl; }
 #undef NK_PALLOC
+    ctx->layout_key = (d.part ? 1 : 0) | (d.pid ? 2 : 0);
+    // tables that follow the segmentation: permuted mode records, 'one_to_one' inboxes
+    if (ctx->have_material) { int rc = nk_update_tau_window(ctx, true); if (rc) return rc; }
+    if (ctx->inbox) { hipFree(ctx->inbox); ctx->inbox = nullptr; }
+    if (ctx->inbox_n) { hipFree(ctx->inbox_n); ctx->inbox_n = nullptr; }
+    d.sp_inbox = nullptr; d.sp_inbox_n = nullptr; d.sp_icap = 0;
+    return NK_OK;
+}
+
+// 'one_to_one': per-segment inboxes for the records of k_emit_one_to_one
+static int nk_ensure_inbox(nk_ctx *ctx) {
+    NkDev &d = ctx->d;
+    if (!(d.R > 0 && d.res_gen == 2) || d.sp_inbox) return NK_OK;
+    const int64_t icap = 4 * (ctx->o2o_first / d.nseg + 64);
+    NK_HIP(hipMalloc(&ctx->inbox, (size_t)d.nseg * icap * 8));
+    NK_HIP(hipMalloc(&ctx->inbox_n, (size_t)d.nseg * 4));
+    NK_HIP(hipMemset(ctx->inbox_n, 0, (size_t)d.nseg * 4));
+    d.sp_inbox = (uint64_t *)ctx->inbox; d.sp_inbox_n = (int32_t *)ctx->inbox_n; d.sp_icap = (int32_t)icap;
+    return NK_OK;
+}
+
+// Grow every segment to `segcap_new` slots on the device (same segmentation: the particles keep their segments).
+static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
+    NkDev &d = ctx->d;
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    const NkDev old = d;
+    std::vector<void *> old_allocs;
+    old_allocs.swap(ctx->pallocs);
+    segcap_new = ((segcap_new + 63) / 64) * 64;
+    NK_ARG((int64_t)old.nseg * segcap_new < (1ll << 31), "particle store too large for 32-bit slot arithmetic");
+    d.segcap = (int32_t)segcap_new;
+    d.cap = (int64_t)d.nseg * d.segcap;
+    const double *pd; const uint32_t *pw; const int32_t *pi; const uint64_t *pu;
+    int rc = NK_OK;
+#define NK_PALLOC(T, field, ptr, count)                                                                \
+    do { if (!rc) { rc = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (!rc) d.field = (T *)ptr; } } while (0)
+    NK_PALLOC(double, x, pd, d.cap); NK_PALLOC(double, y, pd, d.cap); NK_PALLOC(double, z, pd, d.cap);
+    NK_PALLOC(double, occ, pd, d.cap); NK_PALLOC(double, nts, pd, d.cap);
+    NK_PALLOC(uint32_t, w0, pw, d.cap);
+    if (old.pid) NK_PALLOC(uint64_t, pid, pu, d.cap);
+    NK_PALLOC(int32_t, seg_count, pi, d.nseg);
+#undef NK_PALLOC
+    if (rc) {                                            // out of memory: keep the old store
+        for (void *p : ctx->pallocs) hipFree(p);
+        ctx->pallocs.swap(old_allocs);
+        d = old;
+        return rc;
+    }
+    k_regrow<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(old, d);
+    NK_HIP(hipGetLastError());
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    for (void *p : old_allocs) hipFree(p);
+    ctx->timing.slots = d.cap;
     return NK_OK;
 }
 
@@ -975,46 +1092,20 @@ int nk_reserve(nk_ctx *ctx, int64_t capacity) {
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     if (capacity <= d.cap) return NK_OK;
+    if (d.cap == 0) return nk_alloc_particles(ctx, capacity);
+    // Same number of segments before and after (every large ensemble: one segment per resident wave): the segments grow in
+    // place on the device.  Otherwise the particles are re-dealt through the host.
+    int64_t nseg_new = capacity / 128;
+    const int64_t waves = (int64_t)nk_sweep_blocks(ctx) * (NK_WG / 64);
+    if (nseg_new >= waves) nseg_new = waves;
+    nseg_new = nseg_new < 64 ? 64 : (nseg_new > NK_MAX_SEGMENTS ? NK_MAX_SEGMENTS : nseg_new);
+    if (nseg_new == d.nseg || getenv("NK_SEGMENTS")) return nk_regrow(ctx, (capacity + d.nseg - 1) / d.nseg);
     NkHostParticles h;
-    const bool had = d.cap > 0;
-    if (had) {
-        // Same number of segments before and after (every large ensemble: one segment per resident wave): the segments
-        // grow in place on the device.  Otherwise the particles are re-dealt through the host.
-        NK_HIP(hipStreamSynchronize(ctx->stream));
-        const NkDev old = d;
-        std::vector<void *> old_allocs;
-        old_allocs.swap(ctx->pallocs);
-        int rc = nk_alloc_particles(ctx, capacity);
-        if (rc) { for (void *p : old_allocs) hipFree(p); return rc; }
-        if (d.nseg == old.nseg && d.segcap >= old.segcap) {
-            k_regrow<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(old, d);
-            NK_HIP(hipGetLastError());
-            std::vector<int32_t> cnt((size_t)d.nseg);
-            NK_HIP(hipMemcpy(cnt.data(), old.seg_count, (size_t)d.nseg * 4, hipMemcpyDeviceToHost));
-            NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
-            std::vector<int64_t> fp((size_t)d.nseg + 1, 0);
-            for (int sgm = 0; sgm < d.nseg; ++sgm) {              // same rule as nk_update_body
-                const int fs = d.segcap - cnt[sgm];
-                fp[sgm + 1] = fp[sgm] + ((d.segcap < NK_QUANT_SEGCAP || fs >= NK_MIN_FREE) ? fs : 0);
-            }
-            NK_HIP(hipMemcpy(d.seg_free_prefix, fp.data(), fp.size() * 8, hipMemcpyHostToDevice));
-            NK_HIP(hipStreamSynchronize(ctx->stream));
-            for (void *p : old_allocs) hipFree(p);
-            ctx->h_seg_count = cnt;
-            return NK_OK;
-        }
-        // different segmentation: back to the old store for the gather, then allocate again
-        std::vector<void *> new_allocs;
-        new_allocs.swap(ctx->pallocs);
-        for (void *p : new_allocs) hipFree(p);
-        ctx->pallocs.swap(old_allocs);
-        d = old;
-        rc = nk_gather_live(ctx, h, true);
-        if (rc) return rc;
-    }
-    int rc = nk_alloc_particles(ctx, capacity);
+    int rc = nk_gather_live(ctx, h, true);
     if (rc) return rc;
-    if (had && !h.x.empty())
+    rc = nk_alloc_particles(ctx, capacity, h.mode.data(), (int64_t)h.mode.size());
+    if (rc) return rc;
+    if (!h.x.empty())
         return nk_scatter(ctx, (int64_t)h.x.size(), h.x.data(), h.y.data(), h.z.data(), h.mode.data(), h.occ.data(),
                           h.nts.data(), h.facet.data(), h.pid.data(), 0);
     return NK_OK;
@@ -1029,15 +1120,50 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    if (N + N / 5 + 1024 > d.cap) {               // forget old contents and size for 1.5 N
-        int rc = nk_alloc_particles(ctx, N + N / 2 + 65536);
+    bool fits = d.cap > 0 && ctx->layout_key == ((nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0)) && N + N / 5 + 1024 <= d.cap;
+    if (fits && d.part) {                              // every segment must hold its modes' particles with head room
+        std::vector<int64_t> per((size_t)d.nseg, 0);
+        for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0) per[(size_t)(mode[i] % d.nseg)] += 1;
+        const int64_t room = (int64_t)d.segcap - nk_spawn_bound(ctx, d.nseg) - 2 * NK_TILE;
+        for (int64_t v : per) fits = fits && v + v / 16 <= room;
+    }
+    if (!fits) {                                       // forget old contents and size for 1.5 N
+        int rc = nk_alloc_particles(ctx, std::max(N + N / 2 + 65536, d.cap), mode, N);
         if (rc) return rc;
     }
     int rc = nk_scatter(ctx, N, x, y, z, mode, occ, n_ts, facet, pid, pid_offset);
     if (rc) return rc;
-    int32_t zero32 = 0;
-    NK_HIP(hipMemcpy(d.overflow, &zero32, 4, hipMemcpyHostToDevice));
+    int32_t zero4[4] = {0, 0, 0, 0};
+    NK_HIP(hipMemcpy(d.halt, zero4, 16, hipMemcpyHostToDevice));     // halt[2], overflow, ticket
     ctx->pending_relax = false;
+    return NK_OK;
+}
+
+static int nk_check_ready(nk_ctx *ctx) {
+    NK_ARG(ctx->have_material && ctx->have_mesh && ctx->have_sv && ctx->have_params,
+           "engine not configured: need material, mesh, subvolumes and params");
+    NkDev &d = ctx->d;
+    // every rough / reservoir facet must be backed by its table, otherwise a kernel would index garbage
+    for (int f = 0; f < d.Fc; ++f) {
+        const NkFacet &hf = ctx->host_facets[f];
+        NK_ARG(hf.bc != 'R' || hf.rough >= 0, "a facet has BC 'R' but nk_set_rough did not cover it");
+        NK_ARG(!(hf.bc == 'T' || hf.bc == 'F') || hf.res >= 0, "a facet has BC 'T' but nk_set_reservoirs did not cover it");
+    }
+    NK_ARG(d.cap > 0, "no particle storage: call nk_reserve / nk_upload_particles");
+    NK_ARG(nk_lds(ctx, true, true) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
+    // the store's layout follows the configuration (ids, partitioned modes): tables set after the upload re-deal it
+    const int want = (nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0);
+    if (ctx->layout_key != want) {
+        NkHostParticles h;
+        int rc = nk_gather_live(ctx, h, true);
+        if (rc) return rc;
+        const bool had_pid = d.pid != nullptr;
+        const int64_t cap_old = d.cap;
+        if ((rc = nk_alloc_particles(ctx, cap_old, h.mode.data(), (int64_t)h.mode.size()))) return rc;
+        if (!h.x.empty() && (rc = nk_scatter(ctx, (int64_t)h.x.size(), h.x.data(), h.y.data(), h.z.data(), h.mode.data(), h.occ.data(),
+                                             h.nts.data(), h.facet.data(), had_pid ? h.pid.data() : nullptr, 0)))
+            return rc;
+    }
     return NK_OK;
 }
 
@@ -1052,20 +1178,18 @@ int nk_init_boundaries(nk_ctx *ctx) {
     return NK_OK;
 }
 
-static int nk_flush_relax(nk_ctx *ctx) {
+static int nk_flush_relax(nk_ctx *ctx, int honor_halt) {
     if (!ctx->pending_relax) return NK_OK;
-    k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(ctx->d);
+    k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(ctx->d, honor_halt);
     NK_HIP(hipGetLastError());
     ctx->pending_relax = false;
     return NK_OK;
 }
 
-int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
-    NK_ARG(ctx && nsteps > 0, "nk_step: bad arguments");
-    int rc = nk_check_ready(ctx);
-    if (rc) return rc;
-    NK_HIP(hipSetDevice(ctx->device));
-    if ((rc = nk_update_tau_window(ctx, false))) return rc;
+// Enqueue up to `nsteps` timesteps without host synchronisation, drain the stream, copy the history rows back.  A sweep that
+// sees a segment which COULD overflow at the following step raises the halt word; the remaining steps of the batch then do
+// nothing, *done < nsteps comes back, and nk_step grows the store (state intact, nothing dropped) and carries on.
+static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, int32_t *done) {
     NkDev &d = ctx->d;
     const int S = d.S, R = d.R, NB = d.NB;
     const int HROW = NB + 2 * S + 4;
@@ -1076,102 +1200,151 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)rows_alloc * HROW * sizeof(double)));
         ctx->hist_cap = rows_alloc;
     }
+    NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));   // row_valid = 0
     const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, true);
-    const int count_blocks = (int)(((int64_t)R * d.M + NK_WG - 1) / NK_WG);
     const int gm_ = nk_geom_mode(ctx);
-    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3;
+    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = d.pid != nullptr;
     (void)nk_sweep_blocks(ctx);
-    const int g_sweep = ctx->g_sweep < d.nseg ? ctx->g_sweep : d.nseg;
-    const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the call
+    const int g_sweep = ctx->g_sweep < (d.nseg + 3) / 4 ? ctx->g_sweep : (d.nseg + 3) / 4;
+    const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the batch
     if (ctx->evpool.empty()) {                           // events are created once and reused
         ctx->evpool.resize(16 * 4 + 2);
         for (auto &e : ctx->evpool) NK_HIP(hipEventCreate(&e));
     }
     hipEvent_t *ev = ctx->evpool.data();
     hipEvent_t t0 = ctx->evpool[64], t1 = ctx->evpool[65];
+    const bool relax0 = ctx->pending_relax;
     NK_HIP(hipEventRecord(t0, ctx->stream));
+    bool pending = ctx->pending_relax;
+    std::vector<char> relax_flushed((size_t)nsteps, 0);       // steps whose deferred relaxation k_relax ran before them
     for (int s = 0; s < nsteps; ++s) {
-        const uint32_t step = (uint32_t)ctx->step;
-        if (ctx->params.contains_every > 0 && (ctx->step % ctx->params.contains_every) == 0 && d.nS > 0) {
-            if ((rc = nk_flush_relax(ctx))) return rc;
+        const int64_t stepno = ctx->step + s;
+        const uint32_t step = (uint32_t)stepno;
+        if (ctx->params.contains_every > 0 && (stepno % ctx->params.contains_every) == 0 && d.nS > 0) {
+            if (pending) {
+                k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(d, 1);
+                pending = false;
+                relax_flushed[(size_t)s] = 1;
+            }
             NK_GEOM_LAUNCH(k_contains, nk_sweep_grid(ctx), lds_g, d, step);
         }
         const int fe = ctx->params.flux_every;
-        const int do_flux = (fe > 0 && ((ctx->step + 1) % fe) == 0) ? 1 : 0;
+        const int do_flux = (fe > 0 && ((stepno + 1) % fe) == 0) ? 1 : 0;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
-        const int buf = (int)(step & 1u);
-        if (R > 0 && d.res_gen == 2) {                   // one_to_one: needs the reduced N_leaving of the previous step
-            NK_HIP(hipMemsetAsync(d.alloc_count, 0, 8, ctx->stream));
-            k_emit_one_to_one<<<ctx->num_cu * 4, NK_WG, 0, ctx->stream>>>(d, step);
-        } else if (R > 0 && !ctx->spawn_ready) {         // prime: nobody has prepared this step's entering particles
-            NK_HIP(hipMemsetAsync(d.alloc_count, 0, 8, ctx->stream));
-            k_emit_count<<<count_blocks, NK_WG, 0, ctx->stream>>>(d, step);
-        }
+        if (R > 0 && d.res_gen == 2) k_emit_one_to_one<<<ctx->num_cu * 4, NK_WG, 0, ctx->stream>>>(d, step);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
-        // the sweep's tail prepares step + 1 when each workgroup's slice of the (reservoir, mode) table is small
-        const bool emit_next = R > 0 && d.res_gen != 2 && ((int64_t)R * d.M + g_sweep - 1) / g_sweep <= (int64_t)NK_EMIT_KMAX * NK_WG;
         {
-            const int rl = ctx->pending_relax ? 1 : 0;
-            const int flags = do_flux | (emit_next ? 2 : 0);
-            NK_SWEEP_DISPATCH(gm_, rough_, rbf_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, flags)));
+            const int rl = pending ? 1 : 0;
+            NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux)));
         }
-        ctx->spawn_ready = emit_next;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
         double *hrow = ctx->hist + (size_t)s * HROW;
         if (ctx->comm) {
-            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, buf, 0);
-            ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB, ncclDouble, ncclSum, ctx->comm, ctx->stream);
+            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, 0);
+            ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB + 1, ncclDouble, ncclSum, ctx->comm, ctx->stream);
             if (nrc != ncclSuccess) { ctx->err = "ncclAllReduce failed"; return NK_ERR_COMM; }
-            k_update<<<1, NK_WG, 0, ctx->stream>>>(d, ctx->acc, hrow, do_flux, buf);
+            k_update<<<1, NK_WG, 0, ctx->stream>>>(d, ctx->acc, hrow, do_flux);
         } else {
-            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, buf, 1);
+            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, 1);
         }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
-        ctx->pending_relax = true;
-        ctx->step += 1;
+        pending = true;
+        if ((s & 63) == 63) NK_HIP(hipGetLastError());
     }
     NK_HIP(hipEventRecord(t1, ctx->stream));
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
+    h.resize((size_t)nsteps * HROW);
+    NK_HIP(hipMemcpy(h.data(), ctx->hist, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    int32_t nd = 0;
+    while (nd < nsteps && h[(size_t)nd * HROW + NB + 2 * S + 1] != 0.0) ++nd;
+    *done = nd;
+    // the deferred relaxation as the device left it: pending after any completed step; if none ran, whatever it was before,
+    // unless a k_relax ahead of the first step flushed it (that kernel honours the halt word, which was clear then)
+    if (nd > 0) ctx->pending_relax = true;
+    else ctx->pending_relax = relax0 && !(nsteps > 0 && relax_flushed[0]);
     float ms = 0.f;
     double sk = 0.0, ek = 0.0, vk = 0.0;
-    for (int s = 0; s < nev; ++s) {
+    const int nt = nd < nev ? nd : nev;
+    for (int s = 0; s < nt; ++s) {
         NK_HIP(hipEventElapsedTime(&ms, ev[4 * s], ev[4 * s + 1])); ek += ms;
         NK_HIP(hipEventElapsedTime(&ms, ev[4 * s + 1], ev[4 * s + 2])); sk += ms;
         NK_HIP(hipEventElapsedTime(&ms, ev[4 * s + 2], ev[4 * s + 3])); vk += ms;
     }
     NK_HIP(hipEventElapsedTime(&ms, t0, t1));
-    ctx->timing.step_kernel_ms = sk / nev;
-    ctx->timing.emit_kernel_ms = ek / nev;
-    ctx->timing.events_kernel_ms = vk / nev;
-    ctx->timing.total_ms = ms;
-    std::vector<double> h((size_t)nsteps * HROW);
-    NK_HIP(hipMemcpy(h.data(), ctx->hist, h.size() * sizeof(double), hipMemcpyDeviceToHost));
-    int overflow = 0;      // reason mask: 1 more entering particles than free slots, 2 / 4 a segment filled up (tile commit /
-                           // event survivors), 8 spawn list full, 16 one_to_one index overflow
-    for (int s = 0; s < nsteps; ++s) {
-        const double *row = &h[(size_t)s * HROW];
-        if (row[NB + 2 * S + 3] != 0.0) overflow |= (int)row[NB + 2 * S + 3];
-        if (!out) continue;
-        if (out->E_raw) memcpy(out->E_raw + (size_t)s * S, row, S * 8);
-        if (out->N_sv) memcpy(out->N_sv + (size_t)s * S, row + S, S * 8);
-        if (out->flux_raw) {
-            if (row[NB + 2 * S] != 0.0) memcpy(out->flux_raw + (size_t)s * 3 * S, row + 2 * S, 3 * S * 8);
-            else for (int k = 0; k < 3 * S; ++k) out->flux_raw[(size_t)s * 3 * S + k] = NAN;
-        }
-        if (out->N_leaving && R) memcpy(out->N_leaving + (size_t)s * R, row + 5 * S, R * 8);
-        if (out->res_energy && R) memcpy(out->res_energy + (size_t)s * R, row + 5 * S + R, R * 8);
-        if (out->res_flux && R) memcpy(out->res_flux + (size_t)s * 3 * R, row + 5 * S + 2 * R, 3 * R * 8);
-        if (out->N_emitted) out->N_emitted[s] = row[NB - 1];
-        if (out->T_sv) memcpy(out->T_sv + (size_t)s * S, row + NB, S * 8);
-        if (out->E_sv) memcpy(out->E_sv + (size_t)s * S, row + NB + S, S * 8);
+    if (nt > 0 && nd == nsteps) {
+        ctx->timing.step_kernel_ms = sk / nt;
+        ctx->timing.emit_kernel_ms = ek / nt;
+        ctx->timing.events_kernel_ms = vk / nt;
+        ctx->timing.total_ms = ms;
     }
-    const double *last = &h[(size_t)(nsteps - 1) * HROW];
-    nk_track_T(ctx, last + NB, S);
+    return NK_OK;
+}
+
+int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
+    NK_ARG(ctx && nsteps > 0, "nk_step: bad arguments");
+    int rc = nk_check_ready(ctx);
+    if (rc) return rc;
+    NK_HIP(hipSetDevice(ctx->device));
+    if ((rc = nk_update_tau_window(ctx, false))) return rc;
+    if ((rc = nk_ensure_inbox(ctx))) return rc;
+    NkDev &d = ctx->d;
+    const int S = d.S, R = d.R, NB = d.NB;
+    const int HROW = NB + 2 * S + 4;
+    ctx->stepped = true;
+    int32_t s_out = 0;                 // rows delivered so far
+    int overflow = 0;      // reason mask: 2 / 4 a segment filled up (tile commit / event survivors), 8 one_to_one inbox full,
+                           // 16 one_to_one index overflow
+    int grown = 0;
+    std::vector<double> h;
+    double last_T[2] = {0, 0};
+    while (s_out < nsteps) {
+        int32_t nd = 0;
+        if ((rc = nk_step_batch(ctx, nsteps - s_out, h, &nd))) return rc;
+        for (int s = 0; s < nd; ++s) {
+            const double *row = &h[(size_t)s * HROW];
+            if (row[NB + 2 * S + 3] != 0.0) overflow |= (int)row[NB + 2 * S + 3];
+            if (!out) continue;
+            const size_t q = (size_t)(s_out + s);
+            if (out->E_raw) memcpy(out->E_raw + q * S, row, S * 8);
+            if (out->N_sv) memcpy(out->N_sv + q * S, row + S, S * 8);
+            if (out->flux_raw) {
+                if (row[NB + 2 * S] != 0.0) memcpy(out->flux_raw + q * 3 * S, row + 2 * S, 3 * S * 8);
+                else for (int k = 0; k < 3 * S; ++k) out->flux_raw[q * 3 * S + k] = NAN;
+            }
+            if (out->N_leaving && R) memcpy(out->N_leaving + q * R, row + 5 * S, R * 8);
+            if (out->res_energy && R) memcpy(out->res_energy + q * R, row + 5 * S + R, R * 8);
+            if (out->res_flux && R) memcpy(out->res_flux + q * 3 * R, row + 5 * S + 2 * R, 3 * R * 8);
+            if (out->N_emitted) out->N_emitted[q] = row[NB - 1];
+            if (out->T_sv) memcpy(out->T_sv + q * S, row + NB, S * 8);
+            if (out->E_sv) memcpy(out->E_sv + q * S, row + NB + S, S * 8);
+        }
+        if (nd > 0) {
+            const double *last = &h[(size_t)(nd - 1) * HROW];
+            nk_track_T(ctx, last + NB, S);
+            double live = 0.0;
+            for (int k = 0; k < S; ++k) live += last[S + k];
+            ctx->timing.live = (int64_t)live;
+            (void)last_T;
+        }
+        ctx->step += nd;
+        s_out += nd;
+        if (s_out < nsteps) {
+            // halted: a segment could overflow at the next step.  Grow every segment by half (on the device, state intact)
+            // and carry on with the remaining steps.
+            if (++grown > 40) { ctx->err = "nk_step: the particle store keeps filling up"; return NK_ERR_CAPACITY; }
+            const int64_t need = (int64_t)d.segcap + d.segcap / 2 + 2 * nk_spawn_bound(ctx, d.nseg) + 2 * NK_TILE;
+            if ((rc = nk_regrow(ctx, need))) {
+                ctx->err = "particle store nearly full after step " + std::to_string((long long)ctx->step) +
+                           " and it could not be grown (" + ctx->err + "); the state is intact";
+                return NK_ERR_CAPACITY;
+            }
+            int32_t zero2[2] = {0, 0};
+            NK_HIP(hipMemcpy(d.halt, zero2, 8, hipMemcpyHostToDevice));
+            if ((rc = nk_update_tau_window(ctx, false))) return rc;
+        }
+    }
     ctx->timing.slots = d.cap;
-    double live = 0.0;
-    for (int k = 0; k < S; ++k) live += last[S + k];
-    ctx->timing.live = (int64_t)live;
     if (overflow) {
         ctx->err = "particle capacity exceeded during nk_step (reason mask " + std::to_string(overflow) +
                    "): particles were dropped; call nk_reserve with a larger capacity";
@@ -1187,7 +1360,7 @@ int nk_download_particles(nk_ctx *ctx, int64_t capacity, double *x, double *y, d
     NkDev &d = ctx->d;
     *N_out = 0;
     if (d.cap == 0) return NK_OK;
-    if (ctx->have_material && ctx->have_sv && ctx->have_mesh) { int rc = nk_flush_relax(ctx); if (rc) return rc; }
+    if (ctx->have_material && ctx->have_sv && ctx->have_mesh) { int rc = nk_flush_relax(ctx, 0); if (rc) return rc; }
     NkHostParticles h;
     int rc = nk_gather_live(ctx, h, capacity != 0);
     if (rc) return rc;
@@ -1260,7 +1433,7 @@ int nk_comm_unique_id(void *id128) {
 }
 int nk_comm_init(nk_ctx *ctx, const void *id128, int rank, int nranks) {
     NK_ARG(ctx && id128 && nranks >= 1 && rank >= 0 && rank < nranks, "nk_comm_init: bad arguments");
-    NK_ARG(!ctx->spawn_ready, "nk_comm_init: must be called before the first nk_step (emission ownership is per rank)");
+    NK_ARG(!ctx->stepped, "nk_comm_init: must be called before the first nk_step (emission ownership is per rank)");
     NK_HIP(hipSetDevice(ctx->device));
     ctx->d.rank = rank;
     ctx->d.nranks = nranks;
@@ -1275,25 +1448,34 @@ int nk_comm_init(nk_ctx *ctx, const void *id128, int rank, int nranks) {
 }
 
 // ------------------------------------------------------------------------------------- parity taps
-#define NK_DEV_IN(T, name, src, count)                                                                 \
-    T *name = nullptr;                                                                                 \
-    NK_HIP(hipMalloc((void **)&name, (size_t)(count) * sizeof(T)));                                    \
-    if (src) NK_HIP(hipMemcpy(name, src, (size_t)(count) * sizeof(T), hipMemcpyHostToDevice));
-#define NK_DEV_OUT(T, name, dst, count)                                                                \
-    if (dst) NK_HIP(hipMemcpy(dst, name, (size_t)(count) * sizeof(T), hipMemcpyDeviceToHost));         \
-    hipFree(name);
+}  // extern "C"
+// Scratch device buffer of a tap: freed on every return path.
+template <class T>
+struct NkDevBuf {
+    T *p = nullptr;
+    hipError_t err = hipSuccess;
+    NkDevBuf(const T *src, int64_t count) {
+        err = hipMalloc((void **)&p, (size_t)(count > 0 ? count : 1) * sizeof(T));
+        if (err == hipSuccess && src) err = hipMemcpy(p, src, (size_t)count * sizeof(T), hipMemcpyHostToDevice);
+    }
+    ~NkDevBuf() { if (p) hipFree(p); }
+    hipError_t get(T *dst, int64_t count) const { return dst ? hipMemcpy(dst, p, (size_t)count * sizeof(T), hipMemcpyDeviceToHost) : hipSuccess; }
+    NkDevBuf(const NkDevBuf &) = delete;
+    NkDevBuf &operator=(const NkDevBuf &) = delete;
+};
+#define NK_BUF(T, name, src, count) NkDevBuf<T> name(src, count); NK_HIP(name.err)
+extern "C" {
 
 int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x, const double *v, double *xc, double *tc, int32_t *fc) {
     NK_ARG(ctx && ctx->have_mesh && ctx->have_sv && n > 0 && x && v, "nk_find_boundary: bad arguments");
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
-    NK_DEV_IN(double, dx, x, n * 3); NK_DEV_IN(double, dv, v, n * 3);
-    NK_DEV_IN(double, dxc, (double *)nullptr, n * 3); NK_DEV_IN(double, dtc, (double *)nullptr, n);
-    NK_DEV_IN(int32_t, dfc, (int32_t *)nullptr, n);
+    NK_BUF(double, dx, x, n * 3); NK_BUF(double, dv, v, n * 3);
+    NK_BUF(double, dxc, nullptr, n * 3); NK_BUF(double, dtc, nullptr, n); NK_BUF(int32_t, dfc, nullptr, n);
     const bool verbose = getenv("NK_VERBOSE") != nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (verbose) { NK_HIP(hipEventCreate(&e0)); NK_HIP(hipEventCreate(&e1)); NK_HIP(hipEventRecord(e0, ctx->stream)); }
-    NK_GEOM_LAUNCH(k_tap_find_boundary, (int)((n + NK_WG - 1) / NK_WG), nk_lds(ctx, true), d, n, dx, dv, dxc, dtc, dfc);
+    NK_GEOM_LAUNCH(k_tap_find_boundary, (int)((n + NK_WG - 1) / NK_WG), nk_lds(ctx, true), d, n, dx.p, dv.p, dxc.p, dtc.p, dfc.p);
     NK_HIP(hipGetLastError());
     if (verbose) NK_HIP(hipEventRecord(e1, ctx->stream));
     NK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1303,33 +1485,30 @@ int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x, const double *v, d
         fprintf(stderr, "[nanokappa_hip] find_boundary: %lld rays in %.3f ms\n", (long long)n, ms);
         hipEventDestroy(e0); hipEventDestroy(e1);
     }
-    NK_DEV_OUT(double, dxc, xc, n * 3); NK_DEV_OUT(double, dtc, tc, n); NK_DEV_OUT(int32_t, dfc, fc, n);
-    hipFree(dx); hipFree(dv);
+    NK_HIP(dxc.get(xc, n * 3)); NK_HIP(dtc.get(tc, n)); NK_HIP(dfc.get(fc, n));
     return NK_OK;
 }
 int nk_classify(nk_ctx *ctx, int64_t n, const double *x, int32_t *id) {
     NK_ARG(ctx && ctx->have_sv && n > 0 && x && id, "nk_classify: bad arguments");
     NK_HIP(hipSetDevice(ctx->device));
-    NK_DEV_IN(double, dx, x, n * 3); NK_DEV_IN(int32_t, did, (int32_t *)nullptr, n);
-    k_tap_classify<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>(ctx->d, n, dx, did);
+    NK_BUF(double, dx, x, n * 3); NK_BUF(int32_t, did, nullptr, n);
+    k_tap_classify<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, nk_lds(ctx, false), ctx->stream>>>(ctx->d, n, dx.p, did.p);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    NK_DEV_OUT(int32_t, did, id, n);
-    hipFree(dx);
+    NK_HIP(did.get(id, n));
     return NK_OK;
 }
 int nk_eval(nk_ctx *ctx, int32_t what, int64_t n, const double *a, const int32_t *mode, double *out) {
-    NK_ARG(ctx && ctx->have_material && n > 0 && a && out && what >= 0 && what <= 4, "nk_eval: bad arguments");
+    NK_ARG(ctx && ctx->have_material && n > 0 && a && out && what >= 0 && what <= 5, "nk_eval: bad arguments");
     NK_ARG(what > 1 || mode, "nk_eval: mode required");
-    NK_ARG(what != 4 || ctx->have_sv, "nk_eval: subvolumes required");
+    NK_ARG(ctx->have_sv, "nk_eval: subvolumes required");
     NK_HIP(hipSetDevice(ctx->device));
     const int64_t na = what == 4 ? 3 * n : n;
-    NK_DEV_IN(double, da, a, na); NK_DEV_IN(int32_t, dm, mode, n); NK_DEV_IN(double, dout, (double *)nullptr, n);
-    k_tap_eval<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>(ctx->d, what, n, da, dm, dout);
+    NK_BUF(double, da, a, na); NK_BUF(int32_t, dm, mode, n); NK_BUF(double, dout, nullptr, n);
+    k_tap_eval<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, nk_lds(ctx, false), ctx->stream>>>(ctx->d, what, n, da.p, mode ? dm.p : nullptr, dout.p);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    NK_DEV_OUT(double, dout, out, n);
-    hipFree(da); hipFree(dm);
+    NK_HIP(dout.get(out, n));
     return NK_OK;
 }
 int nk_reflect(nk_ctx *ctx, int64_t n, const int32_t *facet, const int32_t *mode_in, const double *col_pos,
@@ -1340,18 +1519,15 @@ int nk_reflect(nk_ctx *ctx, int64_t n, const int32_t *facet, const int32_t *mode
     for (int64_t i = 0; i < n; ++i)
         NK_ARG(facet[i] >= 0 && facet[i] < ctx->d.Fc && ctx->host_facets[facet[i]].rough >= 0, "nk_reflect: facet is not rough");
     NK_HIP(hipSetDevice(ctx->device));
-    NK_DEV_IN(int32_t, df, facet, n); NK_DEV_IN(int32_t, dm, mode_in, n); NK_DEV_IN(double, dc, col_pos, n * 3);
-    NK_DEV_IN(double, dn, n_in, n); NK_DEV_IN(double, dom, omega_in, n); NK_DEV_IN(double, drs, r_spec, n);
-    double *drd = nullptr;
-    if (r_deg) { NK_HIP(hipMalloc((void **)&drd, (size_t)n * 8)); NK_HIP(hipMemcpy(drd, r_deg, (size_t)n * 8, hipMemcpyHostToDevice)); }
-    NK_DEV_IN(double, drf, r_diff, n);
-    NK_DEV_IN(int32_t, dmo, (int32_t *)nullptr, n); NK_DEV_IN(double, dno, (double *)nullptr, n); NK_DEV_IN(double, doo, (double *)nullptr, n);
-    k_tap_reflect<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>(ctx->d, n, df, dm, dc, dn, dom, drs, drd, drf, dmo, dno, doo);
+    NK_BUF(int32_t, df, facet, n); NK_BUF(int32_t, dm, mode_in, n); NK_BUF(double, dc, col_pos, n * 3);
+    NK_BUF(double, dn, n_in, n); NK_BUF(double, dom, omega_in, n); NK_BUF(double, drs, r_spec, n);
+    NK_BUF(double, drd, r_deg, n); NK_BUF(double, drf, r_diff, n);
+    NK_BUF(int32_t, dmo, nullptr, n); NK_BUF(double, dno, nullptr, n); NK_BUF(double, doo, nullptr, n);
+    k_tap_reflect<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, nk_lds(ctx, false), ctx->stream>>>(
+        ctx->d, n, df.p, dm.p, dc.p, dn.p, dom.p, drs.p, r_deg ? drd.p : nullptr, drf.p, dmo.p, dno.p, doo.p);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    NK_DEV_OUT(int32_t, dmo, mode_out, n); NK_DEV_OUT(double, dno, n_out, n); NK_DEV_OUT(double, doo, omega_out, n);
-    hipFree(df); hipFree(dm); hipFree(dc); hipFree(dn); hipFree(dom); hipFree(drs); hipFree(drf);
-    if (drd) hipFree(drd);
+    NK_HIP(dmo.get(mode_out, n)); NK_HIP(dno.get(n_out, n)); NK_HIP(doo.get(omega_out, n));
     return NK_OK;
 }
 int nk_calibrate_stream(nk_ctx *ctx, int32_t launches, int64_t *bytes_read, int64_t *bytes_written) {

@@ -2,16 +2,15 @@
 //
 // Stream order of one timestep (reference Population.run_timestep, Population.py:1724-1769):
 //   [k_relax + k_contains every `contains_every` steps]            contains_check       :1712-1722
-//   [k_emit_count / k_emit_one_to_one: only to prime a run, for very large (reservoir, mode) tables, or for the
-//    'one_to_one' generator]                                        fill_reservoirs      :356-489
+//   [k_emit_one_to_one: only for the 'one_to_one' generator]        fill_reservoirs      :457-489
 //   k_sweep       per segment (one wave): relax(previous step) -> drift -> boundary events -> tally -> compaction,
-//                 then the segment's share of the entering particles; in its tail the NEXT step's emission
+//                 then the reservoir particles of the segment's own modes
 //                                                                   lifetime_scattering  :1701-1710 (deferred)
 //                                                                   drift                :790-795
 //                                                                   boundary_scattering  :1546-1683
+//                                                                   fill_reservoirs      :356-455
 //                                                                   add_reservoir_particles :525-552
 //                                                                   calculate_energy     :704-717
-//                                                                   fill_reservoirs      :356-455 (for step + 1)
 //   k_reduce      deterministic column sums of the per-workgroup tally rows; single rank: the last workgroup also
 //                 normalises, inverts E -> T and writes the history row    calculate_energy :719-728, refresh_temperatures :692
 //   (nranks > 1: RCCL all-reduce of the tally vector, then k_update does that part)
@@ -21,54 +20,49 @@
 // positions, same T_sv): one pass over the particles per step instead of two.  A pending relaxation is flushed by
 // k_relax before anything observes the particles (download, contains_check).
 //
-// Why one fused sweep (measured, profiles/r01_c2_1e7_pmc_v2_uncalibrated.json): with a separate event kernel and
-// free-slot reuse the step kernel moved 2.8 GB per launch for 0.68 GB of algorithmic traffic -- random 64-B mode gathers
-// (1.2 GB) and line-granular write-backs of the scattered event kernel -- and ran AT the HBM roof (6.3 TB/s).  Here
+// The sweep (history: DESIGN.md):
 //   * a WAVE owns a segment and walks it tile by tile (64 particles, coalesced loads, next tile prefetched);
-//   * particles that meet a boundary inside the step (a third of them in a 20 nm box) are parked in the wave's slice of
-//     an LDS buffer and processed 64 at a time by all lanes, one event per pass (no divergence against the streaming
-//     lanes, no second trip through HBM); the few that meet another wall are parked again;
+//   * particles that meet a boundary inside the step (a third of them in a 20 nm box) are moved, with cross-lane
+//     permutes, into a second set of REGISTERS (the carry: up to 63 parked particles, packed in the low lanes); whenever
+//     64 are there the whole wave runs one boundary event per particle with all lanes busy; the few that meet another
+//     wall stay in the carry.  No LDS buffer, no second trip through HBM, no divergence against the streaming lanes;
 //   * survivors are written back compacted IN PLACE (write cursor <= read cursor), absorbed particles simply vanish;
-//   * entering particles are appended to the segment in whole tiles, in runs of (reservoir, mode) order.
+//   * the modes a segment owns (nk_device.h) enter through the reservoirs in the same loop: the wave evaluates its
+//     (reservoir, mode) entries, keeps their counts in LDS and builds the entering particles in whole tiles.
 #pragma once
 #include "nk_device.h"
 
 // =================================================================================== LDS carve-up
-struct NkEvBuf {          // parked boundary-event particles of the workgroup
-    double *x, *y, *z, *occ, *nts, *cts;     // cts: fraction of the step already consumed by earlier events
-    unsigned long long *pid;
-    int *mode, *facet, *evc;                 // evc: events so far in this step (numbers the RNG draws)
-};
 struct NkLds {
-    double *Tsv, *cen;
+    NkSvTab tb;                          // centres, temperatures (+ RBF coefficients), per-subvolume records
     NkBins bins;
     const double *planes, *faces;
     const NkFacet *facets;
-    const double *resT;                  // [R] reservoir temperatures
+    const double *resT;                  // [2R] reservoir {T, 1/T}
     const int *rf_off;                   // reservoir face tables (CSR), LDS copies when d.res_lds
     const double *rf_cdf, *rf_verts;
-    NkEvBuf ev;
+    // emission scratch of the sweep, one slice of NK_EMIT_CHUNK entries per wave
+    unsigned int *sp_pref, *sp_cnt, *sp_rm;
+    double *sp_cv;
 };
 
 // geom: 0 = no ray-casting tables, 1 = planes/faces/facets staged in LDS, 2 = read from global memory (large meshes)
-// nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged)
-__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, bool evbuf, int nrf, int rbfP) {
+// nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged); emit: carve the sweep's emission scratch
+__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, bool emit, int nrf, int rbfP) {
     int Fl = geom == 1 ? F : 0;
     int Pl = Fl ? NP : 0;
     int Fcl = geom == 1 ? Fc : 0;
-    size_t nd = (size_t)S + (size_t)((rbfP + 1) & ~1) + 3 * S + NK_NREP * S + NK_NREP * 3 * S + 4 * R + (size_t)Fl * NK_FACE_DOUBLES +
-                (size_t)Pl * NK_PLANE_DOUBLES + (evbuf ? 7 * NK_EVCAP : 0) + (size_t)R + 10 * (size_t)nrf + 2;
+    size_t nd = (size_t)S + (size_t)((rbfP + 1) & ~1) + 3 * S + ((3 * S) & 1) + 4 * (size_t)S + NK_NREP * S + NK_NREP * 3 * S + 4 * R +
+                (size_t)Fl * NK_FACE_DOUBLES + (size_t)Pl * NK_PLANE_DOUBLES + 2 * (size_t)R + 10 * (size_t)nrf +
+                (emit ? (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + 4;
     size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) +
-                   (size_t)(NK_NREP * S + R + 1 + (R + 1) + (evbuf ? 3 * NK_EVCAP : 0)) * 4 + 16;
+                   (size_t)(NK_NREP * S + R + 1 + (R + 1) + (emit ? 3 * (NK_WG / 64) * NK_EMIT_CHUNK : 0)) * 4 + 32;
     return (bytes + 15) & ~(size_t)15;
 }
 
-// Cooperative fill of the read-only tables and zeroing of the bins; ends with a barrier.  GEOM as in nk_lds_bytes (a
-// compile-time choice, so that the table pointers are provably LDS and are read with ds_read, not flat loads);
-// EVBUF = carve the event buffer.  Plane, face and facet tables start on 16-byte boundaries (they are read 16 bytes
-// at a time).
-// The pointer arithmetic alone (also what an out-of-line helper needs to find the tables again).
-template <int GEOM, bool EVBUF>
+// The pointer arithmetic.  GEOM as in nk_lds_bytes (a compile-time choice, so that the table pointers are provably LDS and
+// are read with ds_read, not flat loads).  Plane, face, facet and subvolume records start on 16-byte boundaries.
+template <int GEOM, bool EMIT>
 __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem, NkLds &L) {
     const int S = d.S, R = d.R;
     const int Fl = GEOM == 1 ? d.F : 0;
@@ -76,38 +70,41 @@ __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem
     const int Fcl = GEOM == 1 ? d.Fc : 0;
     const int nrf = (GEOM == 1 && d.res_lds) ? d.res_nf : 0;
     double *p = (double *)smem;
-    L.Tsv = p; p += S + ((d.rbf_P + 1) & ~1);          // temperatures, then the RBF coefficients (even count)
-    L.cen = p; p += 3 * S;
+    L.tb.Tsv = p; p += S + ((d.rbf_P + 1) & ~1);       // temperatures, then the RBF coefficients (even count)
+    L.tb.cen = p; p += 3 * S + ((3 * S) & 1);
+    p += ((size_t)S & 1);                              // 16-byte alignment of the records below
+    L.tb.sv = (const NkSv *)p; p += 4 * S;
     L.bins.E = p; p += NK_NREP * S;
     L.bins.flux = p; p += NK_NREP * 3 * S;
-    L.bins.resb = p; p += 4 * R;                       // 36 S + 4 R doubles so far: even
+    L.bins.resb = p; p += 4 * R;
+    p += ((size_t)(p - (double *)smem) & 1);
     double *faces = p; p += (size_t)Fl * NK_FACE_DOUBLES;
     double *planes = p; p += (size_t)Pl * NK_PLANE_DOUBLES;
-    if (EVBUF) {
-        L.ev.x = p; p += NK_EVCAP; L.ev.y = p; p += NK_EVCAP; L.ev.z = p; p += NK_EVCAP;
-        L.ev.occ = p; p += NK_EVCAP; L.ev.nts = p; p += NK_EVCAP;
-        L.ev.pid = (unsigned long long *)p; p += NK_EVCAP;
-        L.ev.cts = p; p += NK_EVCAP;
-    }
-    double *resT = p; p += R;
+    double *resT = p; p += 2 * R;
     double *rf_cdf = p; p += nrf;
     double *rf_verts = p; p += 9 * (size_t)nrf;
-    p += ((size_t)R + 10 * (size_t)nrf) & 1;           // keep the facet table 16-byte aligned
+    if (EMIT) { L.sp_cv = p; p += (NK_WG / 64) * NK_EMIT_CHUNK; } else L.sp_cv = nullptr;
+    p += ((size_t)(p - (double *)smem) & 1);           // keep the facet table 16-byte aligned
     NkFacet *facets = (NkFacet *)p;
     unsigned int *u = (unsigned int *)(facets + Fcl);
     L.bins.N = u; u += NK_NREP * S;
     L.bins.nleave = u; u += R;
     L.bins.misc = u; u += 1;
     int *rf_off = (int *)u; u += R + 1;
-    if (EVBUF) { L.ev.mode = (int *)u; u += NK_EVCAP; L.ev.facet = (int *)u; u += NK_EVCAP; L.ev.evc = (int *)u; u += NK_EVCAP; }
+    if (EMIT) {
+        L.sp_pref = u; u += (NK_WG / 64) * NK_EMIT_CHUNK;
+        L.sp_cnt = u; u += (NK_WG / 64) * NK_EMIT_CHUNK;
+        L.sp_rm = u; u += (NK_WG / 64) * NK_EMIT_CHUNK;
+    } else { L.sp_pref = L.sp_cnt = L.sp_rm = nullptr; }
     L.resT = resT;
     L.rf_off = rf_off; L.rf_cdf = rf_cdf; L.rf_verts = rf_verts;
     if (GEOM == 1) { L.faces = faces; L.planes = planes; L.facets = facets; }
     else { L.faces = d.faces; L.planes = d.planes; L.facets = d.facets; }
 }
-template <int GEOM, bool EVBUF>
+// Cooperative fill of the read-only tables and zeroing of the bins; ends with a barrier.
+template <int GEOM, bool EMIT>
 __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem, NkLds &L) {
-    nk_lds_carve<GEOM, EVBUF>(d, smem, L);
+    nk_lds_carve<GEOM, EMIT>(d, smem, L);
     const int S = d.S, R = d.R;
     const int Fl = GEOM == 1 ? d.F : 0;
     const int Pl = Fl ? d.NP : 0;
@@ -117,13 +114,23 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     NkFacet *facets = const_cast<NkFacet *>(L.facets);
     double *resT = const_cast<double *>(L.resT), *rf_cdf = const_cast<double *>(L.rf_cdf), *rf_verts = const_cast<double *>(L.rf_verts);
     int *rf_off = const_cast<int *>(L.rf_off);
+    double *Tsv = const_cast<double *>(L.tb.Tsv), *cen = const_cast<double *>(L.tb.cen);
+    NkSv *sv = const_cast<NkSv *>(L.tb.sv);
     const int t = threadIdx.x;
-    for (int i = t; i < S + d.rbf_P; i += NK_WG) L.Tsv[i] = d.T_sv[i];
-    for (int i = t; i < 3 * S; i += NK_WG) L.cen[i] = d.centers[i];
+    for (int i = t; i < S + d.rbf_P; i += NK_WG) Tsv[i] = d.T_sv[i];
+    for (int i = t; i < 3 * S; i += NK_WG) cen[i] = d.centers[i];
+    for (int i = t; i < S; i += NK_WG) {
+        // per-subvolume record: centre along the slice axis, T, slope of interp1d's bracket (i, i+1), 1 / T
+        const int a = d.sv_axis, j = i + 1 < S ? i + 1 : i;
+        const double c = d.centers[3 * i + a], cn = d.centers[3 * j + a], T = d.T_sv[i], Tn = d.T_sv[j];
+        NkSv q;
+        q.c = c; q.T = T; q.slope = j > i ? (Tn - T) / (cn - c) : 0.0; q.invT = 1.0 / T;
+        sv[i] = q;
+    }
     for (int i = t; i < NK_NREP * S; i += NK_WG) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
     for (int i = t; i < NK_NREP * 3 * S; i += NK_WG) L.bins.flux[i] = 0.0;
     for (int i = t; i < 4 * R; i += NK_WG) L.bins.resb[i] = 0.0;
-    for (int i = t; i < R; i += NK_WG) { L.bins.nleave[i] = 0u; resT[i] = d.res_T[i]; }
+    for (int i = t; i < R; i += NK_WG) { L.bins.nleave[i] = 0u; const double T = d.res_T[i]; resT[2 * i] = T; resT[2 * i + 1] = 1.0 / T; }
     if (t == 0) L.bins.misc[0] = 0u;
     for (int i = t; i < Fl * NK_FACE_DOUBLES; i += NK_WG) faces[i] = d.faces[i];
     for (int i = t; i < Pl * NK_PLANE_DOUBLES; i += NK_WG) planes[i] = d.planes[i];
@@ -160,20 +167,15 @@ __device__ __forceinline__ void nk_lds_flush(const NkDev &d, const NkLds &L, int
 }
 
 // Deferred lifetime_scattering (Population.py:1701-1710) for one particle.
-// The mode record is passed as two 32-byte halves {omega, vx, vy, vz} {tau0..tau3} (two dwordx4 pairs, no struct copy).
+// The mode record is passed as two 32-byte halves {omega, vx, vy, vz} {E0, tau0..tau2} (two dwordx4 pairs, no struct copy).
 template <bool RBF = true>
 __device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const double4 &ra, const double4 &rb, double x,
                                            double y, double z, double occ, int mode) {
-    double T = nk_interp_T<RBF>(d, L.cen, L.Tsv, x, y, z, -1);
-    double tau = nk_lifetime(d, rb.x, rb.y, rb.z, rb.w, T, mode);
-    double n0 = nk_occupation(d, T, ra.x);
-    return (tau > 0.0) ? n0 + (occ - n0) * exp(-d.dt / tau) : n0;
-}
-
-__device__ __forceinline__ void nk_store(const NkDev &d, int64_t i, double x, double y, double z, double occ, double nts,
-                                         int mode, int facet, unsigned long long pid) {
-    d.x[i] = x; d.y[i] = y; d.z[i] = z; d.occ[i] = occ; d.nts[i] = nts;
-    d.mode[i] = mode; d.facet[i] = facet; d.pid[i] = pid;
+    double invT;
+    const double T = nk_interp_T<RBF>(d, L.tb, x, y, z, invT);
+    const double tau = nk_lifetime(d, rb.y, rb.z, rb.w, T, mode);
+    const double n0 = (T > 0.0) ? nk_be(ra.x * d.c_hk, rb.x, invT, d.invT0) : 0.0;
+    return (tau > 0.0) ? n0 + (occ - n0) * nk_exp(-d.dt * nk_rcp(tau)) : n0;
 }
 
 // Mesh.sample_surface on one reservoir facet (Mesh.py:923-951): face by area (np.random.choice, :937), then a uniform
@@ -191,22 +193,36 @@ __device__ __forceinline__ void nk_sample_res_face(const int *off, const double 
     z0 = a0 * fv[2] + a1 * fv[5] + a2 * fv[8];
 }
 
-// Ray cast as the kernels call it: grouped sweep for meshes whose tables stay in global memory, plain sweep over LDS.
+// Ray cast as the kernels call it: tree walk for meshes whose tables stay in global memory, plain sweep over LDS.
 #define NK_RAY(GEOM, d, L, skip, x, y, z, vx, vy, vz, tc, fc)                                                        \
     do {                                                                                                              \
         if ((GEOM) == 2 && (d).NG > 0) nk_find_boundary_tree(d, skip, x, y, z, vx, vy, vz, tc, fc);                      \
         else nk_find_boundary((L).planes, (L).faces, (d).NP, (d).tol, x, y, z, vx, vy, vz, tc, fc);                   \
     } while (0)
 
+// Particle <-> mode bookkeeping of a segment (nk_device.h: modes are partitioned over the segments).
+struct NkSegModes {
+    const NkMode *rec;      // record of stored index i at rec[i]
+    int mstride, moff;      // global mode of stored index i = i * mstride + moff
+    int nl;                 // modes this segment owns
+};
+__device__ __forceinline__ NkSegModes nk_seg_modes(const NkDev &d, int seg) {
+    NkSegModes sm;
+    sm.rec = d.part ? d.modetab_p + (int64_t)seg * d.nlmax : d.modetab;
+    sm.mstride = d.part ? d.nseg : 1;
+    sm.moff = d.part ? seg : 0;
+    sm.nl = seg < d.M ? (d.M - seg + d.nseg - 1) / d.nseg : 0;
+    return sm;
+}
+
 // ========================================================================================= kernels
 // Which modes enter at each reservoir at `step`, and how many particles of each: fill_reservoirs 'constant'
 // (Population.py:358-370) / 'fixed_rate' (:408-420) for one (reservoir, mode) entry.  c = particles entering,
-// c_mine = those this rank owns (emission_owner: (rm + level + step) % nranks).
-__device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int buf, int64_t rm, int &c, int &c_mine) {
-    const double prob = d.enter_prob[rm];
+// c_mine = those this rank owns (emission_owner: (rm + level + step) % nranks); cv = the counter / dice value that the
+// level-1 particle's entry time uses.
+__device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int64_t rm, double prob, int &c, int &c_mine, double &cv) {
     const double fixed = floor(prob);
     int mask;
-    double cv;
     if (d.res_gen == 0) {
         cv = d.res_counter[rm] + (prob - fixed);
         mask = cv >= 1.0;
@@ -218,231 +234,202 @@ __device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int
         mask = cv <= (prob - fixed);
     }
     c = (int)fixed + mask;
-    if (c > 0) d.res_cval[buf][rm] = cv;
-    c_mine = 0;
-    if (d.nranks == 1) c_mine = c;
-    else for (int level = c; level >= 1; --level)                  // rm < 2^28, so 32-bit arithmetic is exact
-        c_mine += (((uint32_t)rm + (uint32_t)level + step) % (uint32_t)d.nranks) == (uint32_t)d.rank;
-}
-
-// The entries [e0, e1) (at most KMAX * NK_WG of them) handled by one workgroup: every entering particle gets one
-// 64-bit record (rm << 12 | level) in spawn_list[buf].  Space is claimed with ONE global atomic per workgroup (a hot
-// counter serves ~90 atomics/us).  Must be called by all threads of the workgroup.
-template <int KMAX>
-__device__ __forceinline__ void nk_emit_block(const NkDev &d, uint32_t step, int buf, int64_t e0, int64_t e1, int *wsum,
-                                              int *bbase) {
-    static_assert(KMAX <= 4, "counts are packed 16 bits per entry");
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint64_t pc = 0, pm = 0;                       // (c, c_mine) of this thread's entries, 16 bits each (c <= 4095);
-    int mine = 0;                                  // rolled loops: this sits in the sweep's tail, keep the code small
-#pragma unroll 1
-    for (int k = 0; k < KMAX; ++k) {
-        const int64_t rm = e0 + (int64_t)k * NK_WG + tid;
-        int c = 0, cm = 0;
-        if (rm < e1) nk_emit_entry(d, step, buf, rm, c, cm);
-        pc |= (uint64_t)c << (16 * k);
-        pm |= (uint64_t)cm << (16 * k);
-        mine += cm;
-    }
-    int incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    const int total = __shfl(incl, 63, 64);
-    if (lane == 63) wsum[wave] = total;
-    __syncthreads();
-    if (tid == 0) {
-        int t = 0;
-        for (int w = 0; w < NK_WG / 64; ++w) t += wsum[w];
-        *bbase = t > 0 ? atomicAdd(d.alloc_count + buf, t) : 0;
-    }
-    __syncthreads();
-    int base = *bbase;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-    int64_t g = (int64_t)base + incl - mine;
-    uint64_t *list = d.spawn_list[buf];
-#pragma unroll 1
-    for (int k = 0; k < KMAX; ++k) {
-        const int64_t rm = e0 + (int64_t)k * NK_WG + tid;
-        const int c = (int)((pc >> (16 * k)) & 0xFFFFu), cm = (int)((pm >> (16 * k)) & 0xFFFFu);
-        for (int level = c; level >= 1 && cm > 0; --level) {
-            if (d.nranks > 1 && (((uint32_t)rm + (uint32_t)level + step) % (uint32_t)d.nranks) != (uint32_t)d.rank) continue;
-            if (g < d.spawn_cap) list[g] = ((uint64_t)rm << 12) | (uint64_t)level;
-            else atomicOr(d.overflow, 8);       // spawn list full
-            ++g;
-        }
+    c_mine = c;
+    if (d.nranks > 1) {
+        c_mine = 0;
+        for (int level = c; level >= 1; --level)                   // rm < 2^28, so 32-bit arithmetic is exact
+            c_mine += (((uint32_t)rm + (uint32_t)level + step) % (uint32_t)d.nranks) == (uint32_t)d.rank;
     }
 }
-#define NK_EMIT_KMAX 4          // entries per thread the sweep's tail may take (else k_emit_count runs every step)
 
 // fill_reservoirs 'one_to_one' (Population.py:457-489): one particle in for every particle that left through the
 // reservoir at the previous step (all ranks; nleave_prev is written by the update after the all-reduce).  One thread
-// per candidate: owner test, mode from the cumulative enter_prob (np.searchsorted :472), record
-// (i << 40 | rm << 12 | 0) -- level 0 marks "entry time uniform in the step" for the sweep's phase B.
+// per candidate: owner test, mode from the cumulative enter_prob (np.searchsorted :472), record (i << 40 | rm << 12)
+// appended to the inbox of the segment that owns the mode.
 __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t step) {
-    __shared__ int wsum[NK_WG / 64];
-    __shared__ int bbase;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int buf = (int)(step & 1u);
+    if (d.halt[0]) return;
     int64_t total = 0;
     for (int r = 0; r < d.R; ++r) total += d.nleave_prev[r];
-    uint64_t *list = d.spawn_list[buf];
-    for (int64_t c0 = (int64_t)blockIdx.x * NK_WG; c0 < total; c0 += (int64_t)gridDim.x * NK_WG) {
-        const int64_t c = c0 + tid;
-        uint64_t rec = 0;
-        int mine = 0;
-        if (c < total) {
-            int r = 0;
-            int64_t i = c;
-            while (r < d.R - 1 && i >= d.nleave_prev[r]) { i -= d.nleave_prev[r]; ++r; }
-            if (((uint32_t)((uint64_t)i + step) % (uint32_t)d.nranks) == (uint32_t)d.rank) {
-                const uint64_t pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | (uint64_t)i;
-                double um, u1;
-                nk_uniform2_dev(d.seed, pid, step, NK_TAG_DICE, um, u1);
-                int m = nk_ss_left(d.res_roulette + (int64_t)r * d.M, d.M, um);
-                m = m > d.M - 1 ? d.M - 1 : m;
-                if (i < (1ll << 24)) { rec = ((uint64_t)i << 40) | ((uint64_t)((int64_t)r * d.M + m) << 12); mine = 1; }
-                else atomicOr(d.overflow, 16);      // one_to_one index beyond 2^24
-            }
-        }
-        int incl = mine;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        if (tid == 0) {
-            int t = 0;
-            for (int w = 0; w < NK_WG / 64; ++w) t += wsum[w];
-            bbase = t > 0 ? atomicAdd(d.alloc_count + buf, t) : 0;
-        }
-        __syncthreads();
-        int base = bbase;
-        for (int w = 0; w < wave; ++w) base += wsum[w];
-        const int64_t g = (int64_t)base + incl - mine;
-        if (mine) { if (g < d.spawn_cap) list[g] = rec; else atomicOr(d.overflow, 8); }
-        __syncthreads();
+    for (int64_t c = (int64_t)blockIdx.x * NK_WG + threadIdx.x; c < total; c += (int64_t)gridDim.x * NK_WG) {
+        int r = 0;
+        int64_t i = c;
+        while (r < d.R - 1 && i >= d.nleave_prev[r]) { i -= d.nleave_prev[r]; ++r; }
+        if (((uint32_t)((uint64_t)i + step) % (uint32_t)d.nranks) != (uint32_t)d.rank) continue;
+        const uint64_t pid = ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | (uint64_t)i;
+        double um, u1;
+        nk_uniform2_dev(d.seed, pid, step, NK_TAG_DICE, um, u1);
+        int m = nk_ss_left(d.res_roulette + (int64_t)r * d.M, d.M, um);
+        m = m > d.M - 1 ? d.M - 1 : m;
+        if (i >= (1ll << 24)) { atomicOr(d.overflow, 16); continue; }          // one_to_one index beyond 2^24
+        const int seg = m % d.nseg;
+        const int at = atomicAdd(d.sp_inbox_n + seg, 1);
+        if (at < d.sp_icap) d.sp_inbox[(int64_t)seg * d.sp_icap + at] = ((uint64_t)i << 40) | ((uint64_t)((int64_t)r * d.M + m) << 12);
+        else atomicOr(d.overflow, 8);                                           // inbox full
     }
 }
 
-// Stand-alone emission pass: primes the first step after (re)configuration, and serves every step when the
-// (reservoir, mode) table is too large for the sweep's tail.
-__global__ __launch_bounds__(NK_WG) void k_emit_count(NkDev d, uint32_t step) {
-    __shared__ int wsum[NK_WG / 64];
-    __shared__ int bbase;
-    const int64_t RM = (int64_t)d.R * d.M;
-    const int64_t e0 = (int64_t)blockIdx.x * NK_WG;
-    nk_emit_block<1>(d, step, (int)(step & 1u), e0, e0 + NK_WG < RM ? e0 + NK_WG : RM, wsum, &bbase);
+// ---- cross-lane moves of a parked particle (the carry)
+__device__ __forceinline__ double nk_pull_d(int src, double v) {      // every lane reads lane `src`
+    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ double nk_push_d(int dst, double v) {      // every lane writes lane `dst` (a permutation)
+    const int lo = __builtin_amdgcn_ds_permute(dst << 2, __double2loint(v));
+    const int hi = __builtin_amdgcn_ds_permute(dst << 2, __double2hiint(v));
+    return __hiloint2double(hi, lo);
+}
+template <bool PID>
+struct NkCarry {
+    double x, y, z, occ, nts, cts;     // cts: fraction of the step already consumed by earlier events
+    uint32_t w0, evc;                  // evc: events so far in this step (numbers the RNG draws)
+    unsigned long long pid;
+    __device__ __forceinline__ NkCarry pull(int src) const {
+        NkCarry o;
+        o.x = nk_pull_d(src, x); o.y = nk_pull_d(src, y); o.z = nk_pull_d(src, z); o.occ = nk_pull_d(src, occ);
+        o.nts = nk_pull_d(src, nts); o.cts = nk_pull_d(src, cts);
+        o.w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)w0);
+        o.evc = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)evc);
+        o.pid = 0;
+        if (PID) o.pid = (unsigned long long)__double_as_longlong(nk_pull_d(src, __longlong_as_double((long long)pid)));
+        return o;
+    }
+    __device__ __forceinline__ NkCarry push(int dst) const {
+        NkCarry o;
+        o.x = nk_push_d(dst, x); o.y = nk_push_d(dst, y); o.z = nk_push_d(dst, z); o.occ = nk_push_d(dst, occ);
+        o.nts = nk_push_d(dst, nts); o.cts = nk_push_d(dst, cts);
+        o.w0 = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)w0);
+        o.evc = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)evc);
+        o.pid = 0;
+        if (PID) o.pid = (unsigned long long)__double_as_longlong(nk_push_d(dst, __longlong_as_double((long long)pid)));
+        return o;
+    }
+};
 
-// The sweep: persistent WAVES, each taking segments w, w + n_waves, ...  A wave owns its segment and its slice of the
-// LDS event buffer, so the loop needs no workgroup barrier: the four waves of a workgroup only share the read-only
-// tables and the tally bins (LDS atomics).
-// Per segment one loop over 64-particle tiles: first the particles already there (phase A), then this segment's share
-// of the entering particles (phase B), then one empty tile that flushes the event buffer.  Every tile ends at the same
-// commit site: final particles are tallied and stored compacted at the write cursor, particles that meet a boundary
-// inside the step are parked in LDS, and whenever 64 are parked the whole wave processes them.
+// The sweep: persistent WAVES, each taking segments w, w + n_waves, ...  A wave owns its segment, so the loop needs no
+// workgroup barrier: the four waves of a workgroup only share the read-only tables and the tally bins (LDS atomics).
+// Per segment ONE loop over 64-particle tiles: first the particles already there (phase A), then the particles entering
+// through the reservoirs in the segment's own modes (phase B: the wave evaluates its (reservoir, mode) entries 128 at a
+// time), then one empty tile that drains the carry.  Every tile ends at the same commit site: final particles are
+// tallied and stored compacted at the write cursor, particles that meet a boundary inside the step join the carry, and
+// whenever the carry holds 64 the whole wave runs one boundary event for each.
 #define NK_TILE 64
-#define NK_MIN_FREE 128         // segments with fewer free slots take no entering particles this step ...
-#define NK_QUANT_SEGCAP 512     // ... when segments are at least this large (tiny test populations deal exactly)
 #ifndef NK_SWEEP_OCC
 #define NK_SWEEP_OCC 3          // workgroups per CU the sweep is compiled for (3 x 4 waves = 3 waves per SIMD)
 #endif
-// Developer ablation build (make ablate -> libnanokappa_hip_ablate.so, env NK_DEBUG = mask): skip one part of the sweep
-// to see what bounds it.  1 no particle stores, 2 no tally, 4 no relaxation, 8 no boundary events, 16 no entering
-// particles, 32 no ray casting after an event, 64 no reservoir tally, 128 no tally of event particles.
-// The production library compiles NK_ABL(b) to false.
-#ifdef NK_ABLATE
-#define NK_ABL(b) ((d.dbg & (b)) != 0)
-#else
-#define NK_ABL(b) false
-#endif
-#define NK_WAVE_EVCAP (NK_EVCAP / (NK_WG / 64))     // 128 parked particles per wave (< 64 pending + 64 new)
-template <int GEOM, bool ROUGH, bool RBF>
+template <int GEOM, bool ROUGH, bool RBF, bool PID>
 __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
     NkLds L;
     nk_lds_setup<GEOM, true>(d, smem, L);
-    const bool do_flux = (flags & 1) != 0;          // flags: 1 = heat-flux step, 2 = emit the next step's particles
-    const int buf = (int)(step & 1u);
-    __shared__ int emit_wsum[NK_WG / 64];
-    __shared__ int emit_base;
+    const bool do_flux = (flags & 1) != 0;          // flags: 1 = heat-flux step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rep = lane & (NK_NREP - 1);
     const unsigned long long lower = (1ull << lane) - 1ull;
-    const int eb = wave * NK_WAVE_EVCAP;                    // this wave's slice of the event buffer
-    int64_t total = d.R > 0 ? (int64_t)d.alloc_count[buf] : 0;
-    if (total > d.spawn_cap) total = d.spawn_cap;
-    const int64_t total_free = d.seg_free_prefix[d.nseg];
-    if (total > total_free) { total = total_free; if (tid == 0) atomicOr(d.overflow, 1); }
-    if (NK_ABL(16)) total = 0;
-    if (NK_ABL(4)) do_relax = 0;
-    if (tid == 0 && blockIdx.x == 0) L.bins.misc[0] = (unsigned int)total;          // "emitted" column
+    const uint32_t lbmask = (1u << d.lb) - 1u;
+    unsigned int *sp_pref = L.sp_pref + wave * NK_EMIT_CHUNK, *sp_cnt = L.sp_cnt + wave * NK_EMIT_CHUNK,
+                 *sp_rm = L.sp_rm + wave * NK_EMIT_CHUNK;
+    double *sp_cv = L.sp_cv + wave * NK_EMIT_CHUNK;
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
-        // entering particles are dealt in proportion to the segment's free space (snapshot of the previous step):
-        // self-balancing, and the share always fits
-        int64_t g0 = total_free > 0 ? total * d.seg_free_prefix[seg] / total_free : 0;
-        int64_t g1 = total_free > 0 ? total * d.seg_free_prefix[seg + 1] / total_free : 0;
-        // whole tiles: share boundaries rounded UP to multiples of 64 and clipped at the total (a 9-lane tile costs as
-        // much as a full one).  A share grows by at most 63, and a segment whose exact share is empty stays empty -- in
-        // particular the excluded ones: the prefix only counts segments with >= NK_MIN_FREE free slots, so the grown
-        // share still fits whenever the entering particles fill at most half of that space.
-        if (d.segcap >= NK_QUANT_SEGCAP && total * 2 <= total_free && !NK_ABL(256)) {
-            g0 = (g0 + 63) & ~(int64_t)63; g0 = g0 < total ? g0 : total;
-            g1 = (g1 + 63) & ~(int64_t)63; g1 = g1 < total ? g1 : total;
+        const NkSegModes sm = nk_seg_modes(d, seg);
+        const int nA = (count + NK_TILE - 1) / NK_TILE;
+        // entering particles: 'constant' / 'fixed_rate' from this segment's own (reservoir, mode) entries, evaluated in
+        // chunks; 'one_to_one' from the segment's inbox
+        const int nent = (d.R > 0 && d.res_gen != 2) ? d.R * sm.nl : 0;
+        int e0 = 0;                                   // next entry chunk
+        int spn = 0, spj = 0;                         // entering particles of the current chunk, next one to build
+        int sp_bound = 0;                             // upper bound of the particles that can enter this segment in one step
+        if (d.R > 0 && d.res_gen == 2) {
+            spn = d.sp_inbox_n[seg];
+            spn = spn < d.sp_icap ? spn : d.sp_icap;
+            sp_bound = lane == 0 ? 2 * spn + 64 : 0;
+            if (lane == 0 && spn > 0) atomicAdd(&L.bins.misc[0], (unsigned int)spn);          // "emitted" column
         }
-        const int nA = (count + NK_TILE - 1) / NK_TILE, nB = (int)((g1 - g0 + NK_TILE - 1) / NK_TILE);
-        int w = 0, ev_n = 0;
+        int w = 0;                                    // write cursor
+        int cn = 0;                                   // particles in the carry (lanes [0, cn))
+        NkCarry<PID> C;
+        C.x = C.y = C.z = C.occ = C.nts = C.cts = 0.0; C.w0 = 0u; C.evc = 0u; C.pid = 0ull;
         // next tile of phase A is requested before the current tile's arithmetic (the loop is latency-bound otherwise)
-        int modeN = 0, facetN = 0;
+        uint32_t w0N = 0u;
         double xN = 0, yN = 0, zN = 0, occN = 0, ntsN = 0;
         unsigned long long pidN = 0;
         if (lane < count) {
             const int64_t i = base + lane;
-            modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
-            facetN = d.facet[i]; pidN = d.pid[i];
+            w0N = d.w0[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
+            if (PID) pidN = d.pid[i];
         }
-        for (int t = 0; t <= nA + nB; ++t) {
+        int t = 0;
+        bool flush = false;
+        for (;;) {
             bool act = false;
-            double x = 0, y = 0, z = 0, occ = 0, nts = 0, omega = 0, vx = 0, vy = 0, vz = 0;
-            int mode = 0, facet = -1;
+            double x = 0, y = 0, z = 0, occ = 0, nts = 0, omega = 0, E0 = 0, vx = 0, vy = 0, vz = 0;
+            uint32_t w0 = 0u;
             unsigned long long pid = 0;
             if (t < nA) {
                 // ---- phase A: relax (deferred from the previous step), drift
                 const int r = t * NK_TILE;
+                ++t;
                 act = r + lane < count;
-                mode = modeN; facet = facetN; x = xN; y = yN; z = zN; occ = occN; nts = ntsN; pid = pidN;
-                const double4 *mrec = reinterpret_cast<const double4 *>(d.modetab + (act ? mode : 0));
-                const double4 ra = mrec[0], rb = mrec[1];                            // {omega, v} {tau rows}
+                w0 = w0N; x = xN; y = yN; z = zN; occ = occN; nts = ntsN; pid = pidN;
+                const int idx = act ? (int)(w0 & lbmask) : 0;
+                const double4 *mrec = reinterpret_cast<const double4 *>(sm.rec + idx);
+                const double4 ra = mrec[0], rb = mrec[1];                            // {omega, v} {E0, tau rows}
                 if (r + NK_TILE + lane < count) {
                     const int64_t i = base + r + NK_TILE + lane;
-                    modeN = d.mode[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
-                    facetN = d.facet[i]; pidN = d.pid[i];
+                    w0N = d.w0[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
+                    if (PID) pidN = d.pid[i];
                 }
-                omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w;
+                omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w; E0 = rb.x;
                 if (act) {
-                    if (do_relax) occ = nk_relax<RBF>(d, L, ra, rb, x, y, z, occ, mode);
+                    if (do_relax) occ = nk_relax<RBF>(d, L, ra, rb, x, y, z, occ, idx * sm.mstride + sm.moff);
                     x += vx * d.dt; y += vy * d.dt; z += vz * d.dt;                 // drift, Population.py:793
                     nts -= 1.0;                                                     // :795
                 }
-            } else if (t < nA + nB) {
+            } else if (spj < spn) {
                 // ---- phase B: an entering particle (Mesh.sample_surface, Mesh.py:923-951; entry times
                 // Population.py:391-394 / :440-443; add_reservoir_particles :525-552)
-                const int64_t g = g0 + (int64_t)(t - nA) * NK_TILE + lane;
-                act = g < g1;
+                const int j = spj + lane;
+                spj += NK_TILE;
+                act = j < spn;
                 if (act) {
-                    const uint64_t recd = d.spawn_list[buf][g];
-                    const int64_t rm = (int64_t)((recd >> 12) & 0xFFFFFFFull);
-                    const int level = (int)(recd & 0xFFFu);      // 0: 'one_to_one' record (index in bits 40..63)
+                    int64_t rm;
+                    int level;
+                    double prob = 0.0, cval = 0.0;
+                    uint64_t o2o = 0;
+                    if (d.res_gen == 2) {
+                        const uint64_t recd = d.sp_inbox[(int64_t)seg * d.sp_icap + j];
+                        rm = (int64_t)((recd >> 12) & 0xFFFFFFFull);
+                        level = 0;                              // 'one_to_one': entry time uniform in the step
+                        o2o = recd >> 40;
+                    } else {
+                        // the entry this particle belongs to: the last one whose exclusive prefix is <= j
+                        int lo = 0, hi = NK_EMIT_CHUNK;
+                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)sp_pref[mid] <= j) lo = mid; else hi = mid; }
+                        const int q = j - (int)sp_pref[lo], c = (int)sp_cnt[lo];
+                        rm = (int64_t)sp_rm[lo];
+                        cval = sp_cv[lo];
+                        prob = d.enter_prob[rm];
+                        // the q-th level this rank owns, counted down from c (nk_emit_entry's order)
+                        if (d.nranks == 1) level = c - q;
+                        else {
+                            const uint32_t n = (uint32_t)d.nranks;
+                            const uint32_t tq = ((uint32_t)d.rank + n - (((uint32_t)rm + step) % n)) % n;   // owned levels = tq mod n
+                            const uint32_t top = (uint32_t)c - (((uint32_t)c + n - tq) % n);                // largest owned level <= c
+                            level = (int)(top - (uint32_t)q * n);
+                        }
+                    }
                     const int r = (int)(rm / d.M);
-                    mode = (int)(rm - (int64_t)r * d.M);
-                    // everything that hangs off the record is requested at once; the Philox rounds cover the latency
-                    const double prob = d.enter_prob[rm];
-                    const double cval = d.res_cval[buf][rm];
-                    const double4 ra = *reinterpret_cast<const double4 *>(d.modetab + mode);
+                    const int mode = (int)(rm - (int64_t)r * d.M);
+                    const int idx = d.part ? mode / d.nseg : mode;
+                    const double4 *mrec = reinterpret_cast<const double4 *>(sm.rec + idx);
+                    const double4 ra = mrec[0];
+                    E0 = sm.rec[idx].E0;
                     pid = level > 0 ? ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level
-                                    : ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | (recd >> 40);
+                                    : ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | o2o;
                     double uf, us, ur, ut;
                     nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
                     nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
@@ -453,8 +440,9 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     if (GEOM == 1 && d.res_lds) nk_sample_res_face(L.rf_off, L.rf_cdf, L.rf_verts, r, uf, us, ur, x0, y0, z0);
                     else nk_sample_res_face(d.res_face_off, d.res_face_cdf, d.res_face_verts, r, uf, us, ur, x0, y0, z0);
                     omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w;
-                    occ = nk_occupation(d, L.resT[r], omega);                        // Population.py:506
+                    occ = nk_be(omega * d.c_hk, E0, L.resT[2 * r + 1], d.invT0);                 // Population.py:506
                     double tc;
+                    int facet;
                     int skip = NK_TREE_NO_SKIP;               // the particle starts on its reservoir's facet
                     if (GEOM == 2 && d.NG > 0) {
                         const int rf = d.res_facet[r];
@@ -464,88 +452,120 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
                     nts = tc / d.dt - dt_in / d.dt;                                  // :535
                     x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;   // :536
+                    w0 = ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx;
                 }
-            }
-            // ---- commit: boundary particles -> LDS buffer; final particles -> tally + compacted store
-            const bool ev = act && nts < 0.0 && !NK_ABL(8);
+            } else if (e0 < nent) {
+                // ---- the next chunk of this segment's (reservoir, mode) entries: entry e = r * nl + l, two per lane
+                unsigned int inc[2];
+                int cm[2];
+                unsigned int run = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = e0 + k * 64 + lane;
+                    int c = 0, cmine = 0;
+                    double cv = 0.0;
+                    unsigned int rm32 = 0;
+                    if (e < nent) {
+                        const int r = e / sm.nl, l = e - r * sm.nl;
+                        const int64_t rm = (int64_t)r * d.M + ((int64_t)l * d.nseg + seg);
+                        const double prob = d.enter_prob[rm];
+                        nk_emit_entry(d, step, rm, prob, c, cmine, cv);
+                        rm32 = (unsigned int)rm;
+                        sp_bound += ((int)floor(prob) + 1 + d.nranks - 1) / d.nranks;
+                    }
+                    unsigned int v = (unsigned int)cmine;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+                    inc[k] = v + run;
+                    cm[k] = cmine;
+                    run += __shfl(v, 63, 64);
+                    sp_cnt[k * 64 + lane] = (unsigned int)c;
+                    sp_rm[k * 64 + lane] = rm32;
+                    sp_cv[k * 64 + lane] = cv;
+                    sp_pref[k * 64 + lane] = inc[k] - (unsigned int)cm[k];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // LDS is in order per wave; keep the compiler honest
+                e0 += NK_EMIT_CHUNK;
+                spn = (int)run;
+                spj = 0;
+                if (lane == 0 && spn > 0) atomicAdd(&L.bins.misc[0], (unsigned int)spn);      // "emitted" column
+                continue;
+            } else if (!flush) {
+                flush = true;                        // one empty tile: drains the carry
+            } else break;
+            // ---- commit: final particles -> tally + compacted store; boundary particles -> the carry
+            const bool ev = act && nts < 0.0;
             const bool done = act && !ev;
             const unsigned long long mD = __ballot(done), mE = __ballot(ev);
-            if (ev) {
-                const int e = eb + ev_n + __popcll(mE & lower);
-                L.ev.x[e] = x; L.ev.y[e] = y; L.ev.z[e] = z; L.ev.occ[e] = occ; L.ev.nts[e] = nts;
-                L.ev.mode[e] = mode; L.ev.facet[e] = facet; L.ev.pid[e] = pid;
-                L.ev.cts[e] = 0.0; L.ev.evc[e] = 0;
-            }
-            ev_n += __popcll(mE);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // LDS is in-order per wave; keep the compiler honest
-            // whenever a full batch is parked (everything on the last, empty tile) the whole wave runs the boundary
-            // event loop below; the batch's mode records are requested now, under the tally and the stores
-            const int keep = (t == nA + nB) ? 0 : NK_TILE - 1;
-            double4 pre = make_double4(0, 0, 0, 0);
-            if (ev_n > keep) {
-                const int n = ev_n >= NK_TILE ? NK_TILE : ev_n;
-                if (lane < n) pre = *reinterpret_cast<const double4 *>(d.modetab + L.ev.mode[eb + ev_n - n + lane]);
-            }
-            if (done && !NK_ABL(2)) nk_tally_one(d, L.cen, L.Tsv, L.bins, x, y, z, occ, omega, vx, vy, vz, do_flux, rep);
+            if (done) nk_tally_one(d, L.tb, L.bins, x, y, z, occ, omega, E0, vx, vy, vz, do_flux, rep);
             if (done) {
                 const int o = w + __popcll(mD & lower);
-                if (o < d.segcap) { if (!NK_ABL(1)) nk_store(d, base + o, x, y, z, occ, nts, mode, facet, pid); }
-                else atomicOr(d.overflow, 2);       // segment full at the commit of a tile
+                if (o < d.segcap) {
+                    const int64_t i = base + o;
+                    d.x[i] = x; d.y[i] = y; d.z[i] = z; d.occ[i] = occ; d.nts[i] = nts; d.w0[i] = w0;
+                    if (PID) d.pid[i] = pid;
+                } else atomicOr(d.overflow, 2);     // segment full at the commit of a tile
             }
             w += __popcll(mD);
-            // ---- drain (Population.py:1546-1683): one boundary event per particle and pass; finished particles are
-            // tallied and appended, absorbed ones vanish, the few that meet another wall go back to the buffer
-            bool first = true;
-            while (ev_n > keep) {
-                const int n = ev_n >= NK_TILE ? NK_TILE : ev_n;
-                const int e = eb + ev_n - n + lane;
-                const bool eact = lane < n;
-                NkParticle p;
-                unsigned long long ppid = 0;
-                double cts = 0.0;
-                uint32_t evc = 0;
-                int st = NK_EV_DEAD;
-                p.alive = false;
-                if (eact) {
-                    p.x = L.ev.x[e]; p.y = L.ev.y[e]; p.z = L.ev.z[e]; p.occ = L.ev.occ[e]; p.nts = L.ev.nts[e];
-                    p.mode = L.ev.mode[e]; p.facet = L.ev.facet[e]; ppid = L.ev.pid[e];
-                    cts = L.ev.cts[e]; evc = (uint32_t)L.ev.evc[e];
-                    const double4 ra = first ? pre : *reinterpret_cast<const double4 *>(d.modetab + p.mode);
-                    p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
-                    p.alive = true;
-                    st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.cen, L.Tsv, L.resT, L.bins, p, cts, evc, ppid, step);
+            // the tile's event particles, packed into lanes [po, po + pn) of P
+            int pn = __popcll(mE), po = 0;
+            NkCarry<PID> P;
+            P.x = x; P.y = y; P.z = z; P.occ = occ; P.nts = nts; P.cts = 0.0; P.w0 = w0; P.evc = 0u; P.pid = pid;
+            if (pn > 0) P = P.push(ev ? __popcll(mE & lower) : pn + __popcll(~mE & lower));
+            // ---- drain (Population.py:1546-1683): fill the carry; whenever it is full (or on the last, empty tile) one
+            // boundary event per particle; finished particles are tallied and appended, absorbed ones vanish, the few that
+            // meet another wall stay
+            while (pn > 0 || (flush && cn > 0)) {
+                if (pn > 0) {
+                    const int k = pn < 64 - cn ? pn : 64 - cn;
+                    const NkCarry<PID> Q = P.pull((po + lane - cn) & 63);
+                    if (lane >= cn && lane < cn + k) C = Q;
+                    cn += k; po += k; pn -= k;
                 }
-                first = false;
+                if (cn < 64 && !(flush && pn == 0)) break;
+                const bool eact = lane < cn;
+                NkParticle p;
+                double cts = C.cts;
+                uint32_t evc = C.evc;
+                int st = NK_EV_DEAD;
+                p.x = C.x; p.y = C.y; p.z = C.z; p.occ = C.occ; p.nts = C.nts;
+                const int idx0 = eact ? (int)(C.w0 & lbmask) : 0;
+                {
+                    const double4 ra = *reinterpret_cast<const double4 *>(sm.rec + idx0);
+                    p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                    p.E0 = sm.rec[idx0].E0;
+                }
+                p.mode = idx0 * sm.mstride + sm.moff;
+                p.facet = (int)(C.w0 >> d.lb) - 1;
+                if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, C.pid, step);
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
-                if (alive && !NK_ABL(2) && !NK_ABL(128)) nk_tally_one(d, L.cen, L.Tsv, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.vx, p.vy, p.vz, do_flux, rep);
+                if (alive) nk_tally_one(d, L.tb, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.E0, p.vx, p.vy, p.vz, do_flux, rep);
+                const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | (uint32_t)(ROUGH ? (d.part ? p.mode / d.nseg : p.mode) : idx0);
                 const unsigned long long mA = __ballot(alive), mM = __ballot(more);
                 if (alive) {
                     const int o = w + __popcll(mA & lower);
-                    if (o < d.segcap) { if (!NK_ABL(1)) nk_store(d, base + o, p.x, p.y, p.z, p.occ, p.nts, p.mode, p.facet, ppid); }
-                    else atomicOr(d.overflow, 4);   // segment full while appending event survivors
+                    if (o < d.segcap) {
+                        const int64_t i = base + o;
+                        d.x[i] = p.x; d.y[i] = p.y; d.z[i] = p.z; d.occ[i] = p.occ; d.nts[i] = p.nts; d.w0[i] = w0e;
+                        if (PID) d.pid[i] = C.pid;
+                    } else atomicOr(d.overflow, 4);   // segment full while appending event survivors
                 }
                 w += __popcll(mA);
-                ev_n -= n;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // all lanes have read their entries
-                if (more) {
-                    const int q = eb + ev_n + __popcll(mM & lower);
-                    L.ev.x[q] = p.x; L.ev.y[q] = p.y; L.ev.z[q] = p.z; L.ev.occ[q] = p.occ; L.ev.nts[q] = p.nts;
-                    L.ev.mode[q] = p.mode; L.ev.facet[q] = p.facet; L.ev.pid[q] = ppid;
-                    L.ev.cts[q] = cts; L.ev.evc[q] = (int)evc;
+                cn = __popcll(mM);
+                if (cn > 0) {
+                    C.x = p.x; C.y = p.y; C.z = p.z; C.occ = p.occ; C.nts = p.nts; C.cts = cts; C.w0 = w0e; C.evc = evc;
+                    C = C.push(more ? __popcll(mM & lower) : cn + __popcll(~mM & lower));
                 }
-                ev_n += __popcll(mM);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             }
         }
-        if (lane == 0 && !NK_ABL(1)) d.seg_count[seg] = w < d.segcap ? w : d.segcap;
-    }
-    // tail: this workgroup's slice of the (reservoir, mode) table for the NEXT step (fill_reservoirs does not look at
-    // the particles), into the other spawn buffer -- no separate launch, and it fills the sweep's ragged end
-    if (flags & 2) {
-        const int64_t RM = (int64_t)d.R * d.M;
-        const int64_t per = (RM + gridDim.x - 1) / gridDim.x;
-        const int64_t e0 = (int64_t)blockIdx.x * per;
-        nk_emit_block<NK_EMIT_KMAX>(d, step + 1u, buf ^ 1, e0 < RM ? e0 : RM, e0 + per < RM ? e0 + per : RM, emit_wsum, &emit_base);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sp_bound += __shfl_xor(sp_bound, o, 64);   // per-lane partial sums of the entries
+        if (lane == 0) {
+            d.seg_count[seg] = w < d.segcap ? w : d.segcap;
+            if (d.R > 0 && d.res_gen == 2) d.sp_inbox_n[seg] = 0;
+            // could the next step overflow this segment?  then nothing after this step runs until the host has grown the store
+            if ((int64_t)w + sp_bound + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+        }
     }
     nk_lds_flush(d, L, blockIdx.x);
 }
@@ -558,31 +578,24 @@ __global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkDev n) {
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
             n.x[b + i] = o.x[a + i]; n.y[b + i] = o.y[a + i]; n.z[b + i] = o.z[a + i];
             n.occ[b + i] = o.occ[a + i]; n.nts[b + i] = o.nts[a + i];
-            n.mode[b + i] = o.mode[a + i]; n.facet[b + i] = o.facet[a + i]; n.pid[b + i] = o.pid[a + i];
+            n.w0[b + i] = o.w0[a + i];
+            if (o.pid && n.pid) n.pid[b + i] = o.pid[a + i];
         }
+        if (threadIdx.x == 0) n.seg_count[seg] = cnt;
     }
 }
 
 // Normalise, invert E(T), publish the new subvolume temperatures, history row: calculate_energy (Population.py:719-728)
 // + refresh_temperatures (:692), run by ONE workgroup.
-// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, 0, 0, overflow
-__device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc, double *hist_row, int do_flux, int buf,
-                                               long long *part) {
-    // One workgroup, so everything here is a chain of memory latencies: all first-round loads are issued together, the
-    // E(T) / T(E) tables are read as one 4-point window around the old temperature (T moves by a small fraction of
-    // the 0.1 K table step per timestep; the general search is the fallback), and the segment counts stay in registers.
+// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, row_valid, halt, overflow
+// acc[NB] (summed over the ranks like the tallies) > 0: some segment could overflow at the next step -> raise the halt word,
+// on every rank at the same step.
+__device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc, double *hist_row, int do_flux) {
+    // One workgroup, so everything here is a chain of memory latencies: the E(T) / T(E) tables are read as one 4-point
+    // window around the old temperature (T moves by a small fraction of the 0.1 K table step per timestep; the general
+    // search is the fallback).
     const int tid = threadIdx.x, nth = blockDim.x;
     const int S = d.S, NB = d.NB, n = d.nE;
-    constexpr int KMAX = NK_MAX_SEGMENTS / NK_WG;              // segments per thread of the update workgroup
-    const int lane = tid & 63, wave = tid >> 6, nw = (nth + 63) >> 6;
-    const int per = (d.nseg + nth - 1) / nth;                  // <= KMAX contiguous segments per thread
-    int fr[KMAX];
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {                           // all loads in flight at once
-        const int sgm = tid * per + k;
-        const int fs = (k < per && sgm < d.nseg) ? d.segcap - d.seg_count[sgm] : 0;
-        fr[k] = (d.segcap < NK_QUANT_SEGCAP || fs >= NK_MIN_FREE) ? fs : 0;
-    }
     const double Ta = d.Tarr[0], Tb = d.Tarr[1], Tz = d.Tarr[n - 1], Ea = d.Earr[0], Ez = d.Earr[n - 1];
     for (int t = tid; t < S; t += nth) {
         const double Eraw = acc[t], Ns = acc[S + t];
@@ -621,7 +634,7 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
         } else { int io; Tnew = nk_interp_lin_hint(d.Earr, d.Tarr, n, E, it, io); }
         hist_row[NB + t] = Tnew;
         hist_row[NB + S + t] = E;
-        if (!NK_ABL(2)) d.T_sv[t] = Tnew;
+        d.T_sv[t] = Tnew;
     }
     for (int b = tid; b < NB; b += nth) hist_row[b] = acc[b];
     if (d.sv_interp == 3) {                          // RBF coefficients of the new temperatures: [w; p] = inv[:, :S] @ T_sv
@@ -633,43 +646,25 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
             d.T_sv[S + j] = a;
         }
     }
-    // free-space prefix over the segments for the next step's spawn distribution: thread t owns the contiguous
-    // segments [t*per, (t+1)*per); one workgroup scan of the per-thread sums
-    long long mine = 0;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) mine += fr[k];
-    long long incl = mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) { long long v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    if (lane == 63) part[wave] = incl;
-    __syncthreads();
-    long long wbase = 0, run = 0;
-    for (int w = 0; w < nw; ++w) { const long long v = part[w]; if (w < wave) wbase += v; run += v; }
-    long long pre = wbase + incl - mine;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-        const int sgm = tid * per + k;
-        if (k < per && sgm < d.nseg) d.seg_free_prefix[sgm] = pre;
-        pre += fr[k];
-    }
     if (d.res_gen == 2) for (int r = tid; r < d.R; r += nth) d.nleave_prev[r] = (int32_t)acc[5 * S + r];
     if (tid == 0) {
-        d.seg_free_prefix[d.nseg] = run;
-        d.alloc_count[buf] = 0;                      // consumed by this step's sweep; refilled two steps on
         hist_row[NB + 2 * S + 0] = (double)do_flux;
-        hist_row[NB + 2 * S + 1] = 0.0;
-        hist_row[NB + 2 * S + 2] = 0.0;
+        hist_row[NB + 2 * S + 1] = 1.0;              // this step ran
+        const bool hreq = acc[NB] > 0.0;
+        hist_row[NB + 2 * S + 2] = hreq ? 1.0 : 0.0;
         hist_row[NB + 2 * S + 3] = (double)*d.overflow;
+        if (hreq) d.halt[0] = 1;
     }
 }
 
 // Column sums of the tally rows, fixed order -> bitwise reproducible for a given grid.  One workgroup per column.
 // fuse != 0 (single rank): the workgroup that finishes last also runs the update, saving a launch.
-__global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc, double *hist_row, int do_flux, int buf,
-                                                  int fuse) {
+// Column NB is the halt request of this step's sweep (halt[1]); halt[0] is only raised by the update at the END of a step,
+// so every kernel of a step sees the same value.
+__global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc, double *hist_row, int do_flux, int fuse) {
     __shared__ double sh[NK_WG];
-    __shared__ long long part[NK_WG];
     __shared__ int last;
+    if (d.halt[0]) return;
     const int b = blockIdx.x, NB = d.NB;
     double v = 0.0;
     for (int r = threadIdx.x; r < rows; r += NK_WG) v += d.partials[(int64_t)r * NB + b];
@@ -680,6 +675,7 @@ __global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc
         __syncthreads();
     }
     if (threadIdx.x == 0) acc[b] = sh[0];
+    if (threadIdx.x == 0 && b == 0) acc[NB] = (double)d.halt[1];
     if (!fuse) return;
     if (threadIdx.x == 0) {
         __threadfence();
@@ -689,29 +685,32 @@ __global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc
     if (!last) return;
     if (threadIdx.x == 0) *d.ticket = 0;
     __threadfence();
-    nk_update_body(d, acc, hist_row, do_flux, buf, part);
+    nk_update_body(d, acc, hist_row, do_flux);
 }
 
 // The update as its own launch (after the RCCL all-reduce when nranks > 1).
-__global__ __launch_bounds__(NK_WG) void k_update(NkDev d, const double *acc, double *hist_row, int do_flux, int buf) {
-    __shared__ long long part[NK_WG];
-    nk_update_body(d, acc, hist_row, do_flux, buf, part);
+__global__ __launch_bounds__(NK_WG) void k_update(NkDev d, const double *acc, double *hist_row, int do_flux) {
+    if (d.halt[0]) return;
+    nk_update_body(d, acc, hist_row, do_flux);
 }
 
 // Stand-alone lifetime_scattering (flushes the deferred relaxation).
-__global__ __launch_bounds__(NK_WG) void k_relax(NkDev d) {
+__global__ __launch_bounds__(NK_WG) void k_relax(NkDev d, int honor_halt) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (honor_halt && d.halt[0]) return;
     NkLds L;
     nk_lds_setup<0, false>(d, smem, L);
+    const uint32_t lbmask = (1u << d.lb) - 1u;
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
+        const NkSegModes sm = nk_seg_modes(d, seg);
         for (int k = threadIdx.x; k < count; k += NK_WG) {
             const int64_t i = base + k;
-            const int mode = d.mode[i];
-            const double4 *mrec = reinterpret_cast<const double4 *>(d.modetab + mode);
+            const int idx = (int)(d.w0[i] & lbmask);
+            const double4 *mrec = reinterpret_cast<const double4 *>(sm.rec + idx);
             const double4 ra = mrec[0], rb = mrec[1];
-            d.occ[i] = nk_relax(d, L, ra, rb, d.x[i], d.y[i], d.z[i], d.occ[i], mode);
+            d.occ[i] = nk_relax(d, L, ra, rb, d.x[i], d.y[i], d.z[i], d.occ[i], idx * sm.mstride + sm.moff);
         }
     }
 }
@@ -722,36 +721,52 @@ __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
     nk_lds_setup<GEOM, false>(d, smem, L);
+    const uint32_t lbmask = (1u << d.lb) - 1u;
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
+        const NkSegModes sm = nk_seg_modes(d, seg);
         for (int k = threadIdx.x; k < count; k += NK_WG) {
             const int64_t i = base + k;
-            const NkMode *rec = d.modetab + d.mode[i];
+            const uint32_t idx = d.w0[i] & lbmask;
+            const NkMode *rec = sm.rec + idx;
             double tc; int fc;
             NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, d.x[i], d.y[i], d.z[i], rec->vx, rec->vy, rec->vz, tc, fc);
             d.nts[i] = tc / d.dt;
-            d.facet[i] = fc;
+            d.w0[i] = ((uint32_t)(fc + 1) << d.lb) | idx;
         }
     }
+}
+
+// Key of a particle's random draws when ids are not tracked: its mode and the bits of its position (DESIGN.md "RNG").
+__device__ __forceinline__ uint64_t nk_state_key(int mode, double x, double y, double z) {
+    uint64_t k = (uint64_t)(uint32_t)mode;
+    k = k * 0x9E3779B97F4A7C15ull + (uint64_t)__double_as_longlong(x);
+    k = k * 0x9E3779B97F4A7C15ull + (uint64_t)__double_as_longlong(y);
+    k = k * 0x9E3779B97F4A7C15ull + (uint64_t)__double_as_longlong(z);
+    return k;
 }
 
 // contains_check (Population.py:1712-1722) + Mesh.sample_volume (Mesh.py:890-904)
 template <int GEOM>
 __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (d.halt[0]) return;
     NkLds L;
     nk_lds_setup<GEOM, false>(d, smem, L);
+    const uint32_t lbmask = (1u << d.lb) - 1u;
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
+        const NkSegModes sm = nk_seg_modes(d, seg);
         for (int k = threadIdx.x; k < count; k += NK_WG) {
             const int64_t i = base + k;
             double x = d.x[i], y = d.y[i], z = d.z[i];
             bool out = x < d.bbox[0] - 1e-10 || y < d.bbox[1] - 1e-10 || z < d.bbox[2] - 1e-10 || x > d.bbox[3] + 1e-10 ||
                        y > d.bbox[4] + 1e-10 || z > d.bbox[5] + 1e-10;
             if (!out) continue;
-            const uint64_t pid = d.pid[i];
+            const uint32_t idx = d.w0[i] & lbmask;
+            const uint64_t pid = d.pid ? d.pid[i] : nk_state_key((int)idx * sm.mstride + sm.moff, x, y, z);
             double u[6];
             nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 0, u[0], u[1]);
             nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 1, u[2], u[3]);
@@ -763,26 +778,29 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
             const double *sp = d.simplex_pts + 12 * (int64_t)s;
             x = y = z = 0.0;
             for (int q = 0; q < 4; ++q) { double wq = a[q] / asum; x += wq * sp[3 * q]; y += wq * sp[3 * q + 1]; z += wq * sp[3 * q + 2]; }
-            const NkMode *rec = d.modetab + d.mode[i];
+            const NkMode *rec = sm.rec + idx;
             double tc; int fc;
             NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
-            d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = tc / d.dt; d.facet[i] = fc;
+            d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = tc / d.dt;
+            d.w0[i] = ((uint32_t)(fc + 1) << d.lb) | idx;
         }
     }
 }
 
-// {omega, v, tau[row0..row0+3]} records for one-gather-per-particle access
-__global__ void k_build_modetab(const double *omega, const double *vg, const double *tau, int M, int NT, int row0,
-                                NkMode *out) {
+// {omega, v, E0, tau[row0..row0+2]} records, by mode index and (part) in the segments' order
+__global__ void k_build_modetab(const double *omega, const double *vg, const double *tau, int M, int NT, int row0, double c_hk,
+                                double invT0, int nseg, int nlmax, NkMode *out, NkMode *out_p) {
     int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     NkMode r;
     r.omega = omega[m]; r.vx = vg[3 * m]; r.vy = vg[3 * m + 1]; r.vz = vg[3 * m + 2];
+    r.E0 = exp(r.omega * c_hk * invT0);
     for (int k = 0; k < NK_TAU_ROWS; ++k) {
         int row = row0 + k;
         r.tau[k] = (row >= 0 && row < NT) ? tau[(int64_t)row * M + m] : 0.0;
     }
     out[m] = r;
+    if (out_p) out_p[(int64_t)(m % nseg) * nlmax + m / nseg] = r;
 }
 
 // ---- parity taps: the reference's primitives evaluated on the device
@@ -800,30 +818,40 @@ __global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n,
     for (int k = 0; k < 3; ++k) xc[3 * i + k] = x[3 * i + k] + t * v[3 * i + k];
 }
 __global__ __launch_bounds__(NK_WG) void k_tap_classify(NkDev d, int64_t n, const double *x, int32_t *id) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    NkLds L;
+    nk_lds_setup<0, false>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
-    if (i < n) id[i] = nk_classify(d, d.centers, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
+    if (i < n) id[i] = nk_classify(d, L.tb, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
 }
 __global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, int what, int64_t n, const double *a, const int32_t *mode,
                                                     double *out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    NkLds L;
+    nk_lds_setup<0, false>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
     switch (what) {
-        case 0: out[i] = nk_occupation(d, a[i], d.modetab[mode[i]].omega); break;
-        case 1: { const NkMode *rec = d.modetab + mode[i]; out[i] = nk_lifetime(d, rec->tau[0], rec->tau[1], rec->tau[2], rec->tau[3], a[i], mode[i]); break; }
+        case 0: out[i] = nk_occupation(d, a[i], d.modetab[mode[i]].omega, d.modetab[mode[i]].E0); break;
+        case 1: { const NkMode *rec = d.modetab + mode[i]; out[i] = nk_lifetime(d, rec->tau[0], rec->tau[1], rec->tau[2], a[i], mode[i]); break; }
         case 2: out[i] = nk_T_of_E(d, a[i]); break;
         case 3: out[i] = nk_E_of_T(d, a[i]); break;
-        default: out[i] = nk_interp_T(d, d.centers, d.T_sv, a[3 * i], a[3 * i + 1], a[3 * i + 2], -1); break;
+        case 5: out[i] = nk_exp(a[i]); break;
+        default: { double invT; out[i] = nk_interp_T(d, L.tb, a[3 * i], a[3 * i + 1], a[3 * i + 2], invT); break; }
     }
 }
 __global__ __launch_bounds__(NK_WG) void k_tap_reflect(NkDev d, int64_t n, const int32_t *facet, const int32_t *mode_in,
                                                        const double *col, const double *n_in, const double *om_in,
                                                        const double *r_spec, const double *r_deg, const double *r_diff,
                                                        int32_t *mode_out, double *n_out, double *om_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    NkLds L;
+    nk_lds_setup<0, false>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
-    int mo; double no, oo;
-    nk_reflect(d, d.centers, d.T_sv, d.facets[facet[i]].rough, mode_in[i], col[3 * i], col[3 * i + 1], col[3 * i + 2],
-               n_in[i], om_in[i], r_spec[i], r_deg ? r_deg[i] : 0.0, r_diff[i], mo, no, oo);
+    int mo; double no, oo, eo;
+    nk_reflect(d, L.tb, d.facets[facet[i]].rough, mode_in[i], col[3 * i], col[3 * i + 1], col[3 * i + 2],
+               n_in[i], om_in[i], d.modetab[mode_in[i]].E0, r_spec[i], r_deg ? r_deg[i] : 0.0, r_diff[i], mo, no, oo, eo);
     mode_out[i] = mo; n_out[i] = no; om_out[i] = oo;
 }
 // Counter calibration: coalesced 8-byte-per-lane sweeps with a KNOWN byte count (44 B read + 32 B written per live
@@ -835,9 +863,9 @@ __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
         const int count = d.seg_count[seg];
         for (int k = threadIdx.x; k < count; k += NK_WG) {
             const int64_t i = base + k;
-            const int mode = d.mode[i];
+            const uint32_t w0 = d.w0[i];
             double x = d.x[i], y = d.y[i], z = d.z[i], occ = d.occ[i], nts = d.nts[i];
-            if (mode == -123456789) { x += occ; }                 // keeps the occ load alive; never true
+            if (w0 == 0xFFFFFFFEu) { x += occ; }                  // keeps the occ load alive; never true
             d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts;
         }
     }

@@ -58,7 +58,7 @@ class nk_rough(C.Structure):
 class nk_params(C.Structure):
     _fields_ = [('dt', C.c_double), ('norm_fixed', C.c_int32), ('particle_density', C.c_double),
                 ('T_ref_local', C.c_int32), ('T_ref', C.c_double), ('flux_every', C.c_int32),
-                ('contains_every', C.c_int32)]
+                ('contains_every', C.c_int32), ('track_ids', C.c_int32)]
 
 
 class nk_tally(C.Structure):
@@ -283,8 +283,12 @@ class Engine(object):
         r.degen_j2 = _p(dj, c_ip)
         self._ck(self.L.nk_set_rough(self.h, C.byref(r)), 'nk_set_rough')
 
-    def set_params(self, dt=1.0, norm_fixed=False, particle_density=0.0, T_ref=None, flux_every=10, contains_every=100):
+    def set_params(self, dt=1.0, norm_fixed=False, particle_density=0.0, T_ref=None, flux_every=10, contains_every=100,
+                   track_ids=False):
+        """track_ids: store 64-bit particle ids even when nothing draws random numbers per particle (then downloads
+        return them; otherwise pid comes back as zeros unless the mesh has rough facets)."""
         p = nk_params()
+        p.track_ids = int(bool(track_ids))
         p.dt, p.norm_fixed, p.particle_density = float(dt), int(bool(norm_fixed)), float(particle_density)
         p.T_ref_local = 1 if T_ref is None else 0
         p.T_ref = 0.0 if T_ref is None else float(T_ref)
@@ -398,7 +402,7 @@ class Engine(object):
         return out
 
     def eval(self, what, a, mode=None):
-        code = {'occupation': 0, 'lifetime': 1, 'T_of_E': 2, 'E_of_T': 3, 'interp_T': 4}[what]
+        code = {'occupation': 0, 'lifetime': 1, 'T_of_E': 2, 'E_of_T': 3, 'interp_T': 4, 'exp': 5}[what]
         a = _d(a)
         n = a.shape[0]
         m = None if mode is None else _i(mode)

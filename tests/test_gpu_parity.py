@@ -184,7 +184,7 @@ def test_frozen_step_vs_reference(variant):
     eng.set_subvolumes(gm['subvol_center'], gm['subvol_volume'], 0, int(gm['slice_axis']), interp, gs['pre_subvol_temperature'])
     eng.set_reservoirs(gm['res_facets'], gs['res_facet_temperature'], np.zeros((2, M)), np.zeros((2, M)))
     eng.set_params(dt=1.0, norm_fixed=(variant == 'fixed'), particle_density=float(gs['particle_density']),
-                   T_ref=(300.0 if variant == 'tref' else None), flux_every=1, contains_every=0)
+                   T_ref=(300.0 if variant == 'tref' else None), flux_every=1, contains_every=0, track_ids=True)
     eng.upload(gs['pre_positions'], gs['pre_modes'][:, 0] * J + gs['pre_modes'][:, 1], gs['pre_occupation'],
                gs['pre_n_timesteps'], gs['pre_collision_facets'])
     t = eng.step(1)
@@ -423,7 +423,7 @@ def test_specular_pairs_on_device_equal_host_builder():
     eng.close()
 
 
-@pytest.mark.parametrize('case,n,new_cap', [('ttrrp', 30000, 400000), ('ttp', 1100000, 3000000)])
+@pytest.mark.parametrize('case,n,new_cap', [('ttrrp', 30000, 400000), ('ttp', 1100000, 6000000)])
 def test_reserve_mid_run_preserves_state(case, n, new_cap):
     """nk_reserve between steps re-lays the particle store out -- through the host when the number of segments changes
     (new segment count, mode-sorted), on the device when it does not (1.1e6 particles: one segment per resident wave
@@ -490,7 +490,7 @@ def test_empty_start_fills_from_reservoirs():
     eng.set_mesh(ct['mesh'])
     eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], 1, np.full(ct['centers'].shape[0], 298.0))
     eng.set_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'], counter)
-    eng.set_params(dt=1.0, particle_density=ct['particle_density'])
+    eng.set_params(dt=1.0, particle_density=ct['particle_density'], track_ids=True)
     eng.reserve(200000)
     eng.upload(pos[:0], mode[:0], occ[:0])
     eng.init_boundaries()

@@ -134,7 +134,9 @@ def first_n_leaving(enter_prob):
 
 
 def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scale=1.0, flux_every=10,
-                contains_every=100, device=0, gen=0, pid_offset=0, comm=None):
+                contains_every=100, device=0, gen=0, pid_offset=0, comm=None, track_ids=True):
+    """track_ids=True: the engine keeps the 64-bit particle ids also where nothing draws random numbers per particle, so that
+    its particles can be matched with the oracle's one by one."""
     from nanokappa_amd.engine import Engine
     eng = Engine(device, seed)
     eng.set_material(ct['tables'])
@@ -148,7 +150,8 @@ def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scal
     if ct['rough'] is not None:
         r = ct['rough']
         eng.set_rough(r['facets'], r['specularity'], r['true_spec'], r['spec_map'], r['roulette'], degen_j2=r.get('degen_j2'))
-    eng.set_params(dt=1.0, particle_density=ct['particle_density'], flux_every=flux_every, contains_every=contains_every)
+    eng.set_params(dt=1.0, particle_density=ct['particle_density'], flux_every=flux_every, contains_every=contains_every,
+                   track_ids=track_ids)
     if comm is not None:                      # (unique id, rank, nranks), before the first step
         eng.comm_init(*comm)
     eng.upload(pos, mode, occ, pid_offset=pid_offset)
