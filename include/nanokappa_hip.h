@@ -152,7 +152,7 @@ typedef struct {
 /* Kernel timing of the last nk_step call, from HIP events on the library's stream. */
 typedef struct {
     double step_kernel_ms;   /* mean duration of k_sweep: relax + drift + boundary events + emission + tally */
-    double emit_kernel_ms;   /* mean duration of k_emit_one_to_one ('one_to_one' reservoirs only; else the sweep emits) */
+    double emit_kernel_ms;   /* mean duration of the reservoir emission (k_emit; + k_emit_one_to_one for that generator) */
     double events_kernel_ms; /* mean duration of the step's tail: k_reduce (+ all-reduce) + k_update */
     double total_ms;         /* wall time of the whole call on the stream */
     int64_t slots;           /* particle capacity (nseg * segcap) */

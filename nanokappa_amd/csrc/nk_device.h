@@ -28,6 +28,8 @@
 #define NK_TAU_ROWS 3        // lifetime rows packed into each mode record (two intervals of the temperature grid)
 #define NK_MAX_SEGMENTS 16384 // upper bound of nseg
 #define NK_EMIT_CHUNK 128    // (reservoir, mode) entries a wave evaluates at a time (two per lane)
+#define NK_LREC 64           // mode records a wave of the sweep stages in LDS (segments that own more read them from L2)
+#define NK_NEWBORN 0x80000000u
 
 // RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")
 #define NK_TAG_REFLECT 0x00000u
@@ -112,7 +114,9 @@ struct NkDev {
     int32_t res_nf;                   // total faces of all reservoir facets
     int32_t res_lds;                  // 1: the three tables above are staged in LDS by the sweep
     const double *enter_prob;         // [R*M]
-    double *res_counter;              // [R*M]
+    double *res_counter;              // [R*M] as uploaded; the live counters are rc_p (nk_engine.hip keeps the two in step)
+    const double *ep_p;               // [nseg * R * nlmax] enter_prob in the segments' order: entry (r, l) of segment s at
+    double *rc_p;                     //   (s * R + r) * nlmax + l -- k_emit reads its entries coalesced; rc_p: the counters
     const double *res_roulette;       // [R*M] 'one_to_one': cumulative enter_prob per reservoir, last = 1 (Population.py:467-468)
     int32_t *nleave_prev;             // [R] 'one_to_one': particles that left at the previous step, all ranks (Population.py:466)
     uint64_t *sp_inbox;               // 'one_to_one': [nseg * sp_icap] spawn records (i << 40 | rm << 12) routed to the owner
@@ -137,8 +141,11 @@ struct NkDev {
     int64_t cap;
     int32_t nseg, segcap;
     int32_t *seg_count;               // [nseg] live particles per segment (contiguous from the segment start)
+    int32_t *seg_new;                 // [nseg] particles k_emit appended behind them at this step (the sweep takes them in)
+    int32_t *seg_bound;               // [nseg] upper bound of the particles that can enter the segment in one step
     double *x, *y, *z, *occ, *nts;
-    uint32_t *w0;                     // (facet + 1) << lb | idx;  idx = mode / nseg (part) or the mode itself
+    uint32_t *w0;                     // newborn << 31 | (facet + 1) << lb | idx;  idx = mode / nseg (part) or the mode itself;
+                                      // newborn: appended by k_emit at this step (no relaxation, no drift yet)
     uint64_t *pid;                    // null: particle ids are not tracked (no per-particle random draws in this configuration)
     int32_t part;                     // 1: idx is the local index of a mode of the owning segment; 0: the global mode index
     int32_t lb;                       // bits of idx in w0
@@ -150,7 +157,7 @@ struct NkDev {
                                       // nk_step call do nothing, so the host can grow the store with the state intact
     double *partials;                 // [rows][NB] per-workgroup tally rows
     int32_t NB;                       // bins per row = 5*S + 5*R + 1
-    int32_t dbg;                      // developer ablation mask (env NK_DEBUG; only read by the NK_ABLATE build, nk_kernels.h)
+    unsigned long long *stamps;       // developer build NK_STAMPS (make stamps): per-wave cycle sums of the sweep's sections
 };
 
 // ------------------------------------------------------------------------------------------------ RNG
@@ -476,9 +483,58 @@ __device__ __forceinline__ void nk_fb_planes(const double *planes, const double 
         }
     }
 }
+// One plane's faces against the hit point of a ray at distance t on that plane (AABB :828-829, barycentric :837-843).
+__device__ __forceinline__ void nk_fb_faces(const double *faces, int f_lo, int f_hi, double tol, double t, double cx, double cy,
+                                            double cz, NkHit &h) {
+    for (int f = f_lo; f < f_hi; ++f) {
+        const double2 *q = reinterpret_cast<const double2 *>(faces + f * NK_FACE_DOUBLES);
+        const double2 q0 = q[0], q1 = q[1], q2 = q[2];              // lo.x lo.y | lo.z hi.x | hi.y hi.z
+        const bool inside = (cx >= q0.x - tol) & (cy >= q0.y - tol) & (cz >= q1.x - tol) & (cx <= q1.y + tol) &
+                            (cy <= q2.x + tol) & (cz <= q2.y + tol);
+        if (!inside) continue;
+        const double2 q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];   // o(3) iu(3) iw(3) {face, facet}
+        const double bx = cx - q3.x, by = cy - q3.y, bz = cz - q4.x;
+        const double u = q4.y * bx + q5.x * by + q5.y * bz;
+        const double w = q6.x * bx + q6.y * by + q7.x * bz;
+        const double r = 1.0 - (u + w);
+        if (!(u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol)) continue;
+        const int idf = __double2loint(q7.y), idc = __double2hiint(q7.y);
+        if (t < h.t || idf < h.face) { h.t = t; h.face = idf; h.facet = idc; }
+    }
+}
+// The reference takes the smallest t among the (plane, face) pairs that pass the face tests.  First every plane's t (cheap),
+// remembering the smallest admissible one; if that plane has a face that passes, it IS the answer -- no other pair can have
+// a smaller t -- and only its faces were tested (from inside a convex body that is always the case: a third of the work of
+// testing faces plane by plane).  If it has none, or two planes tie for the smallest t, the plain sweep runs.  Same result
+// in every case, same arithmetic (no fused multiply-adds: numpy does not fuse, and num cancels near a plane).
 __device__ __forceinline__ void nk_find_boundary(const double *planes, const double *faces, int NP, double tol, double x,
                                                  double y, double z, double vx, double vy, double vz, double &tc, int &fc) {
     NkHit h = {__builtin_inf(), 0x7fffffff, -1};
+    {
+#pragma clang fp contract(off)
+        const double2 *P = reinterpret_cast<const double2 *>(planes);
+        double tmin = __builtin_inf();
+        int pmin = -1, ties = 0;
+        double2 n0 = P[0], n1 = P[1];
+        for (int pl = 0; pl < NP; ++pl) {
+            const double2 p01 = n0, p23 = n1;
+            if (pl + 1 < NP) { n0 = P[3 * pl + 3]; n1 = P[3 * pl + 4]; }
+            const double num = x * p01.x + y * p01.y + z * p23.x + p23.y;
+            const double den = vx * p01.x + vy * p01.y + vz * p23.x;
+            if (!((num < 0.0 && den > 0.0) || (num > 0.0 && den < 0.0))) continue;
+            const double t = -num / den;
+            if (!(t >= tol) || isinf(t)) continue;
+            if (t < tmin) { tmin = t; pmin = pl; ties = 0; }
+            else if (t == tmin) ties = 1;
+        }
+        if (pmin < 0) { tc = h.t; fc = h.facet; return; }            // no admissible plane at all: a miss
+        if (!ties) {
+            const double cx = x + tmin * vx, cy = y + tmin * vy, cz = z + tmin * vz;
+            const double pr = planes[NK_PLANE_DOUBLES * pmin + 4];
+            nk_fb_faces(faces, __double2loint(pr), __double2hiint(pr), tol, tmin, cx, cy, cz, h);
+            if (h.facet >= 0 || h.face != 0x7fffffff) { tc = h.t; fc = h.facet; return; }
+        }
+    }
     nk_fb_planes(planes, faces, 0, NP, tol, x, y, z, vx, vy, vz, h);
     tc = h.t;
     fc = h.facet;
@@ -712,12 +768,12 @@ __device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double
                 const double n0 = d.T_ref_local ? nk_be(p.omega * d.c_hk, p.E0, resT[2 * r + 1], d.invT0)
                                                 : nk_occupation(d, d.T_ref, p.omega, p.E0);
                 double e = d.hbar * p.omega * (p.occ - n0);
-                double vn = p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz;
+                const double evn = e * nk_rcp(p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz);      // e / (v . n), :1602
                 atomicAdd(&b.nleave[r], 1u);
                 atomicAdd(&b.resb[4 * r + 0], -e);
-                atomicAdd(&b.resb[4 * r + 1], e * p.vx / vn);
-                atomicAdd(&b.resb[4 * r + 2], e * p.vy / vn);
-                atomicAdd(&b.resb[4 * r + 3], e * p.vz / vn);
+                atomicAdd(&b.resb[4 * r + 1], evn * p.vx);
+                atomicAdd(&b.resb[4 * r + 2], evn * p.vy);
+                atomicAdd(&b.resb[4 * r + 3], evn * p.vz);
             }
             return NK_EV_DEAD;
         }

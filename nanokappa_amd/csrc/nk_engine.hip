@@ -56,6 +56,8 @@ struct nk_ctx {
     NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
     int64_t modetab_p_len = 0;
     void *inbox = nullptr, *inbox_n = nullptr;   // 'one_to_one' spawn inboxes (sized with nseg)
+    double *ep_p = nullptr, *rc_p = nullptr;     // (reservoir, mode) tables in the segments' order (sized with nseg)
+    int rm_nseg = 0;                             // segmentation rc_p was built for (0: the counters live in res_counter)
     double *acc = nullptr;         // [NB + 1]
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -102,10 +104,11 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 
 // 1 = ray-casting tables fit LDS, 2 = they stay in global memory
 static inline int nk_geom_mode(const nk_ctx *ctx) { return (ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES) ? 1 : 2; }
-static inline size_t nk_lds(const nk_ctx *ctx, bool geom, bool emit = false) {
+// kind: 0 plain, 1 k_emit (emission scratch), 2 k_sweep (mode records)
+static inline size_t nk_lds(const nk_ctx *ctx, bool geom, int kind = 0) {
     const NkDev &d = ctx->d;
     const int gm = geom ? nk_geom_mode(ctx) : 0;
-    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, emit, (gm == 1 && d.res_lds) ? d.res_nf : 0, d.rbf_P);
+    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, kind, (gm == 1 && d.res_lds) ? d.res_nf : 0, d.rbf_P);
 }
 #define NK_GEOM_LAUNCH(kernel, grid, lds, ...)                                                        \
     do {                                                                                               \
@@ -220,7 +223,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.rank = 0;
     ctx->d.nranks = 1;
     ctx->d.tau_row0 = -1;
-    { const char *dbg = getenv("NK_DEBUG"); ctx->d.dbg = dbg ? atoi(dbg) : 0; }
+    ctx->d.stamps = nullptr;
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
     // bookkeeping words in device memory: halt[2], overflow, ticket
@@ -255,6 +258,8 @@ void nk_destroy(nk_ctx *ctx) {
     if (ctx->modetab_p) hipFree(ctx->modetab_p);
     if (ctx->inbox) hipFree(ctx->inbox);
     if (ctx->inbox_n) hipFree(ctx->inbox_n);
+    if (ctx->ep_p) hipFree(ctx->ep_p);
+    if (ctx->rc_p) hipFree(ctx->rc_p);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -628,6 +633,42 @@ static int nk_patch_facets(nk_ctx *ctx) {
     return NK_OK;
 }
 
+// The reservoir counters live in the segments' order (rc_p) while a store exists; before the segmentation changes (or
+// the reservoirs are replaced) they go back to the caller's order.
+static int nk_entry_tables_drop(nk_ctx *ctx, bool keep_counters) {
+    NkDev &d = ctx->d;
+    if (ctx->rm_nseg > 0 && keep_counters && d.R > 0 && d.res_counter) {
+        const int64_t n = (int64_t)d.R * d.M;
+        k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(0, d.R, d.M, ctx->rm_nseg, (d.M + ctx->rm_nseg - 1) / ctx->rm_nseg,
+                                                                   d.res_counter, ctx->rc_p);
+        NK_HIP(hipGetLastError());
+        NK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (ctx->ep_p) { hipFree(ctx->ep_p); ctx->ep_p = nullptr; }
+    if (ctx->rc_p) { hipFree(ctx->rc_p); ctx->rc_p = nullptr; }
+    d.ep_p = nullptr; d.rc_p = nullptr;
+    ctx->rm_nseg = 0;
+    return NK_OK;
+}
+static int nk_entry_tables_build(nk_ctx *ctx) {
+    NkDev &d = ctx->d;
+    if (!(d.R > 0 && d.nseg > 0 && d.enter_prob && d.res_counter) || ctx->rm_nseg == d.nseg) return NK_OK;
+    int rc = nk_entry_tables_drop(ctx, true);
+    if (rc) return rc;
+    const size_t len = (size_t)d.nseg * d.R * d.nlmax;
+    NK_HIP(hipMalloc((void **)&ctx->ep_p, len * 8));
+    NK_HIP(hipMalloc((void **)&ctx->rc_p, len * 8));
+    NK_HIP(hipMemsetAsync(ctx->ep_p, 0, len * 8, ctx->stream));
+    NK_HIP(hipMemsetAsync(ctx->rc_p, 0, len * 8, ctx->stream));
+    const int64_t n = (int64_t)d.R * d.M;
+    k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, (double *)d.enter_prob, ctx->ep_p);
+    k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, d.res_counter, ctx->rc_p);
+    NK_HIP(hipGetLastError());
+    d.ep_p = ctx->ep_p; d.rc_p = ctx->rc_p;
+    ctx->rm_nseg = d.nseg;
+    return NK_OK;
+}
+
 static int nk_alloc_tally(nk_ctx *ctx) {
     NkDev &d = ctx->d;
     d.NB = 5 * d.S + 5 * d.R + 1;
@@ -702,6 +743,7 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
     NK_ARG(r->R >= 0 && r->R <= 64, "nk_set_reservoirs: R must be in [0, 64]");
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
+    { int rc0 = nk_entry_tables_drop(ctx, false); if (rc0) return rc0; }
     d.R = r->R; d.res_gen = r->gen;
     d.res_nf = 0; d.res_lds = 0;
     NK_ARG((int64_t)d.R * d.M < (1ll << 28), "nk_set_reservoirs: R*Q*J too large for the particle id layout");
@@ -764,6 +806,7 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
         d.res_lds = d.res_nf <= NK_LDS_RESFACES ? 1 : 0;
         int rc = nk_patch_facets(ctx);
         if (rc) return rc;
+        if ((rc = nk_entry_tables_build(ctx))) return rc;
     }
     return nk_alloc_tally(ctx);
 }
@@ -953,7 +996,7 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx);
     const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4);
     if (ctx->g_sweep == 0 || ctx->g_sweep_key != key) {
-        const size_t lds_w = nk_lds(ctx, true, true);
+        const size_t lds_w = nk_lds(ctx, true, 2);
         int per_cu = 0;
         hipError_t e_ = hipSuccess;
         NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
@@ -984,6 +1027,7 @@ static int64_t nk_spawn_bound(const nk_ctx *ctx, int nseg) {
 // partitioned (0 = unknown: even spread assumed).
 static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode = nullptr, int64_t N = 0) {
     NkDev &d = ctx->d;
+    { int rc0 = nk_entry_tables_drop(ctx, true); if (rc0) return rc0; }
     for (void *p : ctx->pallocs) hipFree(p);
     ctx->pallocs.clear();
     // Segments = load-balance granularity of the persistent sweep.  For large ensembles exactly ONE segment per resident wave
@@ -1029,6 +1073,11 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     d.pid = nullptr;
     if (nk_want_pid(ctx)) NK_PALLOC(uint64_t, pid, pu, d.cap);
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
+    NK_PALLOC(int32_t, seg_new, pi, d.nseg);
+    NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
+#ifdef NK_STAMPS
+    { const unsigned long long *ps; int rc_ = nk_upload<unsigned long long>(ctx, nullptr, (size_t)d.nseg * 8, &ps, true); if (rc_) return rc_; d.stamps = (unsigned long long *)ps; }
+#endif
 #undef NK_PALLOC
     ctx->layout_key = (d.part ? 1 : 0) | (d.pid ? 2 : 0);
     // tables that follow the segmentation: permuted mode records, 'one_to_one' inboxes
@@ -1036,7 +1085,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     if (ctx->inbox) { hipFree(ctx->inbox); ctx->inbox = nullptr; }
     if (ctx->inbox_n) { hipFree(ctx->inbox_n); ctx->inbox_n = nullptr; }
     d.sp_inbox = nullptr; d.sp_inbox_n = nullptr; d.sp_icap = 0;
-    return NK_OK;
+    return nk_entry_tables_build(ctx);
 }
 
 // 'one_to_one': per-segment inboxes for the records of k_emit_one_to_one
@@ -1071,6 +1120,8 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     NK_PALLOC(uint32_t, w0, pw, d.cap);
     if (old.pid) NK_PALLOC(uint64_t, pid, pu, d.cap);
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
+    NK_PALLOC(int32_t, seg_new, pi, d.nseg);
+    NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
 #undef NK_PALLOC
     if (rc) {                                            // out of memory: keep the old store
         for (void *p : ctx->pallocs) hipFree(p);
@@ -1133,8 +1184,8 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     }
     int rc = nk_scatter(ctx, N, x, y, z, mode, occ, n_ts, facet, pid, pid_offset);
     if (rc) return rc;
-    int32_t zero4[4] = {0, 0, 0, 0};
-    NK_HIP(hipMemcpy(d.halt, zero4, 16, hipMemcpyHostToDevice));     // halt[2], overflow, ticket
+    int32_t zero5[5] = {0, 0, 0, 0, 0};
+    NK_HIP(hipMemcpy(d.halt, zero5, 20, hipMemcpyHostToDevice));     // halt[2], overflow, ticket, emitted
     ctx->pending_relax = false;
     return NK_OK;
 }
@@ -1150,7 +1201,7 @@ static int nk_check_ready(nk_ctx *ctx) {
         NK_ARG(!(hf.bc == 'T' || hf.bc == 'F') || hf.res >= 0, "a facet has BC 'T' but nk_set_reservoirs did not cover it");
     }
     NK_ARG(d.cap > 0, "no particle storage: call nk_reserve / nk_upload_particles");
-    NK_ARG(nk_lds(ctx, true, true) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
+    NK_ARG(nk_lds(ctx, true, 2) <= 160 * 1024 && nk_lds(ctx, true, 1) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
     // the store's layout follows the configuration (ids, partitioned modes): tables set after the upload re-deal it
     const int want = (nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0);
     if (ctx->layout_key != want) {
@@ -1201,11 +1252,12 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         ctx->hist_cap = rows_alloc;
     }
     NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));   // row_valid = 0
-    const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, true);
+    const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, 2), lds_e = nk_lds(ctx, true, 1);
     const int gm_ = nk_geom_mode(ctx);
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = d.pid != nullptr;
     (void)nk_sweep_blocks(ctx);
     const int g_sweep = ctx->g_sweep < (d.nseg + 3) / 4 ? ctx->g_sweep : (d.nseg + 3) / 4;
+    const int g_emit = ctx->num_cu * 8 < (d.nseg + 3) / 4 ? ctx->num_cu * 8 : (d.nseg + 3) / 4;
     const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the batch
     if (ctx->evpool.empty()) {                           // events are created once and reused
         ctx->evpool.resize(16 * 4 + 2);
@@ -1232,6 +1284,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         const int do_flux = (fe > 0 && ((stepno + 1) % fe) == 0) ? 1 : 0;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
         if (R > 0 && d.res_gen == 2) k_emit_one_to_one<<<ctx->num_cu * 4, NK_WG, 0, ctx->stream>>>(d, step);
+        if (R > 0) NK_GEOM_LAUNCH(k_emit, g_emit, lds_e, d, step);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
         {
             const int rl = pending ? 1 : 0;
@@ -1256,6 +1309,17 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     NK_HIP(hipStreamSynchronize(ctx->stream));
     h.resize((size_t)nsteps * HROW);
     NK_HIP(hipMemcpy(h.data(), ctx->hist, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+#ifdef NK_STAMPS
+    if (d.stamps) {                                     // developer build: section shares of the LAST sweep of the batch
+        std::vector<unsigned long long> st((size_t)d.nseg * 8);
+        NK_HIP(hipMemcpy(st.data(), d.stamps, st.size() * 8, hipMemcpyDeviceToHost));
+        double sum[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int sgm = 0; sgm < d.nseg; ++sgm) for (int k = 0; k < 7; ++k) sum[k] += (double)st[(size_t)sgm * 8 + k];
+        double tot = 0; for (int k = 0; k < 6; ++k) tot += sum[k];
+        fprintf(stderr, "[stamps] cycles per tile: arrive %.0f  relax+drift %.0f  tally+store %.0f  pack/merge %.0f  event %.0f  event tally/store/repack %.0f  | total %.0f (tiles %.0f)\n",
+                sum[0] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[4] / sum[6], sum[5] / sum[6], tot / sum[6], sum[6]);
+    }
+#endif
     int32_t nd = 0;
     while (nd < nsteps && h[(size_t)nd * HROW + NB + 2 * S + 1] != 0.0) ++nd;
     *done = nd;

@@ -32,6 +32,23 @@
 #pragma once
 #include "nk_device.h"
 
+#define NK_TILE 64           // particles per tile = lanes of a wave
+// Developer build (make stamps -> libnanokappa_hip_stamps.so, env NK_STAMPS=1): s_memtime stamps around the sections of
+// the sweep's tile loop, summed per wave; shares only (the stamps' waits forbid overlaps the real kernel has).
+#ifdef NK_STAMPS
+#define NK_STAMP(k)                                                                                    \
+    do {                                                                                               \
+        unsigned long long t_;                                                                         \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+        __builtin_amdgcn_sched_barrier(0);                                                             \
+        st_acc[k] += t_ - st_last;                                                                     \
+        st_last = t_;                                                                                  \
+    } while (0)
+#else
+#define NK_STAMP(k) do { } while (0)
+#endif
+
 // =================================================================================== LDS carve-up
 struct NkLds {
     NkSvTab tb;                          // centres, temperatures (+ RBF coefficients), per-subvolume records
@@ -41,20 +58,24 @@ struct NkLds {
     const double *resT;                  // [2R] reservoir {T, 1/T}
     const int *rf_off;                   // reservoir face tables (CSR), LDS copies when d.res_lds
     const double *rf_cdf, *rf_verts;
-    // emission scratch of the sweep, one slice of NK_EMIT_CHUNK entries per wave
+    // emission scratch of k_emit, one slice of NK_EMIT_CHUNK entries per wave
     unsigned int *sp_pref, *sp_cnt, *sp_rm;
-    double *sp_cv;
+    double *sp_cv, *sp_pr;
+    // mode records of the sweep's segments, NK_LREC per wave (16-byte aligned)
+    double *lrec;
 };
 
 // geom: 0 = no ray-casting tables, 1 = planes/faces/facets staged in LDS, 2 = read from global memory (large meshes)
-// nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged); emit: carve the sweep's emission scratch
-__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, bool emit, int nrf, int rbfP) {
+// nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged); kind: 0 plain, 1 + k_emit's scratch,
+// 2 + the sweep's mode records
+__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, int kind, int nrf, int rbfP) {
+    const bool emit = kind == 1;
     int Fl = geom == 1 ? F : 0;
     int Pl = Fl ? NP : 0;
     int Fcl = geom == 1 ? Fc : 0;
     size_t nd = (size_t)S + (size_t)((rbfP + 1) & ~1) + 3 * S + ((3 * S) & 1) + 4 * (size_t)S + NK_NREP * S + NK_NREP * 3 * S + 4 * R +
                 (size_t)Fl * NK_FACE_DOUBLES + (size_t)Pl * NK_PLANE_DOUBLES + 2 * (size_t)R + 10 * (size_t)nrf +
-                (emit ? (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + 4;
+                (emit ? 2 * (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind == 2 ? (size_t)(NK_WG / 64) * NK_LREC * 8 : 0) + 4;
     size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) +
                    (size_t)(NK_NREP * S + R + 1 + (R + 1) + (emit ? 3 * (NK_WG / 64) * NK_EMIT_CHUNK : 0)) * 4 + 32;
     return (bytes + 15) & ~(size_t)15;
@@ -62,8 +83,9 @@ __host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int 
 
 // The pointer arithmetic.  GEOM as in nk_lds_bytes (a compile-time choice, so that the table pointers are provably LDS and
 // are read with ds_read, not flat loads).  Plane, face, facet and subvolume records start on 16-byte boundaries.
-template <int GEOM, bool EMIT>
+template <int GEOM, int KIND>
 __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem, NkLds &L) {
+    constexpr bool EMIT = KIND == 1;
     const int S = d.S, R = d.R;
     const int Fl = GEOM == 1 ? d.F : 0;
     const int Pl = Fl ? d.NP : 0;
@@ -83,8 +105,9 @@ __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem
     double *resT = p; p += 2 * R;
     double *rf_cdf = p; p += nrf;
     double *rf_verts = p; p += 9 * (size_t)nrf;
-    if (EMIT) { L.sp_cv = p; p += (NK_WG / 64) * NK_EMIT_CHUNK; } else L.sp_cv = nullptr;
-    p += ((size_t)(p - (double *)smem) & 1);           // keep the facet table 16-byte aligned
+    if (EMIT) { L.sp_cv = p; p += (NK_WG / 64) * NK_EMIT_CHUNK; L.sp_pr = p; p += (NK_WG / 64) * NK_EMIT_CHUNK; } else L.sp_cv = L.sp_pr = nullptr;
+    p += ((size_t)(p - (double *)smem) & 1);           // keep the records and the facet table 16-byte aligned
+    if (KIND == 2) { L.lrec = p; p += (NK_WG / 64) * NK_LREC * 8; } else L.lrec = nullptr;
     NkFacet *facets = (NkFacet *)p;
     unsigned int *u = (unsigned int *)(facets + Fcl);
     L.bins.N = u; u += NK_NREP * S;
@@ -102,9 +125,9 @@ __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem
     else { L.faces = d.faces; L.planes = d.planes; L.facets = d.facets; }
 }
 // Cooperative fill of the read-only tables and zeroing of the bins; ends with a barrier.
-template <int GEOM, bool EMIT>
+template <int GEOM, int KIND>
 __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem, NkLds &L) {
-    nk_lds_carve<GEOM, EMIT>(d, smem, L);
+    nk_lds_carve<GEOM, KIND>(d, smem, L);
     const int S = d.S, R = d.R;
     const int Fl = GEOM == 1 ? d.F : 0;
     const int Pl = Fl ? d.NP : 0;
@@ -220,14 +243,14 @@ __device__ __forceinline__ NkSegModes nk_seg_modes(const NkDev &d, int seg) {
 // (Population.py:358-370) / 'fixed_rate' (:408-420) for one (reservoir, mode) entry.  c = particles entering,
 // c_mine = those this rank owns (emission_owner: (rm + level + step) % nranks); cv = the counter / dice value that the
 // level-1 particle's entry time uses.
-__device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int64_t rm, double prob, int &c, int &c_mine, double &cv) {
+__device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int64_t rm, int64_t at, double prob, int &c, int &c_mine, double &cv) {
     const double fixed = floor(prob);
     int mask;
     if (d.res_gen == 0) {
-        cv = d.res_counter[rm] + (prob - fixed);
+        cv = d.rc_p[at] + (prob - fixed);
         mask = cv >= 1.0;
         cv -= (double)mask;
-        d.res_counter[rm] = cv;
+        d.rc_p[at] = cv;
     } else {
         double d1;
         nk_uniform2_dev(d.seed, (uint64_t)rm | 0xFFFFFFFF00000000ull, step, NK_TAG_DICE, cv, d1);
@@ -306,14 +329,157 @@ struct NkCarry {
     }
 };
 
+// Reservoir emission as its own (small) kernel: fill_reservoirs + add_reservoir_particles for the modes a segment owns.
+// A wave evaluates its segment's (reservoir, mode) entries 128 at a time ('one_to_one': reads the segment's inbox), builds
+// the entering particles in whole tiles (Mesh.sample_surface, Mesh.py:923-951; entry times Population.py:391-394 /
+// :440-443; add_reservoir_particles :525-552) and appends them BEHIND the segment's live particles, marked newborn; the
+// sweep of the same step takes them in (tally, boundary events) without relaxing or drifting them.
+template <int GEOM>
+__global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (d.halt[0]) return;
+    NkLds L;
+    nk_lds_setup<GEOM, 1>(d, smem, L);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned int *sp_pref = L.sp_pref + wave * NK_EMIT_CHUNK, *sp_cnt = L.sp_cnt + wave * NK_EMIT_CHUNK,
+                 *sp_rm = L.sp_rm + wave * NK_EMIT_CHUNK;
+    double *sp_cv = L.sp_cv + wave * NK_EMIT_CHUNK, *sp_pr = L.sp_pr + wave * NK_EMIT_CHUNK;
+    const int nwaves = gridDim.x * (NK_WG / 64);
+    for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg];
+        const NkSegModes sm = nk_seg_modes(d, seg);
+        const int nent = d.res_gen != 2 ? d.R * sm.nl : 0;
+        int made = 0;                                 // particles appended so far
+        int sp_bound = 0;                             // per-lane partial sums of the entries' upper bounds
+        for (int e0 = 0; e0 < nent || (d.res_gen == 2 && e0 == 0); e0 += NK_EMIT_CHUNK) {
+            int spn = 0;
+            if (d.res_gen == 2) {
+                spn = d.sp_inbox_n[seg];
+                spn = spn < d.sp_icap ? spn : d.sp_icap;
+                sp_bound = lane == 0 ? 2 * spn + 64 : 0;
+            } else {
+                // ---- this chunk of the segment's (reservoir, mode) entries: entry e = r * nl + l, two per lane
+                unsigned int run = 0;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int e = e0 + k * 64 + lane;
+                    int c = 0, cmine = 0;
+                    double cv = 0.0, prob = 0.0;
+                    unsigned int rm32 = 0;
+                    if (e < nent) {
+                        const int r = e / sm.nl, l = e - r * sm.nl;
+                        const int64_t rm = (int64_t)r * d.M + ((int64_t)l * d.nseg + seg);
+                        const int64_t at = ((int64_t)seg * d.R + r) * d.nlmax + l;
+                        prob = d.ep_p[at];
+                        nk_emit_entry(d, step, rm, at, prob, c, cmine, cv);
+                        rm32 = (unsigned int)rm;
+                        sp_bound += ((int)floor(prob) + 1 + d.nranks - 1) / d.nranks;
+                    }
+                    unsigned int v = (unsigned int)cmine;
+#pragma unroll
+                    for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+                    sp_cnt[k * 64 + lane] = (unsigned int)c;
+                    sp_rm[k * 64 + lane] = rm32;
+                    sp_cv[k * 64 + lane] = cv;
+                    sp_pr[k * 64 + lane] = prob;
+                    sp_pref[k * 64 + lane] = v + run - (unsigned int)cmine;
+                    run += __shfl(v, 63, 64);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // LDS is in order per wave; keep the compiler honest
+                spn = (int)run;
+            }
+            for (int spj = 0; spj < spn; spj += NK_TILE) {
+                const int j = spj + lane;
+                if (j >= spn) continue;
+                int64_t rm;
+                int level;
+                double prob = 0.0, cval = 0.0;
+                uint64_t o2o = 0;
+                if (d.res_gen == 2) {
+                    const uint64_t recd = d.sp_inbox[(int64_t)seg * d.sp_icap + j];
+                    rm = (int64_t)((recd >> 12) & 0xFFFFFFFull);
+                    level = 0;                              // 'one_to_one': entry time uniform in the step
+                    o2o = recd >> 40;
+                } else {
+                    // the entry this particle belongs to: the last one whose exclusive prefix is <= j
+                    int lo = 0, hi = NK_EMIT_CHUNK;
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)sp_pref[mid] <= j) lo = mid; else hi = mid; }
+                    const int q = j - (int)sp_pref[lo], c = (int)sp_cnt[lo];
+                    rm = (int64_t)sp_rm[lo];
+                    cval = sp_cv[lo];
+                    prob = sp_pr[lo];
+                    // the q-th level this rank owns, counted down from c (nk_emit_entry's order)
+                    if (d.nranks == 1) level = c - q;
+                    else {
+                        const uint32_t n = (uint32_t)d.nranks;
+                        const uint32_t tq = ((uint32_t)d.rank + n - (((uint32_t)rm + step) % n)) % n;   // owned levels = tq mod n
+                        const uint32_t top = (uint32_t)c - (((uint32_t)c + n - tq) % n);                // largest owned level <= c
+                        level = (int)(top - (uint32_t)q * n);
+                    }
+                }
+                const int r = (int)((uint32_t)rm / (uint32_t)d.M);              // rm < 2^28
+                const int mode = (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
+                const int idx = d.part ? (int)((uint32_t)mode / (uint32_t)d.nseg) : mode;
+                const NkMode *rec = sm.rec + idx;
+                const double4 ra = *reinterpret_cast<const double4 *>(rec);
+                const double E0 = rec->E0;
+                const uint64_t pid = level > 0 ? ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level
+                                               : ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | o2o;
+                double uf, us, ur, ut;
+                nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
+                nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
+                const double dt_in = (level == 0) ? d.dt * ut                               // one_to_one :482
+                                   : (level == 1) ? d.dt * (1.0 - (cval / prob))
+                                                  : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
+                double x0, y0, z0;
+                if (GEOM == 1 && d.res_lds) nk_sample_res_face(L.rf_off, L.rf_cdf, L.rf_verts, r, uf, us, ur, x0, y0, z0);
+                else nk_sample_res_face(d.res_face_off, d.res_face_cdf, d.res_face_verts, r, uf, us, ur, x0, y0, z0);
+                const double omega = ra.x, vx = ra.y, vy = ra.z, vz = ra.w;
+                const double occ = nk_be(omega * d.c_hk, E0, L.resT[2 * r + 1], d.invT0);   // Population.py:506
+                double tc;
+                int facet;
+                int skip = NK_TREE_NO_SKIP;               // the particle starts on its reservoir's facet
+                if (GEOM == 2 && d.NG > 0) {
+                    const int rf = d.res_facet[r];
+                    const NkFacet &fq = d.facets[rf];
+                    skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
+                }
+                NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
+                const int o = count + made + j;
+                if (o < d.segcap) {
+                    const int64_t i = base + o;
+                    d.x[i] = x0 + vx * dt_in; d.y[i] = y0 + vy * dt_in; d.z[i] = z0 + vz * dt_in;   // :536
+                    d.occ[i] = occ;
+                    d.nts[i] = tc / d.dt - dt_in / d.dt;                                            // :535
+                    d.w0[i] = NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx;
+                    if (d.pid) d.pid[i] = pid;
+                } else atomicOr(d.overflow, 1);         // more entering particles than free slots
+            }
+            made += spn;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // the next chunk overwrites the scratch
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sp_bound += __shfl_xor(sp_bound, o, 64);
+        if (lane == 0) {
+            const int room = d.segcap - count;
+            d.seg_new[seg] = made < room ? made : (room > 0 ? room : 0);
+            d.seg_bound[seg] = sp_bound;
+            if (d.res_gen == 2) d.sp_inbox_n[seg] = 0;
+        }
+    }
+}
+
 // The sweep: persistent WAVES, each taking segments w, w + n_waves, ...  A wave owns its segment, so the loop needs no
 // workgroup barrier: the four waves of a workgroup only share the read-only tables and the tally bins (LDS atomics).
-// Per segment ONE loop over 64-particle tiles: first the particles already there (phase A), then the particles entering
-// through the reservoirs in the segment's own modes (phase B: the wave evaluates its (reservoir, mode) entries 128 at a
-// time), then one empty tile that drains the carry.  Every tile ends at the same commit site: final particles are
-// tallied and stored compacted at the write cursor, particles that meet a boundary inside the step join the carry, and
-// whenever the carry holds 64 the whole wave runs one boundary event for each.
-#define NK_TILE 64
+// Per segment ONE loop over 64-particle tiles (the particles that were there, then the newborn ones k_emit appended), and
+// one empty tile that drains the carry.  Every tile ends at the same commit site: final particles are tallied and stored
+// compacted at the write cursor, particles that meet a boundary inside the step join the carry, and whenever the carry
+// holds 64 the whole wave runs one boundary event for each.
+// The segment's mode records are staged in LDS first (<= NK_LREC of them): the loop's only vector-memory operations are
+// then the prefetch of the next tile and the stores of the current one.  That matters beyond bandwidth: vmcnt retires
+// in order, so a gather issued after a tile's stores would wait for the stores' acknowledgement before its data counts as
+// returned -- a full memory round trip per tile in front of the arithmetic.
 #ifndef NK_SWEEP_OCC
 #define NK_SWEEP_OCC 3          // workgroups per CU the sweep is compiled for (3 x 4 waves = 3 waves per SIMD)
 #endif
@@ -322,38 +488,39 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
     extern __shared__ __align__(16) unsigned char smem[];
     if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
     NkLds L;
-    nk_lds_setup<GEOM, true>(d, smem, L);
+    nk_lds_setup<GEOM, 2>(d, smem, L);
     const bool do_flux = (flags & 1) != 0;          // flags: 1 = heat-flux step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rep = lane & (NK_NREP - 1);
     const unsigned long long lower = (1ull << lane) - 1ull;
     const uint32_t lbmask = (1u << d.lb) - 1u;
-    unsigned int *sp_pref = L.sp_pref + wave * NK_EMIT_CHUNK, *sp_cnt = L.sp_cnt + wave * NK_EMIT_CHUNK,
-                 *sp_rm = L.sp_rm + wave * NK_EMIT_CHUNK;
-    double *sp_cv = L.sp_cv + wave * NK_EMIT_CHUNK;
+    double4 *lrec = reinterpret_cast<double4 *>(L.lrec) + wave * NK_LREC * 2;
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
-        const int count = d.seg_count[seg];
+        const int nnew = d.R > 0 ? d.seg_new[seg] : 0;
+        const int count = d.seg_count[seg] + nnew;
+        if (lane == 0 && nnew > 0) atomicAdd(&L.bins.misc[0], (unsigned int)nnew);          // "emitted" column
         const NkSegModes sm = nk_seg_modes(d, seg);
-        const int nA = (count + NK_TILE - 1) / NK_TILE;
-        // entering particles: 'constant' / 'fixed_rate' from this segment's own (reservoir, mode) entries, evaluated in
-        // chunks; 'one_to_one' from the segment's inbox
-        const int nent = (d.R > 0 && d.res_gen != 2) ? d.R * sm.nl : 0;
-        int e0 = 0;                                   // next entry chunk
-        int spn = 0, spj = 0;                         // entering particles of the current chunk, next one to build
-        int sp_bound = 0;                             // upper bound of the particles that can enter this segment in one step
-        if (d.R > 0 && d.res_gen == 2) {
-            spn = d.sp_inbox_n[seg];
-            spn = spn < d.sp_icap ? spn : d.sp_icap;
-            sp_bound = lane == 0 ? 2 * spn + 64 : 0;
-            if (lane == 0 && spn > 0) atomicAdd(&L.bins.misc[0], (unsigned int)spn);          // "emitted" column
+        const bool use_lrec = d.part && sm.nl <= NK_LREC;
+        if (use_lrec) {
+            if (lane < sm.nl) {
+                const double4 *g = reinterpret_cast<const double4 *>(sm.rec + lane);
+                const double4 a = g[0], b = g[1];
+                lrec[2 * lane] = a; lrec[2 * lane + 1] = b;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
+        const int nA = (count + NK_TILE - 1) / NK_TILE;
         int w = 0;                                    // write cursor
         int cn = 0;                                   // particles in the carry (lanes [0, cn))
         NkCarry<PID> C;
         C.x = C.y = C.z = C.occ = C.nts = C.cts = 0.0; C.w0 = 0u; C.evc = 0u; C.pid = 0ull;
-        // next tile of phase A is requested before the current tile's arithmetic (the loop is latency-bound otherwise)
+#ifdef NK_STAMPS
+        unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+#endif
+        // next tile is requested before the current tile's arithmetic
         uint32_t w0N = 0u;
         double xN = 0, yN = 0, zN = 0, occN = 0, ntsN = 0;
         unsigned long long pidN = 0;
@@ -362,137 +529,43 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
             w0N = d.w0[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
             if (PID) pidN = d.pid[i];
         }
-        int t = 0;
-        bool flush = false;
-        for (;;) {
+        for (int t = 0; t <= nA; ++t) {
+            const bool flush = t == nA;               // one empty tile: drains the carry
             bool act = false;
             double x = 0, y = 0, z = 0, occ = 0, nts = 0, omega = 0, E0 = 0, vx = 0, vy = 0, vz = 0;
             uint32_t w0 = 0u;
             unsigned long long pid = 0;
-            if (t < nA) {
-                // ---- phase A: relax (deferred from the previous step), drift
+            if (!flush) {
+                // ---- relax (deferred from the previous step), drift
                 const int r = t * NK_TILE;
-                ++t;
                 act = r + lane < count;
                 w0 = w0N; x = xN; y = yN; z = zN; occ = occN; nts = ntsN; pid = pidN;
-                const int idx = act ? (int)(w0 & lbmask) : 0;
-                const double4 *mrec = reinterpret_cast<const double4 *>(sm.rec + idx);
-                const double4 ra = mrec[0], rb = mrec[1];                            // {omega, v} {E0, tau rows}
                 if (r + NK_TILE + lane < count) {
                     const int64_t i = base + r + NK_TILE + lane;
                     w0N = d.w0[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
                     if (PID) pidN = d.pid[i];
                 }
+                const bool newborn = (w0 & NK_NEWBORN) != 0u;
+                w0 &= ~NK_NEWBORN;
+                const int idx = act ? (int)(w0 & lbmask) : 0;
+                double4 ra, rb;                                                      // {omega, v} {E0, tau rows}
+                if (use_lrec) { ra = lrec[2 * idx]; rb = lrec[2 * idx + 1]; }
+                else { const double4 *g = reinterpret_cast<const double4 *>(sm.rec + idx); ra = g[0]; rb = g[1]; }
                 omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w; E0 = rb.x;
-                if (act) {
+#ifdef NK_STAMPS
+                { const double fence_ = x + omega; asm volatile("" ::"v"(fence_)); }   // the tile's data and record have arrived
+#endif
+                NK_STAMP(0);
+                if (act && !newborn) {
                     if (do_relax) occ = nk_relax<RBF>(d, L, ra, rb, x, y, z, occ, idx * sm.mstride + sm.moff);
                     x += vx * d.dt; y += vy * d.dt; z += vz * d.dt;                 // drift, Population.py:793
                     nts -= 1.0;                                                     // :795
                 }
-            } else if (spj < spn) {
-                // ---- phase B: an entering particle (Mesh.sample_surface, Mesh.py:923-951; entry times
-                // Population.py:391-394 / :440-443; add_reservoir_particles :525-552)
-                const int j = spj + lane;
-                spj += NK_TILE;
-                act = j < spn;
-                if (act) {
-                    int64_t rm;
-                    int level;
-                    double prob = 0.0, cval = 0.0;
-                    uint64_t o2o = 0;
-                    if (d.res_gen == 2) {
-                        const uint64_t recd = d.sp_inbox[(int64_t)seg * d.sp_icap + j];
-                        rm = (int64_t)((recd >> 12) & 0xFFFFFFFull);
-                        level = 0;                              // 'one_to_one': entry time uniform in the step
-                        o2o = recd >> 40;
-                    } else {
-                        // the entry this particle belongs to: the last one whose exclusive prefix is <= j
-                        int lo = 0, hi = NK_EMIT_CHUNK;
-                        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)sp_pref[mid] <= j) lo = mid; else hi = mid; }
-                        const int q = j - (int)sp_pref[lo], c = (int)sp_cnt[lo];
-                        rm = (int64_t)sp_rm[lo];
-                        cval = sp_cv[lo];
-                        prob = d.enter_prob[rm];
-                        // the q-th level this rank owns, counted down from c (nk_emit_entry's order)
-                        if (d.nranks == 1) level = c - q;
-                        else {
-                            const uint32_t n = (uint32_t)d.nranks;
-                            const uint32_t tq = ((uint32_t)d.rank + n - (((uint32_t)rm + step) % n)) % n;   // owned levels = tq mod n
-                            const uint32_t top = (uint32_t)c - (((uint32_t)c + n - tq) % n);                // largest owned level <= c
-                            level = (int)(top - (uint32_t)q * n);
-                        }
-                    }
-                    const int r = (int)(rm / d.M);
-                    const int mode = (int)(rm - (int64_t)r * d.M);
-                    const int idx = d.part ? mode / d.nseg : mode;
-                    const double4 *mrec = reinterpret_cast<const double4 *>(sm.rec + idx);
-                    const double4 ra = mrec[0];
-                    E0 = sm.rec[idx].E0;
-                    pid = level > 0 ? ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level
-                                    : ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | o2o;
-                    double uf, us, ur, ut;
-                    nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
-                    nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
-                    const double dt_in = (level == 0) ? d.dt * ut                               // one_to_one :482
-                                       : (level == 1) ? d.dt * (1.0 - (cval / prob))
-                                                      : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
-                    double x0, y0, z0;
-                    if (GEOM == 1 && d.res_lds) nk_sample_res_face(L.rf_off, L.rf_cdf, L.rf_verts, r, uf, us, ur, x0, y0, z0);
-                    else nk_sample_res_face(d.res_face_off, d.res_face_cdf, d.res_face_verts, r, uf, us, ur, x0, y0, z0);
-                    omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w;
-                    occ = nk_be(omega * d.c_hk, E0, L.resT[2 * r + 1], d.invT0);                 // Population.py:506
-                    double tc;
-                    int facet;
-                    int skip = NK_TREE_NO_SKIP;               // the particle starts on its reservoir's facet
-                    if (GEOM == 2 && d.NG > 0) {
-                        const int rf = d.res_facet[r];
-                        const NkFacet &fq = d.facets[rf];
-                        skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
-                    }
-                    NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
-                    nts = tc / d.dt - dt_in / d.dt;                                  // :535
-                    x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;   // :536
-                    w0 = ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx;
-                }
-            } else if (e0 < nent) {
-                // ---- the next chunk of this segment's (reservoir, mode) entries: entry e = r * nl + l, two per lane
-                unsigned int inc[2];
-                int cm[2];
-                unsigned int run = 0;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int e = e0 + k * 64 + lane;
-                    int c = 0, cmine = 0;
-                    double cv = 0.0;
-                    unsigned int rm32 = 0;
-                    if (e < nent) {
-                        const int r = e / sm.nl, l = e - r * sm.nl;
-                        const int64_t rm = (int64_t)r * d.M + ((int64_t)l * d.nseg + seg);
-                        const double prob = d.enter_prob[rm];
-                        nk_emit_entry(d, step, rm, prob, c, cmine, cv);
-                        rm32 = (unsigned int)rm;
-                        sp_bound += ((int)floor(prob) + 1 + d.nranks - 1) / d.nranks;
-                    }
-                    unsigned int v = (unsigned int)cmine;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
-                    inc[k] = v + run;
-                    cm[k] = cmine;
-                    run += __shfl(v, 63, 64);
-                    sp_cnt[k * 64 + lane] = (unsigned int)c;
-                    sp_rm[k * 64 + lane] = rm32;
-                    sp_cv[k * 64 + lane] = cv;
-                    sp_pref[k * 64 + lane] = inc[k] - (unsigned int)cm[k];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // LDS is in order per wave; keep the compiler honest
-                e0 += NK_EMIT_CHUNK;
-                spn = (int)run;
-                spj = 0;
-                if (lane == 0 && spn > 0) atomicAdd(&L.bins.misc[0], (unsigned int)spn);      // "emitted" column
-                continue;
-            } else if (!flush) {
-                flush = true;                        // one empty tile: drains the carry
-            } else break;
+#ifdef NK_STAMPS
+                { const double fence_ = x + occ; asm volatile("" ::"v"(fence_)); }
+#endif
+                NK_STAMP(1);
+            }
             // ---- commit: final particles -> tally + compacted store; boundary particles -> the carry
             const bool ev = act && nts < 0.0;
             const bool done = act && !ev;
@@ -507,6 +580,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 } else atomicOr(d.overflow, 2);     // segment full at the commit of a tile
             }
             w += __popcll(mD);
+            NK_STAMP(2);
             // the tile's event particles, packed into lanes [po, po + pn) of P
             int pn = __popcll(mE), po = 0;
             NkCarry<PID> P;
@@ -523,6 +597,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     cn += k; po += k; pn -= k;
                 }
                 if (cn < 64 && !(flush && pn == 0)) break;
+                NK_STAMP(3);
                 const bool eact = lane < cn;
                 NkParticle p;
                 double cts = C.cts;
@@ -530,7 +605,11 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 int st = NK_EV_DEAD;
                 p.x = C.x; p.y = C.y; p.z = C.z; p.occ = C.occ; p.nts = C.nts;
                 const int idx0 = eact ? (int)(C.w0 & lbmask) : 0;
-                {
+                if (use_lrec) {
+                    const double4 ra = lrec[2 * idx0];
+                    p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                    p.E0 = reinterpret_cast<const double *>(lrec)[8 * idx0 + 4];
+                } else {
                     const double4 ra = *reinterpret_cast<const double4 *>(sm.rec + idx0);
                     p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                     p.E0 = sm.rec[idx0].E0;
@@ -539,6 +618,10 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 p.facet = (int)(C.w0 >> d.lb) - 1;
                 if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, C.pid, step);
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
+#ifdef NK_STAMPS
+                { const double fence_ = p.x + p.nts; asm volatile("" ::"v"(fence_)); }
+#endif
+                NK_STAMP(4);
                 if (alive) nk_tally_one(d, L.tb, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.E0, p.vx, p.vy, p.vz, do_flux, rep);
                 const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | (uint32_t)(ROUGH ? (d.part ? p.mode / d.nseg : p.mode) : idx0);
                 const unsigned long long mA = __ballot(alive), mM = __ballot(more);
@@ -556,15 +639,24 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                     C.x = p.x; C.y = p.y; C.z = p.z; C.occ = p.occ; C.nts = p.nts; C.cts = cts; C.w0 = w0e; C.evc = evc;
                     C = C.push(more ? __popcll(mM & lower) : cn + __popcll(~mM & lower));
                 }
+                NK_STAMP(5);
             }
+            NK_STAMP(3);
         }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sp_bound += __shfl_xor(sp_bound, o, 64);   // per-lane partial sums of the entries
+#ifdef NK_STAMPS
+        if (lane == 0 && d.stamps) {
+            unsigned long long *o = d.stamps + (int64_t)seg * 8;
+            for (int k = 0; k < 6; ++k) o[k] = st_acc[k];
+            o[6] = (unsigned long long)nA;
+        }
+#endif
         if (lane == 0) {
             d.seg_count[seg] = w < d.segcap ? w : d.segcap;
-            if (d.R > 0 && d.res_gen == 2) d.sp_inbox_n[seg] = 0;
             // could the next step overflow this segment?  then nothing after this step runs until the host has grown the store
-            if ((int64_t)w + sp_bound + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+            if (d.R > 0) {
+                d.seg_new[seg] = 0;
+                if ((int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+            }
         }
     }
     nk_lds_flush(d, L, blockIdx.x);
@@ -699,7 +791,7 @@ __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d, int honor_halt) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (honor_halt && d.halt[0]) return;
     NkLds L;
-    nk_lds_setup<0, false>(d, smem, L);
+    nk_lds_setup<0, 0>(d, smem, L);
     const uint32_t lbmask = (1u << d.lb) - 1u;
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
@@ -720,7 +812,7 @@ template <int GEOM>
 __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<GEOM, false>(d, smem, L);
+    nk_lds_setup<GEOM, 0>(d, smem, L);
     const uint32_t lbmask = (1u << d.lb) - 1u;
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
@@ -753,7 +845,7 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (d.halt[0]) return;
     NkLds L;
-    nk_lds_setup<GEOM, false>(d, smem, L);
+    nk_lds_setup<GEOM, 0>(d, smem, L);
     const uint32_t lbmask = (1u << d.lb) - 1u;
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
@@ -787,6 +879,15 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
     }
 }
 
+// (reservoir, mode) tables between the caller's order [r * M + m] and the segments' order (nk_device.h ep_p / rc_p)
+__global__ void k_perm_rm(int to_seg_order, int R, int M, int nseg, int nlmax, double *canon, double *perm) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)R * M) return;
+    const int r = (int)(i / M), m = (int)(i - (int64_t)r * M);
+    const int64_t at = ((int64_t)(m % nseg) * R + r) * nlmax + m / nseg;
+    if (to_seg_order) perm[at] = canon[i]; else canon[i] = perm[at];
+}
+
 // {omega, v, E0, tau[row0..row0+2]} records, by mode index and (part) in the segments' order
 __global__ void k_build_modetab(const double *omega, const double *vg, const double *tau, int M, int NT, int row0, double c_hk,
                                 double invT0, int nseg, int nlmax, NkMode *out, NkMode *out_p) {
@@ -809,7 +910,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n,
                                                              double *xc, double *tc, int32_t *fc) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<GEOM, false>(d, smem, L);
+    nk_lds_setup<GEOM, 0>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
     double t; int f;
@@ -820,7 +921,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n,
 __global__ __launch_bounds__(NK_WG) void k_tap_classify(NkDev d, int64_t n, const double *x, int32_t *id) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<0, false>(d, smem, L);
+    nk_lds_setup<0, 0>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i < n) id[i] = nk_classify(d, L.tb, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
 }
@@ -828,7 +929,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, int what, int64_t n
                                                     double *out) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<0, false>(d, smem, L);
+    nk_lds_setup<0, 0>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
     switch (what) {
@@ -846,7 +947,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_reflect(NkDev d, int64_t n, const
                                                        int32_t *mode_out, double *n_out, double *om_out) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
-    nk_lds_setup<0, false>(d, smem, L);
+    nk_lds_setup<0, 0>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= n) return;
     int mo; double no, oo, eo;

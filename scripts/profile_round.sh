@@ -10,6 +10,17 @@ rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $
 echo "kernel trace done"
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/sq -o p --output-format csv -- $B > /dev/null 2> $O/sq.log
 echo "sq pass done"
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS -d $O/sq2 -o p --output-format csv -- $B > /dev/null 2> $O/sq2.log
+python3 - <<PY > $O/sq2.json
+import sys
+sys.path.insert(0, '$R/scripts')
+import json, pmc_summary
+try:
+    print(json.dumps(pmc_summary.load('$O/sq2'), indent=1, sort_keys=True))
+except Exception as e:
+    print(json.dumps({'error': repr(e)}))
+PY
+echo "sq2 pass done"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $O/fe -o p --output-format csv -- $B > /dev/null 2> $O/fe.log
 echo "fetch pass done"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $O/wr -o p --output-format csv -- $B > /dev/null 2> $O/wr.log
