@@ -104,7 +104,7 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 
 // 1 = ray-casting tables fit LDS, 2 = they stay in global memory
 static inline int nk_geom_mode(const nk_ctx *ctx) { return (ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES) ? 1 : 2; }
-// kind: 0 plain, 1 k_emit (emission scratch), 2 k_sweep (mode records)
+// kind: 0 plain, 1 k_emit (emission scratch), 2 / 3 k_sweep (mode records, output ring without / with ids)
 static inline size_t nk_lds(const nk_ctx *ctx, bool geom, int kind = 0) {
     const NkDev &d = ctx->d;
     const int gm = geom ? nk_geom_mode(ctx) : 0;
@@ -996,7 +996,7 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx);
     const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4);
     if (ctx->g_sweep == 0 || ctx->g_sweep_key != key) {
-        const size_t lds_w = nk_lds(ctx, true, 2);
+        const size_t lds_w = nk_lds(ctx, true, pid_ ? 3 : 2);
         int per_cu = 0;
         hipError_t e_ = hipSuccess;
         NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
@@ -1201,7 +1201,7 @@ static int nk_check_ready(nk_ctx *ctx) {
         NK_ARG(!(hf.bc == 'T' || hf.bc == 'F') || hf.res >= 0, "a facet has BC 'T' but nk_set_reservoirs did not cover it");
     }
     NK_ARG(d.cap > 0, "no particle storage: call nk_reserve / nk_upload_particles");
-    NK_ARG(nk_lds(ctx, true, 2) <= 160 * 1024 && nk_lds(ctx, true, 1) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
+    NK_ARG(nk_lds(ctx, true, 3) <= 160 * 1024 && nk_lds(ctx, true, 1) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
     // the store's layout follows the configuration (ids, partitioned modes): tables set after the upload re-deal it
     const int want = (nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0);
     if (ctx->layout_key != want) {
@@ -1252,7 +1252,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         ctx->hist_cap = rows_alloc;
     }
     NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));   // row_valid = 0
-    const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, 2), lds_e = nk_lds(ctx, true, 1);
+    const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, d.pid ? 3 : 2), lds_e = nk_lds(ctx, true, 1);
     const int gm_ = nk_geom_mode(ctx);
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = d.pid != nullptr;
     (void)nk_sweep_blocks(ctx);
