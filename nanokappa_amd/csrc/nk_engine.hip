@@ -1058,7 +1058,9 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         for (int64_t v : per) mx = std::max(mx, v);
         segcap = std::max(segcap, mx + mx / 4 + 64);
     }
-    if (ctx->have_material && d.R > 0 && !ctx->h_enter_prob.empty()) segcap = std::max(segcap, segcap / 8 * 9) + 2 * nk_spawn_bound(ctx, (int)nseg) + 2 * NK_TILE;
+    const bool tight = getenv("NK_TIGHT_STORE") != nullptr;      // test hook: barely enough room, so that a growing ensemble halts soon
+    if (ctx->have_material && d.R > 0 && !ctx->h_enter_prob.empty())
+        segcap = (tight ? segcap : std::max(segcap, segcap / 8 * 9)) + (tight ? 1 : 2) * nk_spawn_bound(ctx, (int)nseg) + 2 * NK_TILE;
     segcap = ((segcap + 63) / 64) * 64;
     NK_ARG(nseg * segcap < (1ll << 31), "particle store too large for 32-bit slot arithmetic");
     d.segcap = (int32_t)segcap;
@@ -1179,7 +1181,8 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
         for (int64_t v : per) fits = fits && v + v / 16 <= room;
     }
     if (!fits) {                                       // forget old contents and size for 1.5 N
-        int rc = nk_alloc_particles(ctx, std::max(N + N / 2 + 65536, d.cap), mode, N);
+        const int64_t want = getenv("NK_TIGHT_STORE") ? N + N / 8 + 1024 : N + N / 2 + 65536;
+        int rc = nk_alloc_particles(ctx, std::max(want, d.cap), mode, N);
         if (rc) return rc;
     }
     int rc = nk_scatter(ctx, N, x, y, z, mode, occ, n_ts, facet, pid, pid_offset);

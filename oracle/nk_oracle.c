@@ -575,6 +575,13 @@ void nko_heat_flux(const nko_material *mat, const nko_subvols *sv, const nko_par
     }
 }
 
+/* Key of a particle's random draws when ids are not tracked (test infrastructure mirror of the engine's nk_state_key). */
+static uint64_t state_key(int32_t mode, const double *x) {
+    uint64_t k = (uint64_t)(uint32_t)mode, b;
+    for (int d = 0; d < 3; ++d) { memcpy(&b, x + d, 8); k = k * 0x9E3779B97F4A7C15ull + b; }
+    return k;
+}
+
 /* contains_check, Population.py:1712-1722 + Mesh.sample_volume, Mesh.py:890-904 */
 int64_t nko_contains_check(const nko_material *mat, const nko_mesh *mesh, const nko_params *p,
                            int64_t step, nko_particles *P) {
@@ -588,9 +595,10 @@ int64_t nko_contains_check(const nko_material *mat, const nko_mesh *mesh, const 
             if (x[d] < mesh->bbox[d] - 1e-10 || x[d] > mesh->bbox[3 + d] + 1e-10) out = 1;
         if (!out) continue;
         double u[6];
-        nko_uniform2(p->seed, P->pid[i], (uint32_t)step, TAG_RESAMP + 0, &u[0], &u[1]);
-        nko_uniform2(p->seed, P->pid[i], (uint32_t)step, TAG_RESAMP + 1, &u[2], &u[3]);
-        nko_uniform2(p->seed, P->pid[i], (uint32_t)step, TAG_RESAMP + 2, &u[4], &u[5]);
+        const uint64_t key = p->ids_from_state ? state_key(P->mode[i], x) : P->pid[i];
+        nko_uniform2(p->seed, key, (uint32_t)step, TAG_RESAMP + 0, &u[0], &u[1]);
+        nko_uniform2(p->seed, key, (uint32_t)step, TAG_RESAMP + 1, &u[2], &u[3]);
+        nko_uniform2(p->seed, key, (uint32_t)step, TAG_RESAMP + 2, &u[4], &u[5]);
         double acc = 0; int32_t s = mesh->nS - 1;
         for (int32_t k = 0; k < mesh->nS; ++k) { acc += mesh->simplex_vol[k] / tot; if (u[0] < acc) { s = k; break; } }
         double a[4], asum = 0;

@@ -108,6 +108,8 @@ typedef struct {
     int32_t T_ref_local;     /* 1 = 'local' */
     double T_ref;
     uint64_t seed;
+    int32_t ids_from_state;  /* 1: the resampling draws of contains_check are keyed on the particle's state (mode and the bits
+                              * of its position) instead of its id -- the engine's rule when it does not track ids */
 } nko_params;
 
 /* Particle arrays in the reference's own layout (Population.py:199-321). */

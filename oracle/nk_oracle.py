@@ -57,7 +57,7 @@ class Rough(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [('dt', C.c_double), ('norm_fixed', C.c_int32), ('particle_density', C.c_double),
-                ('T_ref_local', C.c_int32), ('T_ref', C.c_double), ('seed', C.c_uint64)]
+                ('T_ref_local', C.c_int32), ('T_ref', C.c_double), ('seed', C.c_uint64), ('ids_from_state', C.c_int32)]
 
 
 class Particles(C.Structure):
@@ -228,8 +228,9 @@ def make_rough(facets, specularity, true_spec, spec_map, roulette, degen_j2=None
     return r
 
 
-def make_params(dt=1.0, norm_fixed=False, particle_density=0.0, T_ref=None, seed=0):
+def make_params(dt=1.0, norm_fixed=False, particle_density=0.0, T_ref=None, seed=0, ids_from_state=False):
     p = Params()
+    p.ids_from_state = int(bool(ids_from_state))
     p.dt = dt
     p.norm_fixed = int(norm_fixed)
     p.particle_density = particle_density

@@ -1,0 +1,156 @@
+"""More parity of the HIP engine against the CPU oracle: the branches short runs never reach -- contains_check with
+escaped particles (Population.py:1712-1722, Mesh.py:890-904), runs across the 100-step bookkeeping boundaries, a store
+that must grow by itself, temperature ranges beyond the packed tables, an STL-imported 5000-triangle wire, and the
+configuration that tracks no particle ids.  Needs a real MI355X: run with `pytest -m gpu`."""
+import os
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from util import rel_err, case_tables, random_population, make_oracle_sim, make_engine
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+
+
+def compare_by_pid(p, sim, pos_atol=1e-8):
+    n = sim.P.N
+    assert p['pid'].shape[0] == n
+    o1, o2 = np.argsort(p['pid']), np.argsort(sim.P.pid[:n])
+    assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
+    assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
+    assert np.array_equal(p['facet'][o1], sim.P.facet[:n][o2])
+    assert np.allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=pos_atol)
+    assert np.allclose(p['n_timesteps'][o1], sim.P.n_ts[:n][o2], rtol=1e-9, atol=1e-9)
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+
+
+def compare_by_state(p, sim):
+    """Without ids: the two ensembles as multisets, lined up by (mode, x, y, z)."""
+    n = sim.P.N
+    assert p['mode'].shape[0] == n and not p['pid'].any()
+    o1 = np.lexsort((p['positions'][:, 2], p['positions'][:, 1], p['positions'][:, 0], p['mode']))
+    q = sim.P.pos[:n]
+    o2 = np.lexsort((q[:, 2], q[:, 1], q[:, 0], sim.P.mode[:n]))
+    assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
+    assert np.array_equal(p['facet'][o1], sim.P.facet[:n][o2])
+    assert np.allclose(p['positions'][o1], q[o2], rtol=1e-10, atol=1e-8)
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+
+
+def steps_agree(eng, sim, nsteps, chunk=50):
+    done = 0
+    while done < nsteps:
+        k = min(chunk, nsteps - done)
+        t = eng.step(k)
+        for s in range(k):
+            sim.run_timestep()
+            assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % (done + s)
+            assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % (done + s)
+        done += k
+
+
+@pytest.mark.parametrize('ids', [True, False])
+def test_contains_check_resamples_escapees(ids):
+    """Particles placed outside the bounding box: contains_check (step 0) draws them a new position in the volume
+    (simplex by volume, Dirichlet weights) and a new first boundary; with and without particle ids (then the draws are
+    keyed on the particle's state, in engine and oracle alike)."""
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 30000, seed=21)
+    b = ct['mesh']['bounds']
+    rng = np.random.default_rng(2)
+    esc = rng.choice(30000, 700, replace=False)
+    pos[esc] += (rng.integers(0, 2, (700, 3)) * 2 - 1) * (b[1] - b[0]) * rng.uniform(1.05, 3.0, (700, 3))
+    assert np.all(np.any((pos[esc] < b[0]) | (pos[esc] > b[1]), axis=1))
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=12, ids_from_state=not ids)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=12, track_ids=ids)
+    steps_agree(eng, sim, 3)
+    p = eng.download()
+    inside = np.all((p['positions'] >= b[0] - 1e-9) & (p['positions'] <= b[1] + 1e-9), axis=1)
+    assert inside.mean() > 0.999                       # the escapees are back (a resampled particle may sit on the hull)
+    (compare_by_pid if ids else compare_by_state)(p, sim)
+
+
+def test_without_ids_matches_oracle_multiset():
+    """The default layout of a mesh without rough facets stores no particle ids (44 bytes per particle): 40 steps of the
+    T T P box against the oracle, ensembles compared as multisets."""
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 30000, seed=5)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=77)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=77, track_ids=False)
+    steps_agree(eng, sim, 40)
+    compare_by_state(eng.download(), sim)
+
+
+@pytest.mark.parametrize('case', ['ttrrp', 'wire72'])
+def test_long_run_vs_oracle(case):
+    """260 steps: across two contains_check / bookkeeping boundaries (steps 100, 200), 26 heat-flux tallies, and, for the
+    wire, the face-tree ray caster with rough walls.  Engine and oracle step for step, then particle for particle."""
+    if case == 'ttrrp':
+        ct = case_tables('ttrrp')
+        pos, mode, occ, counter = random_population(ct, 30000, seed=31)
+    else:
+        from util import case_from_args, population_in_mesh
+        from test_gpu_parity import EXTRA_CASES, COMMON_ARGS
+        argv, species = EXTRA_CASES['wire72']
+        ct = case_from_args(argv + COMMON_ARGS, species)
+        pos, mode, occ, counter = population_in_mesh(ct, 30000, seed=31)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=2024, cap=200000)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=2024)
+    steps_agree(eng, sim, 260, chunk=65)               # chunks that do not line up with the 100-step boundaries
+    compare_by_pid(eng.download(), sim)
+
+
+def test_store_grows_by_itself(monkeypatch):
+    """Six times the entry rate into a store with hardly any head room (NK_TIGHT_STORE): the ensemble outgrows it several
+    times over.  nk_step must stop before a step that could drop a particle, grow the segments on the device and carry
+    on -- the run equals the oracle's throughout."""
+    monkeypatch.setenv('NK_TIGHT_STORE', '1')
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 20000, seed=9)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=3, cap=600000, emit_scale=6.0)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=3, emit_scale=6.0)
+    slots0 = eng.timing()['slots']
+    steps_agree(eng, sim, 90, chunk=45)
+    tm = eng.timing()
+    assert tm['live'] > slots0 and tm['slots'] > slots0            # it did outgrow the first allocation
+    compare_by_pid(eng.download(), sim)
+
+
+def test_wide_temperature_range_vs_oracle():
+    """Reservoirs at 340 K and 290 K, start at 340 K: the subvolume temperatures sweep a range wider than the two grid
+    intervals packed into the mode records and further from the reference temperature of the precomputed exponentials
+    than their short series allows -- the full-table lifetime lookup, the general exponential and the rebuilds of the
+    records as the range moves must all agree with the oracle."""
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 30000, seed=41, T0=340.0)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=8, T0=340.0, res_T=[340.0, 290.0])
+    eng = make_engine(ct, pos, mode, occ, counter, seed=8, T0=340.0, res_T=[340.0, 290.0])
+    steps_agree(eng, sim, 120, chunk=30)
+    assert sim.T_sv.max() - sim.T_sv.min() > 8.0 and sim.T_sv.max() < 330.0
+    compare_by_pid(eng.download(), sim)
+
+
+def test_stl_wire_5000_faces_vs_oracle():
+    """BASELINE config 4's mesh -- the cylinder primitive with 1250 sides written as ASCII STL and imported again: 5000
+    triangles, 1250 rough facets, caps at 302 / 298 K -- at 1.5e5 particles against the oracle's brute-force ray casts."""
+    from util import case_from_args, population_in_mesh
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    tail = ['--subvolumes', 'slice', '20', '2', '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1',
+            '--bound_cond', 'T', 'T', 'R', '--bound_values', '302', '298', '5', '--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
+            '--temp_interp', 'linear', '--timestep', '1', '--energy_normal', 'mean', '--particles', 'total', '150000']
+    prim = initialise_parser().parse_args(['--geometry', 'cylinder', '--dimensions', '2000', '200', '1250'] + tail)
+    prim.results_folder = ''
+    g0 = Geometry(prim)
+    tmp = tempfile.mkdtemp()
+    g0.mesh.export_stl('wire', tmp)
+    ct = case_from_args(['--geometry', os.path.join(tmp, 'wire.stl'), '--dimensions', '1', '1', '1'] + tail)
+    assert ct['mesh']['face_normals'].shape[0] == 5000 and ct['rough']['facets'].shape[0] == 1250
+    pos, mode, occ, counter = population_in_mesh(ct, 150000, seed=13)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=99, cap=400000)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=99)
+    steps_agree(eng, sim, 10)
+    compare_by_pid(eng.download(), sim)

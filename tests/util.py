@@ -90,7 +90,8 @@ def random_population(ct, n, seed, T0=298.0):
     return pos, mode, occ, counter
 
 
-def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=298.0, emit_scale=1.0, gen=0):
+def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=298.0, emit_scale=1.0, gen=0,
+                    ids_from_state=False, res_T=None):
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
     import nk_oracle as O
@@ -100,7 +101,7 @@ def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=29
     itp, rbf = sv_interp_of(ct, kind, interp)
     sv = O.make_subvols(ct['centers'], ct['volumes'], kind, ct['axis'], itp, rbf=rbf)
     ep = ct['enter_prob'] * emit_scale
-    res = O.make_reservoirs(ct['res_facets'], ct['res_T'], ep, counter.copy(), gen=gen,
+    res = O.make_reservoirs(ct['res_facets'], ct['res_T'] if res_T is None else np.asarray(res_T, dtype=float), ep, counter.copy(), gen=gen,
                             n_leaving=(first_n_leaving(ep) if gen == 2 else None))
     if ct['rough'] is not None:
         r = ct['rough']
@@ -109,7 +110,7 @@ def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=29
     else:
         z = np.zeros(0)
         rough = O.make_rough(np.zeros(0, dtype=np.int32), z, np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32), z)
-    par = O.make_params(dt=1.0, particle_density=ct['particle_density'], seed=seed)
+    par = O.make_params(dt=1.0, particle_density=ct['particle_density'], seed=seed, ids_from_state=ids_from_state)
     n = pos.shape[0]
     store = O.ParticleStore(cap or (2 * n + 4096))
     store.load(pos, mode, occ)
@@ -134,7 +135,7 @@ def first_n_leaving(enter_prob):
 
 
 def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scale=1.0, flux_every=10,
-                contains_every=100, device=0, gen=0, pid_offset=0, comm=None, track_ids=True):
+                contains_every=100, device=0, gen=0, pid_offset=0, comm=None, track_ids=True, res_T=None):
     """track_ids=True: the engine keeps the 64-bit particle ids also where nothing draws random numbers per particle, so that
     its particles can be matched with the oracle's one by one."""
     from nanokappa_amd.engine import Engine
@@ -145,7 +146,7 @@ def make_engine(ct, pos, mode, occ, counter, seed, interp=1, T0=298.0, emit_scal
     itp, rbf = sv_interp_of(ct, kind, interp)
     eng.set_subvolumes(ct['centers'], ct['volumes'], kind, ct['axis'], itp, np.full(ct['centers'].shape[0], T0), rbf=rbf)
     ep = ct['enter_prob'] * emit_scale
-    eng.set_reservoirs(ct['res_facets'], ct['res_T'], ep, counter, gen=gen,
+    eng.set_reservoirs(ct['res_facets'], ct['res_T'] if res_T is None else np.asarray(res_T, dtype=float), ep, counter, gen=gen,
                        n_leaving=(first_n_leaving(ep) if gen == 2 else None))
     if ct['rough'] is not None:
         r = ct['rough']
