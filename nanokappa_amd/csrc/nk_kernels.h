@@ -33,6 +33,18 @@
 #include "nk_device.h"
 
 #define NK_TILE 64           // particles per tile = lanes of a wave
+// NK_NT=1 builds the sweep's particle loads / stores as non-temporal accesses (developer comparison; measured SLOWER on
+// MI355X: k_sweep 0.29-0.32 ms against 0.263-0.267 ms with plain accesses at 1e7 particles, profiles/r02_notes.txt).
+#ifndef NK_NT
+#define NK_NT 0
+#endif
+#if NK_NT
+#define NK_LD(p) __builtin_nontemporal_load(p)
+#define NK_ST(p, v) __builtin_nontemporal_store(v, p)
+#else
+#define NK_LD(p) (*(p))
+#define NK_ST(p, v) (*(p) = (v))
+#endif
 // Developer build (make stamps -> libnanokappa_hip_stamps.so, env NK_STAMPS=1): s_memtime stamps around the sections of
 // the sweep's tile loop, summed per wave; shares only (the stamps' waits forbid overlaps the real kernel has).
 #ifdef NK_STAMPS
@@ -504,8 +516,8 @@ struct NkOut {
                 const int o = wout + rank;
                 if (o < d.segcap) {
                     const int64_t i = base + o;
-                    d.x[i] = px; d.y[i] = py; d.z[i] = pz; d.occ[i] = pocc; d.nts[i] = pnts; d.w0[i] = pw0;
-                    if (PID) d.pid[i] = ppid;
+                    NK_ST(d.x + i, px); NK_ST(d.y + i, py); NK_ST(d.z + i, pz); NK_ST(d.occ + i, pocc); NK_ST(d.nts + i, pnts); NK_ST(d.w0 + i, pw0);
+                    if (PID) NK_ST(d.pid + i, ppid);
                 } else atomicOr(d.overflow, 2);     // segment full
             }
             wout += n;
@@ -593,8 +605,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
         unsigned long long pidN = 0;
         if (lane < count) {
             const int64_t i = base + lane;
-            w0N = d.w0[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
-            if (PID) pidN = d.pid[i];
+            w0N = NK_LD(d.w0 + i); xN = NK_LD(d.x + i); yN = NK_LD(d.y + i); zN = NK_LD(d.z + i); occN = NK_LD(d.occ + i); ntsN = NK_LD(d.nts + i);
+            if (PID) pidN = NK_LD(d.pid + i);
         }
         for (int t = 0; t <= nA; ++t) {
             const bool flush = t == nA;               // one empty tile: drains the carry
@@ -609,8 +621,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 w0 = w0N; x = xN; y = yN; z = zN; occ = occN; nts = ntsN; pid = pidN;
                 if (r + NK_TILE + lane < count) {
                     const int64_t i = base + r + NK_TILE + lane;
-                    w0N = d.w0[i]; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; occN = d.occ[i]; ntsN = d.nts[i];
-                    if (PID) pidN = d.pid[i];
+                    w0N = NK_LD(d.w0 + i); xN = NK_LD(d.x + i); yN = NK_LD(d.y + i); zN = NK_LD(d.z + i); occN = NK_LD(d.occ + i); ntsN = NK_LD(d.nts + i);
+                    if (PID) pidN = NK_LD(d.pid + i);
                 }
                 const bool newborn = (w0 & NK_NEWBORN) != 0u;
                 w0 &= ~NK_NEWBORN;
