@@ -319,11 +319,14 @@ def main():
         live_rank = tm['live'] / world if world > 1 else tm['live']
         k_ms = float(np.median([r['tm']['step_kernel_ms'] for r in runs]))
         achieved = BYTES_PER_PHONON_STEP * live_rank / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # written by scripts/profile_round.sh from a PMC pass
+        # HBM bytes of one k_sweep launch from the PMC counters: they cannot be collected inside this run (rocprofv3 wraps the
+        # process), so the line carries the committed figure of the round's profile of this same command and says so
+        traffic, traffic_source = None, None
+        tf = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')     # written from scripts/profile_round.sh's PMC passes
         if os.path.exists(tf) and world == 1 and a.config == 'c2' and int(per_gpu) == 10000000 and a.mesh_n == 31:
             try:
-                traffic = json.load(open(tf)).get('k_sweep_hbm_bytes_per_launch')
+                tj = json.load(open(tf))
+                traffic, traffic_source = tj.get('k_sweep_hbm_bytes_per_launch'), tj.get('source')
             except Exception:
                 traffic = None
         ms = [1e3 * r['elapsed'] / a.steps for r in runs]
@@ -338,7 +341,7 @@ def main():
                                    % (species, a.mesh_n, desc, per_gpu, a.config),
                        'particles_total': total, 'live_particles_end': tm['live'], 'parallelism': 'particle-shard x%d' % world},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': 'k_sweep', 'kernel_ms': k_ms, 'emit_count_kernel_ms': tm['emit_kernel_ms'],
                          'reduce_update_ms': tm['events_kernel_ms'], 'stream_ms_per_step': tm['total_ms'] / a.steps,
                          'frac_whole_step': BYTES_PER_PHONON_STEP * value / 1e9 / HBM_PEAK_GBS / max(world, 1),
