@@ -153,8 +153,14 @@ struct NkDev {
     // ---- bookkeeping words in device memory
     int32_t *ticket;                  // arrival counter of k_reduce's workgroups (the last one runs the update)
     int32_t *overflow;                // set when a particle had to be dropped for lack of capacity
-    int32_t *halt;                    // set by a sweep whose segments could overflow at the NEXT step: later steps of the same
-                                      // nk_step call do nothing, so the host can grow the store with the state intact
+    int32_t *halt;                    // [0] set (by the update, at the end of a step) when a sweep saw a segment that could
+                                      // overflow at the NEXT step: later steps of the same nk_step call do nothing, so the host can
+                                      // grow the store with the state intact; [1] the sweep's request; [2] k_deliver could not place
+                                      // a segment's migrants (they wait in its inbox); [3] an inbox is more than half full
+    // ---- migration (rough facets: a reflection changes a particle's mode, hence the segment that owns it)
+    double2 *mig_buf;                 // [nseg * mig_cap * 4] 64-byte records {x, y} {z, occ} {nts, pid} {w0, -, -, -}
+    int32_t *mig_n;                   // [nseg] records waiting in each segment's inbox (k_deliver empties them every step)
+    int32_t mig_cap;
     double *partials;                 // [rows][NB] per-workgroup tally rows
     int32_t NB;                       // bins per row = 5*S + 5*R + 1
     unsigned long long *stamps;       // developer build NK_STAMPS (make stamps): per-wave cycle sums of the sweep's sections
@@ -699,27 +705,48 @@ __device__ __forceinline__ void nk_reflect(const NkDev &d, const NkSvTab &tb, in
                                            double cx, double cy, double cz, double n_in, double omega_in, double E0_in,
                                            double r_spec, double r_deg, double r_diff, int &mode_out, double &n_out,
                                            double &omega_out, double &E0_out) {
-    int64_t idx = (int64_t)rough_idx * d.M + mode_in;
-    bool spec = d.true_spec[idx] && (r_spec <= d.specularity[idx]);
+    // Every table read that does not depend on another one is issued up front, for both outcomes: the event pass is a chain
+    // of memory round trips, and a load inside the branch it feeds only starts once the branch is resolved.
+    const int64_t idx = (int64_t)rough_idx * d.M + mode_in;
+    const int nlut = d.roul_nlut;
+    int kb = (int)(r_diff * (double)nlut);
+    kb = kb < 0 ? 0 : (kb > nlut - 1 ? nlut - 1 : kb);
+    const int32_t *lut = d.roul_lut + (int64_t)rough_idx * (nlut + 1);
+    const double *roul = d.roulette + (int64_t)rough_idx * d.M;
+    const uint8_t ts = d.true_spec[idx];
+    const double sp = d.specularity[idx];
+#ifndef NK_REFLECT_LAZY
+    const int smap = d.spec_map[idx];
+    const int lo = lut[kb], hi = lut[kb + 1];
+    const double rlast = roul[d.M - 1];
+#endif
+    const bool spec = ts && (r_spec <= sp);
     if (spec) {
-        int out = d.spec_map[idx];
+#ifdef NK_REFLECT_LAZY
+        const int smap = d.spec_map[idx];
+#endif
+        int out = smap;
         if (d.degen_j2) {
             int j2 = d.degen_j2[out];
             if (j2 > -1 && r_deg >= 0.5) out = (out / d.J) * d.J + j2;
         }
         mode_out = out; n_out = n_in; omega_out = omega_in; E0_out = E0_in;
     } else {
-        const double *roul = d.roulette + (int64_t)rough_idx * d.M;
-        double r = r_diff * roul[d.M - 1];
-        // np.searchsorted(roulette, r) (Population.py:1005) through a bucket index: r_diff in [k, k+1) / roul_nlut brackets
-        // the answer between two precomputed positions about four entries apart, so the bisection is a chain of ~2
-        // dependent global loads instead of ~18 over the whole table; same result
-        const int nlut = d.roul_nlut;
-        int kb = (int)(r_diff * (double)nlut);
-        kb = kb < 0 ? 0 : (kb > nlut - 1 ? nlut - 1 : kb);
-        const int32_t *lut = d.roul_lut + (int64_t)rough_idx * (nlut + 1);
+#ifdef NK_REFLECT_LAZY
         const int lo = lut[kb], hi = lut[kb + 1];
-        int flat = lo + nk_ss_left(roul + lo, hi - lo, r);
+        const double rlast = roul[d.M - 1];
+#endif
+        const double r = r_diff * rlast;
+        // np.searchsorted(roulette, r) (Population.py:1005) through a bucket index: r_diff in [k, k+1) / roul_nlut brackets
+        // the answer between two precomputed positions a few entries apart; up to four of them are read in one go (same
+        // result as the bisection over the whole table, one memory round trip instead of ~18)
+        int flat;
+        if (hi - lo <= 4) {
+            const double a0 = lo + 0 < hi ? roul[lo + 0] : __builtin_inf(), a1 = lo + 1 < hi ? roul[lo + 1] : __builtin_inf(),
+                         a2 = lo + 2 < hi ? roul[lo + 2] : __builtin_inf(), a3 = lo + 3 < hi ? roul[lo + 3] : __builtin_inf();
+            flat = lo + (a0 < r ? 1 : 0) + (a1 < r ? 1 : 0) + (a2 < r ? 1 : 0) + (a3 < r ? 1 : 0);     // sorted: count of entries < r
+            if (flat > hi) flat = hi;
+        } else flat = lo + nk_ss_left(roul + lo, hi - lo, r);
         if (flat > d.M - 1) flat = d.M - 1;
         mode_out = flat;
         omega_out = d.modetab[flat].omega;

@@ -56,6 +56,7 @@ struct nk_ctx {
     NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
     int64_t modetab_p_len = 0;
     void *inbox = nullptr, *inbox_n = nullptr;   // 'one_to_one' spawn inboxes (sized with nseg)
+    void *mig_buf = nullptr, *mig_n = nullptr;   // migration inboxes (rough facets; sized with nseg and segcap)
     double *ep_p = nullptr, *rc_p = nullptr;     // (reservoir, mode) tables in the segments' order (sized with nseg)
     int rm_nseg = 0;                             // segmentation rc_p was built for (0: the counters live in res_counter)
     double *acc = nullptr;         // [NB + 1]
@@ -226,17 +227,17 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.stamps = nullptr;
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
-    // bookkeeping words in device memory: halt[2], overflow, ticket
+    // bookkeeping words in device memory: halt[4], overflow, ticket
     const int32_t *p32 = nullptr;
     int rc;
-    if ((rc = nk_upload<int32_t>(ctx, nullptr, 8, &p32))) {
+    if ((rc = nk_upload<int32_t>(ctx, nullptr, 16, &p32))) {
         g_create_error = ctx->err;
         delete ctx;
         return rc;
     }
     ctx->d.halt = (int32_t *)p32;
-    ctx->d.overflow = (int32_t *)p32 + 2;
-    ctx->d.ticket = (int32_t *)p32 + 3;
+    ctx->d.overflow = (int32_t *)p32 + 4;
+    ctx->d.ticket = (int32_t *)p32 + 5;
     *out = ctx;
     return NK_OK;
 }
@@ -258,6 +259,8 @@ void nk_destroy(nk_ctx *ctx) {
     if (ctx->modetab_p) hipFree(ctx->modetab_p);
     if (ctx->inbox) hipFree(ctx->inbox);
     if (ctx->inbox_n) hipFree(ctx->inbox_n);
+    if (ctx->mig_buf) hipFree(ctx->mig_buf);
+    if (ctx->mig_n) hipFree(ctx->mig_n);
     if (ctx->ep_p) hipFree(ctx->ep_p);
     if (ctx->rc_p) hipFree(ctx->rc_p);
     hipStreamDestroy(ctx->stream);
@@ -982,10 +985,10 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
     return NK_OK;
 }
 
-// Does this configuration draw random numbers per particle (then ids are tracked), and does a particle's mode change
-// (then the modes cannot be partitioned over the segments)?
+// Does this configuration draw random numbers per particle (then ids are tracked)?  Are the modes partitioned over the
+// segments (always, but for a developer probe; with rough facets a particle whose mode changed migrates, k_deliver)?
 static inline bool nk_want_pid(const nk_ctx *ctx) { return ctx->d.Fr > 0 || ctx->params.track_ids != 0; }
-static inline bool nk_want_part(const nk_ctx *ctx) { return ctx->d.Fr == 0 && !getenv("NK_NO_PARTITION"); }   // env: developer probe
+static inline bool nk_want_part(const nk_ctx *ctx) { return !getenv("NK_NO_PARTITION"); }   // env: developer probe
 
 // Persistent grid of the sweep = what the device keeps resident of the instantiation this configuration uses (before the
 // tables are known: four workgroups per CU, the common case).
@@ -1087,7 +1090,27 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     if (ctx->inbox) { hipFree(ctx->inbox); ctx->inbox = nullptr; }
     if (ctx->inbox_n) { hipFree(ctx->inbox_n); ctx->inbox_n = nullptr; }
     d.sp_inbox = nullptr; d.sp_inbox_n = nullptr; d.sp_icap = 0;
+    if (ctx->mig_buf) { hipFree(ctx->mig_buf); ctx->mig_buf = nullptr; }
+    if (ctx->mig_n) { hipFree(ctx->mig_n); ctx->mig_n = nullptr; }
+    d.mig_buf = nullptr; d.mig_n = nullptr; d.mig_cap = 0;
     return nk_entry_tables_build(ctx);
+}
+
+// Rough facets with partitioned modes: per-segment inboxes of 64-byte records for the particles that change segment
+// (`cap` records each; 0 = half a segment).  The inboxes are empty between steps, so resizing them loses nothing.
+static int nk_ensure_migration(nk_ctx *ctx, int64_t cap) {
+    NkDev &d = ctx->d;
+    if (!(d.Fr > 0 && d.part)) return NK_OK;
+    if (cap <= 0) cap = std::max<int64_t>(256, d.segcap / 2);
+    if (d.mig_buf && d.mig_cap >= cap) return NK_OK;
+    if (ctx->mig_buf) { hipFree(ctx->mig_buf); ctx->mig_buf = nullptr; }
+    if (ctx->mig_n) { hipFree(ctx->mig_n); ctx->mig_n = nullptr; }
+    d.mig_buf = nullptr; d.mig_n = nullptr; d.mig_cap = 0;
+    NK_HIP(hipMalloc(&ctx->mig_buf, (size_t)d.nseg * cap * 64));
+    NK_HIP(hipMalloc(&ctx->mig_n, (size_t)d.nseg * 4));
+    NK_HIP(hipMemset(ctx->mig_n, 0, (size_t)d.nseg * 4));
+    d.mig_buf = (double2 *)ctx->mig_buf; d.mig_n = (int32_t *)ctx->mig_n; d.mig_cap = (int32_t)cap;
+    return NK_OK;
 }
 
 // 'one_to_one': per-segment inboxes for the records of k_emit_one_to_one
@@ -1187,8 +1210,8 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     }
     int rc = nk_scatter(ctx, N, x, y, z, mode, occ, n_ts, facet, pid, pid_offset);
     if (rc) return rc;
-    int32_t zero5[5] = {0, 0, 0, 0, 0};
-    NK_HIP(hipMemcpy(d.halt, zero5, 20, hipMemcpyHostToDevice));     // halt[2], overflow, ticket, emitted
+    int32_t zero6[6] = {0, 0, 0, 0, 0, 0};
+    NK_HIP(hipMemcpy(d.halt, zero6, 24, hipMemcpyHostToDevice));     // halt[4], overflow, ticket
     ctx->pending_relax = false;
     return NK_OK;
 }
@@ -1303,6 +1326,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         } else {
             k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, 1);
         }
+        if (d.mig_buf) k_deliver<<<g_emit, NK_WG, 0, ctx->stream>>>(d);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
         pending = true;
         if ((s & 63) == 63) NK_HIP(hipGetLastError());
@@ -1355,6 +1379,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     NK_HIP(hipSetDevice(ctx->device));
     if ((rc = nk_update_tau_window(ctx, false))) return rc;
     if ((rc = nk_ensure_inbox(ctx))) return rc;
+    if ((rc = nk_ensure_migration(ctx, 0))) return rc;
     NkDev &d = ctx->d;
     const int S = d.S, R = d.R, NB = d.NB;
     const int HROW = NB + 2 * S + 4;
@@ -1396,18 +1421,36 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         }
         ctx->step += nd;
         s_out += nd;
-        if (s_out < nsteps) {
-            // halted: a segment could overflow at the next step.  Grow every segment by half (on the device, state intact)
-            // and carry on with the remaining steps.
+        int32_t hw[4] = {0, 0, 0, 0};
+        NK_HIP(hipMemcpy(hw, d.halt, 16, hipMemcpyDeviceToHost));
+        if (s_out < nsteps || hw[0] || hw[2] || hw[3]) {
+            // halted: a segment could overflow at the next step (or could not take its migrants, which then wait in its
+            // inbox).  Grow every segment by half (on the device, state intact), deliver, and carry on.
             if (++grown > 40) { ctx->err = "nk_step: the particle store keeps filling up"; return NK_ERR_CAPACITY; }
-            const int64_t need = (int64_t)d.segcap + d.segcap / 2 + 2 * nk_spawn_bound(ctx, d.nseg) + 2 * NK_TILE;
-            if ((rc = nk_regrow(ctx, need))) {
-                ctx->err = "particle store nearly full after step " + std::to_string((long long)ctx->step) +
-                           " and it could not be grown (" + ctx->err + "); the state is intact";
-                return NK_ERR_CAPACITY;
+            const bool only_inbox = hw[3] && !hw[0] && !hw[2] && s_out == nsteps;
+            if (!only_inbox) {
+                const int64_t need = (int64_t)d.segcap + d.segcap / 2 + 2 * nk_spawn_bound(ctx, d.nseg) + 2 * NK_TILE;
+                if ((rc = nk_regrow(ctx, need))) {
+                    ctx->err = "particle store nearly full after step " + std::to_string((long long)ctx->step) +
+                               " and it could not be grown (" + ctx->err + "); the state is intact";
+                    return NK_ERR_CAPACITY;
+                }
             }
-            int32_t zero2[2] = {0, 0};
-            NK_HIP(hipMemcpy(d.halt, zero2, 8, hipMemcpyHostToDevice));
+            int32_t zero4[4] = {0, 0, 0, 0};
+            NK_HIP(hipMemcpy(d.halt, zero4, 16, hipMemcpyHostToDevice));
+            if (hw[2]) {                                 // migrants that did not fit: they do now
+                k_deliver<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(d);
+                NK_HIP(hipGetLastError());
+                NK_HIP(hipStreamSynchronize(ctx->stream));
+                int32_t again[4];
+                NK_HIP(hipMemcpy(again, d.halt, 16, hipMemcpyDeviceToHost));
+                if (again[2]) { ctx->err = "nk_step: migrating particles do not fit their segment after growing it"; return NK_ERR_CAPACITY; }
+                NK_HIP(hipMemcpy(d.halt, zero4, 16, hipMemcpyHostToDevice));
+            }
+            if (d.mig_buf && (hw[3] || !only_inbox)) {   // inboxes follow the segments (or double when they ran half full)
+                const int64_t want = std::max<int64_t>(hw[3] ? 2 * (int64_t)d.mig_cap : 0, d.segcap / 2);
+                if ((rc = nk_ensure_migration(ctx, want))) return rc;
+            }
             if ((rc = nk_update_tau_window(ctx, false))) return rc;
         }
     }

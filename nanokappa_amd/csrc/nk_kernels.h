@@ -325,10 +325,12 @@ __device__ __forceinline__ double nk_push_d(int dst, double v) {      // every l
     const int hi = __builtin_amdgcn_ds_permute(dst << 2, __double2hiint(v));
     return __hiloint2double(hi, lo);
 }
-template <bool PID>
+template <bool PID, bool GM = false>
 struct NkCarry {
     double x, y, z, occ, nts, cts;     // cts: fraction of the step already consumed by earlier events
     uint32_t w0, evc;                  // evc: events so far in this step (numbers the RNG draws)
+    uint32_t gm;                       // GM (rough facets): the particle's GLOBAL mode -- a reflection may have moved it to a
+                                       // mode another segment owns, which the local index in w0 cannot express
     unsigned long long pid;
     __device__ __forceinline__ NkCarry pull(int src) const {
         NkCarry o;
@@ -336,6 +338,7 @@ struct NkCarry {
         o.nts = nk_pull_d(src, nts); o.cts = nk_pull_d(src, cts);
         o.w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)w0);
         o.evc = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)evc);
+        o.gm = GM ? (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)gm) : 0u;
         o.pid = 0;
         if (PID) o.pid = (unsigned long long)__double_as_longlong(nk_pull_d(src, __longlong_as_double((long long)pid)));
         return o;
@@ -346,6 +349,7 @@ struct NkCarry {
         o.nts = nk_push_d(dst, nts); o.cts = nk_push_d(dst, cts);
         o.w0 = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)w0);
         o.evc = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)evc);
+        o.gm = GM ? (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)gm) : 0u;
         o.pid = 0;
         if (PID) o.pid = (unsigned long long)__double_as_longlong(nk_push_d(dst, __longlong_as_double((long long)pid)));
         return o;
@@ -561,8 +565,15 @@ struct NkOut {
 #ifndef NK_SWEEP_OCC
 #define NK_SWEEP_OCC 3          // workgroups per CU the sweep is compiled for (3 x 4 waves = 3 waves per SIMD)
 #endif
+// Residency per instantiation: a register spilled inside the tile loop is reloaded through the same in-order memory queue
+// as the next tile's prefetch, so the reload waits for the prefetch (stamps: every section of the loop 2.5 x slower on the
+// rough box at 33 spilled VGPRs).  The variants that need more than 168 VGPRs therefore run two workgroups per CU without
+// spills rather than three with.
 template <int GEOM, bool ROUGH, bool RBF, bool PID>
-__global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
+#ifndef NK_SWEEP_OCC_G2
+#define NK_SWEEP_OCC_G2 2
+#endif
+__global__ __launch_bounds__(NK_WG, GEOM == 2 ? NK_SWEEP_OCC_G2 : ((ROUGH || RBF) ? 2 : NK_SWEEP_OCC)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
     NkLds L;
@@ -593,8 +604,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
         NkOut<PID> O;                                 // finished particles on their way back to the segment
         O.init(L, wave);
         int cn = 0;                                   // particles in the carry (lanes [0, cn))
-        NkCarry<PID> C;
-        C.x = C.y = C.z = C.occ = C.nts = C.cts = 0.0; C.w0 = 0u; C.evc = 0u; C.pid = 0ull;
+        NkCarry<PID, ROUGH> C;
+        C.x = C.y = C.z = C.occ = C.nts = C.cts = 0.0; C.w0 = 0u; C.evc = 0u; C.gm = 0u; C.pid = 0ull;
 #ifdef NK_STAMPS
         unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
@@ -654,8 +665,9 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
             NK_STAMP(2);
             // the tile's event particles, packed into lanes [po, po + pn) of P
             int pn = __popcll(mE), po = 0;
-            NkCarry<PID> P;
+            NkCarry<PID, ROUGH> P;
             P.x = x; P.y = y; P.z = z; P.occ = occ; P.nts = nts; P.cts = 0.0; P.w0 = w0; P.evc = 0u; P.pid = pid;
+            P.gm = (uint32_t)((int)(w0 & lbmask) * sm.mstride + sm.moff);
             if (pn > 0) P = P.push(ev ? __popcll(mE & lower) : pn + __popcll(~mE & lower));
             // ---- drain (Population.py:1546-1683): fill the carry; whenever it is full (or on the last, empty tile) one
             // boundary event per particle; finished particles are tallied and appended, absorbed ones vanish, the few that
@@ -663,7 +675,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
             while (pn > 0 || (flush && cn > 0)) {
                 if (pn > 0) {
                     const int k = pn < 64 - cn ? pn : 64 - cn;
-                    const NkCarry<PID> Q = P.pull((po + lane - cn) & 63);
+                    const NkCarry<PID, ROUGH> Q = P.pull((po + lane - cn) & 63);
                     if (lane >= cn && lane < cn + k) C = Q;
                     cn += k; po += k; pn -= k;
                 }
@@ -676,16 +688,35 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
                 int st = NK_EV_DEAD;
                 p.x = C.x; p.y = C.y; p.z = C.z; p.occ = C.occ; p.nts = C.nts;
                 const int idx0 = eact ? (int)(C.w0 & lbmask) : 0;
-                if (use_lrec) {
-                    const double4 ra = lrec[2 * idx0];
-                    p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
-                    p.E0 = reinterpret_cast<const double *>(lrec)[8 * idx0 + 4];
+                if (ROUGH) {                              // the carried particle may be in a mode another segment owns
+                    p.mode = eact ? (int)C.gm : sm.moff;
+                    const uint32_t q = (uint32_t)p.mode / (uint32_t)sm.mstride;
+#ifndef NK_PASS_LDS_REC          // (records from LDS for the lanes whose mode is ours: measured SLOWER, 0.69 against 0.54 ms on the rough box)
+                    if (false) {
+#else
+                    if (use_lrec && (int)((uint32_t)p.mode - q * (uint32_t)sm.mstride) == sm.moff) {
+#endif
+                        const double4 ra = lrec[2 * q];
+                        p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                        p.E0 = reinterpret_cast<const double *>(lrec)[8 * q + 4];
+                    } else {
+                        const NkMode *rec = d.modetab + p.mode;
+                        const double4 ra = *reinterpret_cast<const double4 *>(rec);
+                        p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                        p.E0 = rec->E0;
+                    }
                 } else {
-                    const double4 ra = *reinterpret_cast<const double4 *>(sm.rec + idx0);
-                    p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
-                    p.E0 = sm.rec[idx0].E0;
+                    if (use_lrec) {
+                        const double4 ra = lrec[2 * idx0];
+                        p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                        p.E0 = reinterpret_cast<const double *>(lrec)[8 * idx0 + 4];
+                    } else {
+                        const double4 ra = *reinterpret_cast<const double4 *>(sm.rec + idx0);
+                        p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                        p.E0 = sm.rec[idx0].E0;
+                    }
+                    p.mode = idx0 * sm.mstride + sm.moff;
                 }
-                p.mode = idx0 * sm.mstride + sm.moff;
                 p.facet = (int)(C.w0 >> d.lb) - 1;
                 if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, C.pid, step);
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
@@ -694,12 +725,31 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_OCC) void k_sweep(NkDev d, uint32_t
 #endif
                 NK_STAMP(4);
                 if (alive) nk_tally_one(d, L.tb, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.E0, p.vx, p.vy, p.vz, do_flux, rep);
-                const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | (uint32_t)(ROUGH ? (d.part ? p.mode / d.nseg : p.mode) : idx0);
-                const unsigned long long mA = __ballot(alive), mM = __ballot(more);
-                O.push(d, base, lane, alive, __popcll(mA & lower), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0e, C.pid);
+                // the particle's segment after the event: a reflection may have handed it to another one
+                bool stay = true;
+                uint32_t idxe = (uint32_t)idx0;
+                if (ROUGH) {
+                    if (d.part) { const uint32_t q = (uint32_t)p.mode / (uint32_t)d.nseg; stay = (int)((uint32_t)p.mode - q * (uint32_t)d.nseg) == seg; idxe = q; }
+                    else idxe = (uint32_t)p.mode;
+                }
+                const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
+                const bool home = alive && stay, away = alive && !stay;
+                const unsigned long long mA = __ballot(home), mM = __ballot(more);
+                O.push(d, base, lane, home, __popcll(mA & lower), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0e, C.pid);
+                if (ROUGH && away) {                       // one 64-byte record into the inbox of the segment that owns the new mode
+                    const int dst = (int)((uint32_t)p.mode - idxe * (uint32_t)d.nseg);
+                    const int at = atomicAdd(d.mig_n + dst, 1);
+                    if (at < d.mig_cap) {
+                        double2 *r = d.mig_buf + ((int64_t)dst * d.mig_cap + at) * 4;
+                        r[0] = make_double2(p.x, p.y); r[1] = make_double2(p.z, p.occ);
+                        r[2] = make_double2(p.nts, __longlong_as_double((long long)C.pid));
+                        r[3] = make_double2(__longlong_as_double((long long)w0e), 0.0);
+                    } else atomicOr(d.overflow, 32);      // inbox full: the particle is lost (k_deliver asks for larger inboxes long before)
+                }
                 cn = __popcll(mM);
                 if (cn > 0) {
                     C.x = p.x; C.y = p.y; C.z = p.z; C.occ = p.occ; C.nts = p.nts; C.cts = cts; C.w0 = w0e; C.evc = evc;
+                    C.gm = (uint32_t)p.mode;
                     C = C.push(more ? __popcll(mM & lower) : cn + __popcll(~mM & lower));
                 }
                 NK_STAMP(5);
@@ -739,6 +789,37 @@ __global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkDev n) {
             if (o.pid && n.pid) n.pid[b + i] = o.pid[a + i];
         }
         if (threadIdx.x == 0) n.seg_count[seg] = cnt;
+    }
+}
+
+// Rough facets: the particles whose reflection moved them to a mode of another segment wait in that segment's inbox; after
+// the step's update they are appended to the segment (one wave per segment, coalesced stores).  A segment that cannot
+// take its migrants keeps them in the inbox and raises the halt word: the host grows the store and delivers again.
+__global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * (NK_WG / 64);
+    for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
+        int n = d.mig_n[seg];
+        if (n <= 0) continue;
+        if (n > d.mig_cap) n = d.mig_cap;
+        const int count = d.seg_count[seg];
+        if (count + n > d.segcap) { if (lane == 0) { atomicOr(d.halt + 2, 1); atomicOr(d.halt, 1); } continue; }
+        const int64_t base = (int64_t)seg * d.segcap + count;
+        for (int j = lane; j < n; j += 64) {
+            const double2 *r = d.mig_buf + ((int64_t)seg * d.mig_cap + j) * 4;
+            const double2 a = r[0], b = r[1], c = r[2], e = r[3];
+            d.x[base + j] = a.x; d.y[base + j] = a.y; d.z[base + j] = b.x; d.occ[base + j] = b.y; d.nts[base + j] = c.x;
+            d.pid[base + j] = (uint64_t)__double_as_longlong(c.y);
+            d.w0[base + j] = (uint32_t)__double_as_longlong(e.x);
+        }
+        if (lane == 0) {
+            d.seg_count[seg] = count + n;
+            d.mig_n[seg] = 0;
+            // room for the next step: its emission and about as many migrants again
+            const int bound = d.R > 0 ? d.seg_bound[seg] : 0;
+            if ((int64_t)count + n + bound + 2 * n + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt, 1);
+            if (2 * n > d.mig_cap) atomicOr(d.halt + 3, 1);
+        }
     }
 }
 
