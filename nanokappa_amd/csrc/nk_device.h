@@ -157,6 +157,12 @@ struct NkDev {
                                       // overflow at the NEXT step: later steps of the same nk_step call do nothing, so the host can
                                       // grow the store with the state intact; [1] the sweep's request; [2] k_deliver could not place
                                       // a segment's migrants (they wait in its inbox); [3] an inbox is more than half full
+    // ---- event queues (split sweep, large meshes): the particles that meet a boundary inside the step, per segment, in
+    // arrays of their own with the segments' geometry; k_events works them off at a residency the fused sweep cannot reach
+    double *qx, *qy, *qz, *qocc, *qnts;
+    uint32_t *qw0;
+    uint64_t *qpid;
+    int32_t *seg_evq;                 // [nseg] entries in each segment's queue
     // ---- migration (rough facets: a reflection changes a particle's mode, hence the segment that owns it)
     double2 *mig_buf;                 // [nseg * mig_cap * 4] 64-byte records {x, y} {z, occ} {nts, pid} {w0, -, -, -}
     int32_t *mig_n;                   // [nseg] records waiting in each segment's inbox (k_deliver empties them every step)
@@ -635,6 +641,7 @@ __device__ __forceinline__ int nk_tree_skip(const NkDev &d, int facet, double cx
 }
 __device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, int skip, double x, double y, double z, double vx,
                                                       double vy, double vz, double &tc, int &fc) {
+    const float *boxes = d.tree_boxes;
     NkHit h = {__builtin_inf(), 0x7fffffff, -1};
     const NkRayF rf = nk_ray_f32(x, y, z, vx, vy, vz, d.tree_bound);
     const int top = d.tree_top, NL = d.tree_leaves;
@@ -653,7 +660,7 @@ __device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, int skip, 
 #pragma unroll
             for (int k = 1; k < NK_TREE_LEVELS; ++k) base = (l == k) ? d.tree_base[k] : base;
             const int cnt = (NL + (1 << (2 * l)) - 1) >> (2 * l);
-            const float4 *B = reinterpret_cast<const float4 *>(d.tree_boxes + (size_t)((base >> 2) + fam) * NK_TREE_FAMILY_FLOATS);
+            const float4 *B = reinterpret_cast<const float4 *>(boxes + (size_t)((base >> 2) + fam) * NK_TREE_FAMILY_FLOATS);
             float4 b[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) b[k] = B[k];

@@ -117,15 +117,25 @@ static inline size_t nk_lds(const nk_ctx *ctx, bool geom, int kind = 0) {
         else kernel<2><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);                                \
     } while (0)
 static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
-// The sweep is instantiated per (table placement, rough facets, RBF temperatures, particle ids): run STMT with KERNEL bound
-// to the one that matches.  Rough facets draw random numbers per particle, so they imply ids.
-#define NK_SWEEP_CASE(G, R, B, P, STMT) { auto KERNEL = k_sweep<G, R, B, P>; STMT; }
-#define NK_SWEEP_CASE_RP(G, B, rough, pid, STMT)                                                      \
-    { if (rough) NK_SWEEP_CASE(G, true, B, true, STMT) else if (pid) NK_SWEEP_CASE(G, false, B, true, STMT) else NK_SWEEP_CASE(G, false, B, false, STMT) }
-#define NK_SWEEP_DISPATCH(gm, rough, rbf, pid, STMT)                                                  \
+// The sweep is instantiated per (table placement, rough facets, RBF temperatures, particle ids, split): run STMT with
+// KERNEL bound to the one that matches.  Rough facets draw random numbers per particle, so they imply ids.
+#define NK_SWEEP_CASE(G, R, B, P, S, STMT) { auto KERNEL = k_sweep<G, R, B, P, S>; STMT; }
+#define NK_SWEEP_CASE_S(G, R, B, P, split, STMT) { if (split) NK_SWEEP_CASE(G, R, B, P, true, STMT) else NK_SWEEP_CASE(G, R, B, P, false, STMT) }
+#define NK_SWEEP_CASE_RP(G, B, rough, pid, split, STMT)                                               \
+    { if (rough) NK_SWEEP_CASE_S(G, true, B, true, split, STMT) else if (pid) NK_SWEEP_CASE_S(G, false, B, true, split, STMT) else NK_SWEEP_CASE_S(G, false, B, false, split, STMT) }
+#define NK_SWEEP_DISPATCH(gm, rough, rbf, pid, split, STMT)                                           \
     do {                                                                                               \
-        if ((gm) == 1) { if (rbf) NK_SWEEP_CASE_RP(1, true, rough, pid, STMT) else NK_SWEEP_CASE_RP(1, false, rough, pid, STMT) }   \
-        else { if (rbf) NK_SWEEP_CASE_RP(2, true, rough, pid, STMT) else NK_SWEEP_CASE_RP(2, false, rough, pid, STMT) }             \
+        if ((gm) == 1) { if (rbf) NK_SWEEP_CASE_RP(1, true, rough, pid, split, STMT) else NK_SWEEP_CASE_RP(1, false, rough, pid, split, STMT) }   \
+        else { if (rbf) NK_SWEEP_CASE_RP(2, true, rough, pid, split, STMT) else NK_SWEEP_CASE_RP(2, false, rough, pid, split, STMT) }             \
+    } while (0)
+// k_events, the same way
+#define NK_EVENTS_CASE(G, R, B, P, STMT) { auto KERNEL = k_events<G, R, B, P>; STMT; }
+#define NK_EVENTS_CASE_RP(G, B, rough, pid, STMT)                                                     \
+    { if (rough) NK_EVENTS_CASE(G, true, B, true, STMT) else if (pid) NK_EVENTS_CASE(G, false, B, true, STMT) else NK_EVENTS_CASE(G, false, B, false, STMT) }
+#define NK_EVENTS_DISPATCH(gm, rough, rbf, pid, STMT)                                                 \
+    do {                                                                                               \
+        if ((gm) == 1) { if (rbf) NK_EVENTS_CASE_RP(1, true, rough, pid, STMT) else NK_EVENTS_CASE_RP(1, false, rough, pid, STMT) }   \
+        else { if (rbf) NK_EVENTS_CASE_RP(2, true, rough, pid, STMT) else NK_EVENTS_CASE_RP(2, false, rough, pid, STMT) }             \
     } while (0)
 
 // The mode records hold three lifetime rows (two grid intervals) around the live temperature range [T_lo, T_hi] and
@@ -681,7 +691,7 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)(d.NB + 1) * sizeof(double)));
     NK_HIP(hipMemset(ctx->acc, 0, (size_t)(d.NB + 1) * sizeof(double)));
     const double *p;
-    NK_UP((const double *)nullptr, (size_t)(ctx->num_cu * 8) * d.NB, &p);      // >= any persistent grid we launch
+    NK_UP((const double *)nullptr, (size_t)(ctx->num_cu * 16) * d.NB, &p);     // >= the sweep's and k_events' persistent grids
     d.partials = (double *)p;
     return NK_OK;
 }
@@ -988,6 +998,11 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
 // Does this configuration draw random numbers per particle (then ids are tracked)?  Are the modes partitioned over the
 // segments (always, but for a developer probe; with rough facets a particle whose mode changed migrates, k_deliver)?
 static inline bool nk_want_pid(const nk_ctx *ctx) { return ctx->d.Fr > 0 || ctx->params.track_ids != 0; }
+// Split sweep (events through per-segment queues and k_events): large meshes, whose events are tree walks.  NK_SPLIT=0/1 forces.
+static inline bool nk_want_split(const nk_ctx *ctx) {
+    if (const char *e = getenv("NK_SPLIT")) return atoi(e) != 0;
+    return ctx->have_mesh && !(ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES);
+}
 static inline bool nk_want_part(const nk_ctx *ctx) { return !getenv("NK_NO_PARTITION"); }   // env: developer probe
 
 // Persistent grid of the sweep = what the device keeps resident of the instantiation this configuration uses (before the
@@ -996,13 +1011,13 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     NkDev &d = ctx->d;
     if (!(ctx->have_material && ctx->have_mesh && ctx->have_sv)) return ctx->num_cu * NK_SWEEP_OCC;
     const int gm_ = nk_geom_mode(ctx);
-    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx);
-    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4);
+    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx), split_ = nk_want_split(ctx);
+    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4) | (split_ << 5);
     if (ctx->g_sweep == 0 || ctx->g_sweep_key != key) {
         const size_t lds_w = nk_lds(ctx, true, pid_ ? 3 : 2);
         int per_cu = 0;
         hipError_t e_ = hipSuccess;
-        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
+        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
         if (e_ != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
         if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
@@ -1080,11 +1095,19 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
+    d.qx = d.qy = d.qz = d.qocc = d.qnts = nullptr; d.qw0 = nullptr; d.qpid = nullptr; d.seg_evq = nullptr;
+    if (nk_want_split(ctx)) {
+        NK_PALLOC(double, qx, pd, d.cap); NK_PALLOC(double, qy, pd, d.cap); NK_PALLOC(double, qz, pd, d.cap);
+        NK_PALLOC(double, qocc, pd, d.cap); NK_PALLOC(double, qnts, pd, d.cap);
+        NK_PALLOC(uint32_t, qw0, pw, d.cap);
+        if (d.pid) NK_PALLOC(uint64_t, qpid, pu, d.cap);
+        NK_PALLOC(int32_t, seg_evq, pi, d.nseg);
+    }
 #ifdef NK_STAMPS
     { const unsigned long long *ps; int rc_ = nk_upload<unsigned long long>(ctx, nullptr, (size_t)d.nseg * 8, &ps, true); if (rc_) return rc_; d.stamps = (unsigned long long *)ps; }
 #endif
 #undef NK_PALLOC
-    ctx->layout_key = (d.part ? 1 : 0) | (d.pid ? 2 : 0);
+    ctx->layout_key = (d.part ? 1 : 0) | (d.pid ? 2 : 0) | (d.qx ? 4 : 0);
     // tables that follow the segmentation: permuted mode records, 'one_to_one' inboxes
     if (ctx->have_material) { int rc = nk_update_tau_window(ctx, true); if (rc) return rc; }
     if (ctx->inbox) { hipFree(ctx->inbox); ctx->inbox = nullptr; }
@@ -1147,6 +1170,13 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
+    if (old.qx) {                                       // the event queues are empty between steps: new ones, nothing to copy
+        NK_PALLOC(double, qx, pd, d.cap); NK_PALLOC(double, qy, pd, d.cap); NK_PALLOC(double, qz, pd, d.cap);
+        NK_PALLOC(double, qocc, pd, d.cap); NK_PALLOC(double, qnts, pd, d.cap);
+        NK_PALLOC(uint32_t, qw0, pw, d.cap);
+        if (old.pid) NK_PALLOC(uint64_t, qpid, pu, d.cap);
+        NK_PALLOC(int32_t, seg_evq, pi, d.nseg);
+    }
 #undef NK_PALLOC
     if (rc) {                                            // out of memory: keep the old store
         for (void *p : ctx->pallocs) hipFree(p);
@@ -1196,7 +1226,7 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    bool fits = d.cap > 0 && ctx->layout_key == ((nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0)) && N + N / 5 + 1024 <= d.cap;
+    bool fits = d.cap > 0 && ctx->layout_key == ((nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0) | (nk_want_split(ctx) ? 4 : 0)) && N + N / 5 + 1024 <= d.cap;
     if (fits && d.part) {                              // every segment must hold its modes' particles with head room
         std::vector<int64_t> per((size_t)d.nseg, 0);
         for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0) per[(size_t)(mode[i] % d.nseg)] += 1;
@@ -1229,7 +1259,7 @@ static int nk_check_ready(nk_ctx *ctx) {
     NK_ARG(d.cap > 0, "no particle storage: call nk_reserve / nk_upload_particles");
     NK_ARG(nk_lds(ctx, true, 3) <= 160 * 1024 && nk_lds(ctx, true, 1) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
     // the store's layout follows the configuration (ids, partitioned modes): tables set after the upload re-deal it
-    const int want = (nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0);
+    const int want = (nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0) | (nk_want_split(ctx) ? 4 : 0);
     if (ctx->layout_key != want) {
         NkHostParticles h;
         int rc = nk_gather_live(ctx, h, true);
@@ -1280,10 +1310,12 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));   // row_valid = 0
     const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, d.pid ? 3 : 2), lds_e = nk_lds(ctx, true, 1);
     const int gm_ = nk_geom_mode(ctx);
-    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = d.pid != nullptr;
+    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = d.pid != nullptr, split_ = d.qx != nullptr;
     (void)nk_sweep_blocks(ctx);
     const int g_sweep = ctx->g_sweep < (d.nseg + 3) / 4 ? ctx->g_sweep : (d.nseg + 3) / 4;
     const int g_emit = ctx->num_cu * 8 < (d.nseg + 3) / 4 ? ctx->num_cu * 8 : (d.nseg + 3) / 4;
+    const int g_ev = split_ ? g_emit : 0;                // k_events: one wave per segment like the others
+    const int rows = g_sweep + g_ev;
     const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the batch
     if (ctx->evpool.empty()) {                           // events are created once and reused
         ctx->evpool.resize(16 * 4 + 2);
@@ -1314,17 +1346,18 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
         {
             const int rl = pending ? 1 : 0;
-            NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux)));
+            NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux)));
+            if (split_) NK_EVENTS_DISPATCH(gm_, rough_, rbf_, pid_, (KERNEL<<<g_ev, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, g_sweep)));
         }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
         double *hrow = ctx->hist + (size_t)s * HROW;
         if (ctx->comm) {
-            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, 0);
+            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 0);
             ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB + 1, ncclDouble, ncclSum, ctx->comm, ctx->stream);
             if (nrc != ncclSuccess) { ctx->err = "ncclAllReduce failed"; return NK_ERR_COMM; }
             k_update<<<1, NK_WG, 0, ctx->stream>>>(d, ctx->acc, hrow, do_flux);
         } else {
-            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, g_sweep, ctx->acc, hrow, do_flux, 1);
+            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 1);
         }
         if (d.mig_buf) k_deliver<<<g_emit, NK_WG, 0, ctx->stream>>>(d);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));

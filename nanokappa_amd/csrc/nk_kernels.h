@@ -162,10 +162,10 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     int *rf_off = const_cast<int *>(L.rf_off);
     double *Tsv = const_cast<double *>(L.tb.Tsv), *cen = const_cast<double *>(L.tb.cen);
     NkSv *sv = const_cast<NkSv *>(L.tb.sv);
-    const int t = threadIdx.x;
-    for (int i = t; i < S + d.rbf_P; i += NK_WG) Tsv[i] = d.T_sv[i];
-    for (int i = t; i < 3 * S; i += NK_WG) cen[i] = d.centers[i];
-    for (int i = t; i < S; i += NK_WG) {
+    const int t = threadIdx.x, nth = blockDim.x;
+    for (int i = t; i < S + d.rbf_P; i += nth) Tsv[i] = d.T_sv[i];
+    for (int i = t; i < 3 * S; i += nth) cen[i] = d.centers[i];
+    for (int i = t; i < S; i += nth) {
         // per-subvolume record: centre along the slice axis, T, slope of interp1d's bracket (i, i+1), 1 / T
         const int a = d.sv_axis, j = i + 1 < S ? i + 1 : i;
         const double c = d.centers[3 * i + a], cn = d.centers[3 * j + a], T = d.T_sv[i], Tn = d.T_sv[j];
@@ -173,23 +173,23 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
         q.c = c; q.T = T; q.slope = j > i ? (Tn - T) / (cn - c) : 0.0; q.invT = 1.0 / T;
         sv[i] = q;
     }
-    for (int i = t; i < NK_NREP * S; i += NK_WG) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
-    for (int i = t; i < NK_NREP * 3 * S; i += NK_WG) L.bins.flux[i] = 0.0;
-    for (int i = t; i < 4 * R; i += NK_WG) L.bins.resb[i] = 0.0;
-    for (int i = t; i < R; i += NK_WG) { L.bins.nleave[i] = 0u; const double T = d.res_T[i]; resT[2 * i] = T; resT[2 * i + 1] = 1.0 / T; }
+    for (int i = t; i < NK_NREP * S; i += nth) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
+    for (int i = t; i < NK_NREP * 3 * S; i += nth) L.bins.flux[i] = 0.0;
+    for (int i = t; i < 4 * R; i += nth) L.bins.resb[i] = 0.0;
+    for (int i = t; i < R; i += nth) { L.bins.nleave[i] = 0u; const double T = d.res_T[i]; resT[2 * i] = T; resT[2 * i + 1] = 1.0 / T; }
     if (t == 0) L.bins.misc[0] = 0u;
-    for (int i = t; i < Fl * NK_FACE_DOUBLES; i += NK_WG) faces[i] = d.faces[i];
-    for (int i = t; i < Pl * NK_PLANE_DOUBLES; i += NK_WG) planes[i] = d.planes[i];
+    for (int i = t; i < Fl * NK_FACE_DOUBLES; i += nth) faces[i] = d.faces[i];
+    for (int i = t; i < Pl * NK_PLANE_DOUBLES; i += nth) planes[i] = d.planes[i];
     if (nrf > 0) {
-        for (int i = t; i <= R; i += NK_WG) rf_off[i] = d.res_face_off[i];
-        for (int i = t; i < nrf; i += NK_WG) rf_cdf[i] = d.res_face_cdf[i];
-        for (int i = t; i < 9 * nrf; i += NK_WG) rf_verts[i] = d.res_face_verts[i];
+        for (int i = t; i <= R; i += nth) rf_off[i] = d.res_face_off[i];
+        for (int i = t; i < nrf; i += nth) rf_cdf[i] = d.res_face_cdf[i];
+        for (int i = t; i < 9 * nrf; i += nth) rf_verts[i] = d.res_face_verts[i];
     }
     {
         const int nw = Fcl * (int)(sizeof(NkFacet) / 4);
         const int32_t *src = (const int32_t *)d.facets;
         int32_t *dst = (int32_t *)facets;
-        for (int i = t; i < nw; i += NK_WG) dst[i] = src[i];
+        for (int i = t; i < nw; i += nth) dst[i] = src[i];
     }
     __syncthreads();
 }
@@ -199,7 +199,7 @@ __device__ __forceinline__ void nk_lds_flush(const NkDev &d, const NkLds &L, int
     __syncthreads();
     const int S = d.S, R = d.R;
     double *out = d.partials + row * d.NB;
-    for (int b = threadIdx.x; b < d.NB; b += NK_WG) {
+    for (int b = threadIdx.x; b < d.NB; b += blockDim.x) {
         double v = 0.0;
         if (b < S) { for (int r = 0; r < NK_NREP; ++r) v += L.bins.E[r * S + b]; }
         else if (b < 2 * S) { unsigned int c = 0; for (int r = 0; r < NK_NREP; ++r) c += L.bins.N[r * S + (b - S)]; v = (double)c; }
@@ -569,11 +569,15 @@ struct NkOut {
 // as the next tile's prefetch, so the reload waits for the prefetch (stamps: every section of the loop 2.5 x slower on the
 // rough box at 33 spilled VGPRs).  The variants that need more than 168 VGPRs therefore run two workgroups per CU without
 // spills rather than three with.
-template <int GEOM, bool ROUGH, bool RBF, bool PID>
-#ifndef NK_SWEEP_OCC_G2
-#define NK_SWEEP_OCC_G2 2
+// SPLIT (large meshes): the sweep only streams -- a particle that meets a boundary goes to its segment's event queue in HBM
+// (coalesced, one extra round trip for those particles) and k_events runs the events, whose tree walks are chains of
+// dependent loads, at twice the residency; the fused form keeps the events in registers (boxes: a third of the particles
+// have one every step, a second trip through HBM would cost more than the residency gains).
+#ifndef NK_SWEEP_OCC_SPLIT
+#define NK_SWEEP_OCC_SPLIT 4
 #endif
-__global__ __launch_bounds__(NK_WG, GEOM == 2 ? NK_SWEEP_OCC_G2 : ((ROUGH || RBF) ? 2 : NK_SWEEP_OCC)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
+template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT>
+__global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || ROUGH || RBF) ? 2 : NK_SWEEP_OCC)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
     NkLds L;
@@ -603,6 +607,7 @@ __global__ __launch_bounds__(NK_WG, GEOM == 2 ? NK_SWEEP_OCC_G2 : ((ROUGH || RBF
         const int nA = (count + NK_TILE - 1) / NK_TILE;
         NkOut<PID> O;                                 // finished particles on their way back to the segment
         O.init(L, wave);
+        int qn = 0;                                   // SPLIT: entries in the segment's event queue
         int cn = 0;                                   // particles in the carry (lanes [0, cn))
         NkCarry<PID, ROUGH> C;
         C.x = C.y = C.z = C.occ = C.nts = C.cts = 0.0; C.w0 = 0u; C.evc = 0u; C.gm = 0u; C.pid = 0ull;
@@ -663,6 +668,18 @@ __global__ __launch_bounds__(NK_WG, GEOM == 2 ? NK_SWEEP_OCC_G2 : ((ROUGH || RBF
             if (done) nk_tally_one(d, L.tb, L.bins, x, y, z, occ, omega, E0, vx, vy, vz, do_flux, rep);
             O.push(d, base, lane, done, __popcll(mD & lower), __popcll(mD), x, y, z, occ, nts, w0, pid);
             NK_STAMP(2);
+            if (SPLIT) {                               // the tile's event particles leave for the queue; k_events takes over
+                if (ev) {
+                    const int o = qn + __popcll(mE & lower);
+                    if (o < d.segcap) {
+                        const int64_t i = base + o;
+                        d.qx[i] = x; d.qy[i] = y; d.qz[i] = z; d.qocc[i] = occ; d.qnts[i] = nts; d.qw0[i] = w0;
+                        if (PID) d.qpid[i] = pid;
+                    }
+                }
+                qn += __popcll(mE);
+                continue;
+            }
             // the tile's event particles, packed into lanes [po, po + pn) of P
             int pn = __popcll(mE), po = 0;
             NkCarry<PID, ROUGH> P;
@@ -765,16 +782,109 @@ __global__ __launch_bounds__(NK_WG, GEOM == 2 ? NK_SWEEP_OCC_G2 : ((ROUGH || RBF
 #endif
         if (O.on > 0) O.flush(d, base, lane, O.on);
         const int w = O.wout;
+        if (SPLIT && lane == 0) d.seg_evq[seg] = qn < d.segcap ? qn : d.segcap;
         if (lane == 0) {
             d.seg_count[seg] = w < d.segcap ? w : d.segcap;
             // could the next step overflow this segment?  then nothing after this step runs until the host has grown the store
             if (d.R > 0) {
                 d.seg_new[seg] = 0;
-                if ((int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+                if (!SPLIT && (int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
             }
         }
     }
     nk_lds_flush(d, L, blockIdx.x);
+}
+
+// The events of a split sweep: one wave per segment works its queue off, 64 entries at a time, every lane looping over its
+// particle's events (Population.py:1546-1683; few particles have more than one), then tally and append to the segment.
+// Lean enough for four waves per SIMD: the tree walks (chains of dependent loads) are what the extra residency is for.
+#ifndef NK_EVENTS_OCC
+#define NK_EVENTS_OCC 4          // measured on the 5000-triangle wire (ms per step): 2 -> 7.7, 3 -> 7.2, 4 -> 5.9-6.2, 5 -> 6.4, 6 -> 7.1, 8 -> 11.3
+#endif
+// (Tried on the 5000-triangle wire and dropped: one workgroup of 1024 threads per CU that stages the face tree's boxes in LDS
+// -- 6.00 against 6.03 ms per step; the walk's box reads are not what the events wait for.)
+template <int GEOM, bool ROUGH, bool RBF, bool PID>
+__global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32_t step, int flags, int row0) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (d.halt[0]) return;
+    NkLds L;
+    nk_lds_setup<GEOM, 0>(d, smem, L);
+    const bool do_flux = (flags & 1) != 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rep = lane & (NK_NREP - 1);
+    const unsigned long long lower = (1ull << lane) - 1ull;
+    const uint32_t lbmask = (1u << d.lb) - 1u;
+    const int wpb = blockDim.x >> 6, nwaves = gridDim.x * wpb;
+    for (int seg = blockIdx.x * wpb + wave; seg < d.nseg; seg += nwaves) {
+        const int q = d.seg_evq[seg];
+        const int64_t base = (int64_t)seg * d.segcap;
+        const NkSegModes sm = nk_seg_modes(d, seg);
+        int w = d.seg_count[seg];
+        for (int j0 = 0; j0 < q; j0 += NK_TILE) {
+            const int j = j0 + lane;
+            const bool act = j < q;
+            NkParticle p;
+            uint32_t w0 = 0u, evc = 0u;
+            unsigned long long pid = 0;
+            double cts = 0.0;
+            int st = NK_EV_DEAD;
+            p.x = p.y = p.z = p.occ = p.nts = 0.0;
+            if (act) {
+                const int64_t i = base + j;
+                p.x = d.qx[i]; p.y = d.qy[i]; p.z = d.qz[i]; p.occ = d.qocc[i]; p.nts = d.qnts[i]; w0 = d.qw0[i];
+                if (PID) pid = d.qpid[i];
+            }
+            const int idx0 = (int)(w0 & lbmask);
+            p.mode = idx0 * sm.mstride + sm.moff;
+            {
+                const NkMode *rec = d.modetab + p.mode;
+                const double4 ra = *reinterpret_cast<const double4 *>(rec);
+                p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                p.E0 = rec->E0;
+            }
+            p.facet = (int)(w0 >> d.lb) - 1;
+            if (act) {
+                do st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, pid, step);
+                while (st == NK_EV_MORE);
+            }
+            const bool alive = act && st == NK_EV_DONE;
+            if (alive) nk_tally_one(d, L.tb, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.E0, p.vx, p.vy, p.vz, do_flux, rep);
+            bool stay = true;
+            uint32_t idxe = (uint32_t)idx0;
+            if (ROUGH) {
+                if (d.part) { const uint32_t qq = (uint32_t)p.mode / (uint32_t)d.nseg; stay = (int)((uint32_t)p.mode - qq * (uint32_t)d.nseg) == seg; idxe = qq; }
+                else idxe = (uint32_t)p.mode;
+            }
+            const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
+            const bool home = alive && stay, away = alive && !stay;
+            const unsigned long long mA = __ballot(home);
+            if (home) {
+                const int o = w + __popcll(mA & lower);
+                if (o < d.segcap) {
+                    const int64_t i = base + o;
+                    d.x[i] = p.x; d.y[i] = p.y; d.z[i] = p.z; d.occ[i] = p.occ; d.nts[i] = p.nts; d.w0[i] = w0e;
+                    if (PID) d.pid[i] = pid;
+                } else atomicOr(d.overflow, 4);
+            }
+            w += __popcll(mA);
+            if (ROUGH && away) {
+                const int dst = (int)((uint32_t)p.mode - idxe * (uint32_t)d.nseg);
+                const int at = atomicAdd(d.mig_n + dst, 1);
+                if (at < d.mig_cap) {
+                    double2 *r = d.mig_buf + ((int64_t)dst * d.mig_cap + at) * 4;
+                    r[0] = make_double2(p.x, p.y); r[1] = make_double2(p.z, p.occ);
+                    r[2] = make_double2(p.nts, __longlong_as_double((long long)pid));
+                    r[3] = make_double2(__longlong_as_double((long long)w0e), 0.0);
+                } else atomicOr(d.overflow, 32);
+            }
+        }
+        if (lane == 0) {
+            d.seg_count[seg] = w < d.segcap ? w : d.segcap;
+            d.seg_evq[seg] = 0;
+            if (d.R > 0 && (int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+        }
+    }
+    nk_lds_flush(d, L, row0 + blockIdx.x);
 }
 
 // nk_reserve with an unchanged number of segments: every segment's particles move to the start of its longer successor.
