@@ -79,8 +79,8 @@ class Phonon(Constants):
     `arguments.hdf_file[mat_index]` selects the source:
       * 'synthetic' | 'synthetic:<n>' | 'synthetic:<n>:<Si|Ge>'  -> analytic material,
       * '<file>.npz'                                            -> tables saved by `save_npz`,
-      * '<file>.hdf5'                                           -> phono3py file (needs h5py and an
-        FBZ-expanded file; irreducible-wedge expansion is SURVEY section 8f row 2, not built yet).
+      * '<file>.hdf5'                                           -> phono3py file (needs h5py): irreducible q-points +
+        weights, expanded to the full zone with the POSCAR's point group (crystal.py; tests/test_phonon_golden.py).
     """
 
     def __init__(self, arguments=None, mat_index=0, material=None):

@@ -10,6 +10,7 @@ listed in SURVEY.md section 8b are read.  The particle state lives in HBM inside
 keeps the tallies (subvolume temperatures, energies, fluxes, reservoir balances), the convergence bookkeeping
 and the text outputs.  There is no CPU fallback: without the library / a GPU the constructor raises.
 """
+import glob
 import inspect
 import os
 import sys
@@ -293,15 +294,25 @@ class Population(Constants):
                 chunks.append(np.ones((k, 3)) * np.asarray(geometry.subvol_center)[i])
             pos = np.vstack(chunks)[:NL, :]
         else:
-            data = np.loadtxt(key, delimiter=',', comments='#', dtype=float)        # resume file, Population.py:284-306
+            # resume file, Population.py:284-306; a run on several ranks leaves one file per rank beside it
+            # (write_final_state), and every rank reads them all before taking its share
+            files = [key] if os.path.exists(key) else []
+            stem, ext = os.path.splitext(key)
+            files += sorted(glob.glob(stem + '.rank*of*' + ext))
+            if not files:
+                raise Exception('Wrong particle data file. Change the keyword or check whether the file exists.')
+            data = np.vstack([np.loadtxt(f, delimiter=',', comments='#', dtype=float, ndmin=2) for f in files])
             modes = data[:, [0, 1]].astype(int)
             pos = data[:, [2, 3, 4]].copy()
             occ = data[:, 5].copy()
+            # subvolume temperatures: from --temp_dist, then the fixed point of refresh_temperatures on the loaded
+            # occupations (:296-303), on the WHOLE ensemble -- the same on every rank
+            sv = geometry.subvol_classifier.predict(pos) if S > 1 else np.zeros(pos.shape[0], dtype=int)
+            self.subvol_temperature = self._resume_temperatures(phonon, sv, modes, occ, self._assign_subvol_temperatures(geometry))
             lo, hi = self._shard(pos.shape[0])
             self.N_total, self.pid_lo, self.N_local = pos.shape[0], lo, hi - lo
             modes, pos, occ = modes[lo:hi], pos[lo:hi], occ[lo:hi]
-            self.subvol_id = geometry.subvol_classifier.predict(pos)
-            self.subvol_temperature = self._assign_subvol_temperatures(geometry)
+            self.subvol_id = sv[lo:hi]
             return pos, modes, occ
         modes = self.initialise_modes(phonon)
         self.subvol_id = geometry.subvol_classifier.predict(pos) if S > 1 else np.zeros(pos.shape[0], dtype=int)
@@ -309,6 +320,30 @@ class Population(Constants):
         T = self.subvol_temperature[self.subvol_id]
         occ = phonon.calculate_occupation(T, phonon.omega[modes[:, 0], modes[:, 1]])  # Population.py:280
         return pos, modes, occ
+
+    def _resume_temperatures(self, phonon, sv, modes, occ, T):
+        """Population.py:296-303: iterate refresh_temperatures (calculate_energy :704-728 with the current subvolume
+        temperatures as local reference, then T = temperature_function(E)) until no subvolume moves by more than 1e-6."""
+        S = self.n_of_subvols
+        om = phonon.omega[modes[:, 0], modes[:, 1]]
+        N_sv = np.bincount(sv, minlength=S).astype(float)
+        T = np.array(T, dtype=float)
+        old_T = np.zeros(S)
+        err, it = 1.0, 0
+        while err > 1e-6 and it < 1000:
+            if self.T_reference == 'local':
+                dn = occ - phonon.calculate_occupation(T[sv], om)
+                ref = phonon.crystal_energy_function(T)
+            else:
+                dn = occ - self.reference_occupation[modes[:, 0], modes[:, 1]]
+                ref = self.ref_en_density
+            E_raw = np.bincount(sv, weights=self.hbar * om * dn, minlength=S)
+            T = np.asarray(phonon.temperature_function(self._normalise_energy(phonon, E_raw, N_sv) + ref), dtype=float)
+            with np.errstate(divide='ignore', invalid='ignore'):
+                err = np.nanmax(np.absolute((T - old_T) / T))
+            old_T = T.copy()
+            it += 1
+        return T
 
     def _assign_subvol_temperatures(self, geometry):
         """assign_temperatures (Population.py:565-655), subvolume part."""
@@ -519,7 +554,7 @@ class Population(Constants):
             done += chunk
 
     def _every_hundred(self, geometry):
-        if self.rank == 0 and self.results_folder_name and getattr(self.args, 'checkpoint', True):
+        if self.results_folder_name and getattr(self.args, 'checkpoint', True):     # every rank: its shard of the particles
             self.write_final_state(geometry)
         self.view.postprocess(verbose=False)
         self.update_residue(geometry)
@@ -656,8 +691,11 @@ class Population(Constants):
                   'hdf file = {}, POSCAR file = {}\n'.format(self.args.hdf_file, self.args.poscar_file) +
                   'q-point, branch, pos x [angs], pos y [angs], pos z [angs], occupation')
         data = np.hstack((p['modes'], p['positions'], p['occupation'].reshape(-1, 1)))
-        np.savetxt(os.path.join(self.results_folder_name, 'particle_data.txt'), data, '%d, %d, %.3f, %.3f, %.3f, %.6e',
+        name = 'particle_data.txt' if self.nranks == 1 else 'particle_data.rank%dof%d.txt' % (self.rank, self.nranks)
+        np.savetxt(os.path.join(self.results_folder_name, name), data, '%d, %d, %.3f, %.3f, %.3f, %.6e',
                    delimiter=',', header=header)
+        if self.rank != 0:
+            return
         if self.current_timestep > 0 and geometry.subvol_type == 'slice' and hasattr(self.view, 'mean_T'):
             v = self.view
             S = self.n_of_subvols

@@ -1,5 +1,7 @@
 """Host-side material tables vs the reference's Phonon (golden: tests/golden/phonon.npz)."""
 import numpy as np
+import os
+
 import pytest
 
 from util import golden, golden_phonon, rel_err
@@ -144,3 +146,47 @@ def test_isotope_scattering_option(tmp_path):
     np.savez(tmp_path / 'kappa.npz', **data)
     with pytest.raises(Exception, match='gamma_isotope'):
         Phonon(initialise_parser().parse_args(base + ['--isotope_scat', '0']), 0)
+
+
+def test_hdf5_loader_branch(tmp_path):
+    """The phono3py HDF5 container itself (reference Phonon.py:66-149, :158-187): tests/golden/kappa-m999.hdf5 (written by
+    tests/golden/make_hdf5_material.py) through `Phonon`'s .hdf5 branch must give the tables of the same datasets
+    handed over as .npz.  h5py is not installed for the system interpreter of this image, so the loading runs in whichever
+    interpreter has it (this one, or the image's conda python); skipped where neither does."""
+    import shutil
+    import subprocess
+    import sys
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    root = os.path.abspath(os.path.join(golden_dir, '..', '..'))
+    shutil.copy(os.path.join(golden_dir, 'kappa-m999.hdf5'), tmp_path / 'kappa-m999.hdf5')
+    shutil.copy(os.path.join(golden_dir, 'POSCAR_Si'), tmp_path / 'POSCAR')
+    code = ("import sys; sys.path.insert(0, %r); import numpy as np\n"
+            "from nanokappa_amd.argument_parser import initialise_parser\n"
+            "from nanokappa_amd.phonon import Phonon\n"
+            "a = initialise_parser().parse_args(['--mat_folder', %r, '--hdf_file', 'kappa-m999.hdf5', '--poscar_file', 'POSCAR', '--isotope_scat', '0'])\n"
+            "p = Phonon(a, 0)\n"
+            "np.savez(%r, q_points=p.q_points, omega=p.omega, group_vel=p.group_vel, gamma=p.gamma, T=p.temperature_array, lifetime=p.lifetime)\n"
+            % (root, str(tmp_path), str(tmp_path / 'from_hdf5.npz')))
+    interp = None
+    for cand in (sys.executable, '/opt/conda/bin/python3.9'):
+        if os.path.exists(cand) and subprocess.run([cand, '-c', 'import h5py'], capture_output=True).returncode == 0:
+            interp = cand
+            break
+    if interp is None:
+        pytest.skip('no interpreter with h5py')
+    r = subprocess.run([interp, '-W', 'ignore', '-c', code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(tmp_path / 'from_hdf5.npz')
+    # the same datasets as .npz through the other branch
+    sys.path.insert(0, golden_dir)
+    import make_hdf5_material_data as M
+    d = M.datasets()
+    np.savez(tmp_path / 'kappa.npz', **d)
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.phonon import Phonon
+    ref = Phonon(initialise_parser().parse_args(['--mat_folder', str(tmp_path), '--hdf_file', 'kappa.npz', '--poscar_file', 'POSCAR',
+                                                 '--isotope_scat', '0']), 0)
+    assert got['q_points'].shape == (729, 3)
+    for k, v in (('q_points', ref.q_points), ('omega', ref.omega), ('group_vel', ref.group_vel), ('gamma', ref.gamma),
+                 ('T', ref.temperature_array), ('lifetime', ref.lifetime)):
+        assert np.allclose(got[k], v, rtol=1e-13, atol=1e-300), k
