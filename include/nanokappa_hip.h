@@ -225,6 +225,22 @@ int nk_specular_pairs(nk_ctx *ctx, const double *normal /* [3] */, double crit, 
                       int32_t *pair_out, int64_t *n_pairs);
 int nk_specular_end(nk_ctx *ctx);
 
+
+/* The rough-facet tables built on the device and installed in place of nk_set_rough ('velocity' reflection model):
+ * calculate_fbz_specularity (Population.py:852-877), true_specular and the specular map of find_specular_correspondences
+ * (:1457-1459), diffuse_scat_probability (:879-939).  Protocol, inside nk_specular_begin .. nk_specular_end:
+ *   nk_rough_begin(Fr, facet[Fr], inward normals [Fr*3] (= -facets_normal), eta [Fr], |k| per q-point [Q]);
+ *   for every distinct (rounded) normal: nk_specular_pairs(normal, ...), then nk_rough_pairs(the rough-facet indices that
+ *   share it) -- the pairs are taken from the device, where the search left them;
+ *   nk_rough_finish(): specularity, creation rates, their cumulative roulette and its bucket index; the tables stay on the
+ *   device.  nk_rough_download copies them back (tests, host attributes); any pointer may be NULL. */
+int nk_rough_begin(nk_ctx *ctx, int32_t Fr, const int32_t *facet, const double *normal_in, const double *eta, const double *k_norm);
+int nk_rough_pairs(nk_ctx *ctx, int32_t nf, const int32_t *fidx);
+int nk_rough_finish(nk_ctx *ctx);
+int nk_rough_download(nk_ctx *ctx, double *specularity, uint8_t *true_spec, int32_t *spec_map, double *roulette);
+/* enter_probability (Population.py:146-161) on the device: out[r*M + m] = max(0, v_m . n_in_r) * dt / thickness_r */
+int nk_build_enter_prob(nk_ctx *ctx, int32_t R, const double *normal_in, const double *thickness, double dt, double *out);
+
 #ifdef __cplusplus
 }
 #endif

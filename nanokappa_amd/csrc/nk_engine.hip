@@ -51,6 +51,13 @@ struct nk_ctx {
     int32_t *spec_in = nullptr, *spec_out = nullptr;
     unsigned long long *spec_count = nullptr;
     int64_t spec_cap = 0;
+    int64_t spec_last = 0;            // pairs of the last nk_specular_pairs call (still on the device)
+    // rough tables under construction on the device (nk_rough_begin .. nk_rough_finish)
+    int rb_Fr = 0;
+    double *rb_k2 = nullptr, *rb_nin = nullptr, *rb_eta = nullptr, *rb_sub = nullptr, *rb_spec = nullptr, *rb_roul = nullptr;
+    uint8_t *rb_ts = nullptr;
+    unsigned int *rb_map = nullptr;
+    std::vector<int32_t> rb_facet;
     int64_t o2o_first = 0;            // 'one_to_one': particles entering at the first step (sizes the spawn inboxes)
     bool stepped = false;             // a timestep has run (the emission ownership of a rank is fixed from then on)
     NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
@@ -1771,6 +1778,7 @@ int nk_specular_pairs(nk_ctx *ctx, const double *normal, double crit, int64_t ca
     NK_HIP(hipMemcpy(&n, ctx->spec_count, 8, hipMemcpyDeviceToHost));
     *n_pairs = (int64_t)n;
     const int64_t got = (int64_t)n < cap ? (int64_t)n : cap;
+    ctx->spec_last = (int64_t)n <= cap ? (int64_t)n : -1;      // -1: truncated, the caller asks again with more room
     if (got > 0) {
         NK_HIP(hipMemcpy(pair_in, ctx->spec_in, (size_t)got * 4, hipMemcpyDeviceToHost));
         NK_HIP(hipMemcpy(pair_out, ctx->spec_out, (size_t)got * 4, hipMemcpyDeviceToHost));
@@ -1781,5 +1789,111 @@ int nk_specular_end(nk_ctx *ctx) {
     NK_ARG(ctx, "nk_specular_end: NULL context");
     NK_HIP(hipSetDevice(ctx->device));
     nk_specular_free(ctx);
+    return NK_OK;
+}
+
+// ---- the rough-facet tables built on the device (header: nk_rough_begin / nk_rough_pairs / nk_rough_finish)
+static void nk_rough_build_free(nk_ctx *ctx, bool tables) {
+    for (void *p : {(void *)ctx->rb_k2, (void *)ctx->rb_nin, (void *)ctx->rb_eta, (void *)ctx->rb_sub}) if (p) hipFree(p);
+    ctx->rb_k2 = ctx->rb_nin = ctx->rb_eta = ctx->rb_sub = nullptr;
+    if (tables) {
+        for (void *p : {(void *)ctx->rb_spec, (void *)ctx->rb_roul, (void *)ctx->rb_ts, (void *)ctx->rb_map}) if (p) hipFree(p);
+        ctx->rb_spec = ctx->rb_roul = nullptr; ctx->rb_ts = nullptr; ctx->rb_map = nullptr;
+    }
+}
+int nk_rough_begin(nk_ctx *ctx, int32_t Fr, const int32_t *facet, const double *normal_in, const double *eta, const double *k_norm) {
+    NK_ARG(ctx && Fr > 0 && facet && normal_in && eta && k_norm, "nk_rough_begin: bad arguments");
+    NK_ARG(ctx->have_material && ctx->have_mesh, "nk_rough_begin: set material and mesh first");
+    NK_HIP(hipSetDevice(ctx->device));
+    NkDev &d = ctx->d;
+    nk_rough_build_free(ctx, true);
+    for (int i = 0; i < Fr; ++i) NK_ARG(facet[i] >= 0 && facet[i] < d.Fc, "nk_rough_begin: facet index");
+    const size_t n = (size_t)Fr * d.M;
+    std::vector<double> k2((size_t)d.Q);
+    for (int q = 0; q < d.Q; ++q) k2[(size_t)q] = k_norm[q] * k_norm[q];
+    NK_HIP(hipMalloc((void **)&ctx->rb_k2, (size_t)d.Q * 8));
+    NK_HIP(hipMalloc((void **)&ctx->rb_nin, (size_t)Fr * 24));
+    NK_HIP(hipMalloc((void **)&ctx->rb_eta, (size_t)Fr * 8));
+    NK_HIP(hipMalloc((void **)&ctx->rb_sub, n * 8));
+    NK_HIP(hipMalloc((void **)&ctx->rb_spec, n * 8));
+    NK_HIP(hipMalloc((void **)&ctx->rb_roul, n * 8));
+    NK_HIP(hipMalloc((void **)&ctx->rb_ts, n));
+    NK_HIP(hipMalloc((void **)&ctx->rb_map, n * 4));
+    NK_HIP(hipMemcpy(ctx->rb_k2, k2.data(), (size_t)d.Q * 8, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ctx->rb_nin, normal_in, (size_t)Fr * 24, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ctx->rb_eta, eta, (size_t)Fr * 8, hipMemcpyHostToDevice));
+    NK_HIP(hipMemsetAsync(ctx->rb_sub, 0, n * 8, ctx->stream));
+    NK_HIP(hipMemsetAsync(ctx->rb_ts, 0, n, ctx->stream));
+    k_fill_u32<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(ctx->rb_map, (int64_t)n, 0xFFFFFFFFu);
+    NK_HIP(hipGetLastError());
+    ctx->rb_Fr = Fr;
+    ctx->rb_facet.assign(facet, facet + Fr);
+    return NK_OK;
+}
+int nk_rough_pairs(nk_ctx *ctx, int32_t nf, const int32_t *fidx) {
+    NK_ARG(ctx && nf > 0 && fidx && ctx->rb_Fr > 0, "nk_rough_pairs: call nk_rough_begin first");
+    NK_ARG(ctx->spec_last >= 0, "nk_rough_pairs: the last nk_specular_pairs call was truncated");
+    for (int i = 0; i < nf; ++i) NK_ARG(fidx[i] >= 0 && fidx[i] < ctx->rb_Fr, "nk_rough_pairs: rough-facet index");
+    if (ctx->spec_last == 0) return NK_OK;
+    NK_HIP(hipSetDevice(ctx->device));
+    NkDev &d = ctx->d;
+    NK_BUF(int32_t, df, fidx, nf);
+    k_rough_pairs<<<(int)((ctx->spec_last + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>(d.M, d.J, ctx->spec_v, ctx->rb_k2, ctx->spec_last,
+                                                                                         ctx->spec_in, ctx->spec_out, nf, df.p, ctx->rb_nin,
+                                                                                         ctx->rb_eta, ctx->rb_ts, ctx->rb_map, ctx->rb_sub);
+    NK_HIP(hipGetLastError());
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    return NK_OK;
+}
+int nk_rough_finish(nk_ctx *ctx) {
+    NK_ARG(ctx && ctx->rb_Fr > 0 && ctx->spec_v, "nk_rough_finish: call nk_rough_begin (inside nk_specular_begin .. end) first");
+    NK_HIP(hipSetDevice(ctx->device));
+    NkDev &d = ctx->d;
+    const int Fr = ctx->rb_Fr;
+    const size_t n = (size_t)Fr * d.M;
+    k_rough_finish<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>(Fr, d.M, d.J, ctx->spec_v, ctx->rb_k2, ctx->rb_nin, ctx->rb_eta,
+                                                                              ctx->rb_ts, (int32_t *)ctx->rb_map, ctx->rb_sub, ctx->rb_spec,
+                                                                              ctx->rb_roul);
+    k_rough_cumsum<<<Fr, 64, 0, ctx->stream>>>(d.M, ctx->rb_roul);
+    int nlut = 1024;
+    while (nlut < 65536 && (int64_t)nlut * 4 < d.M) nlut *= 2;
+    int32_t *lut = nullptr;
+    NK_HIP(hipMalloc((void **)&lut, (size_t)Fr * (nlut + 1) * 4));
+    ctx->allocs.push_back(lut);
+    k_rough_lut<<<(int)(((size_t)Fr * (nlut + 1) + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>(Fr, d.M, nlut, ctx->rb_roul, lut);
+    NK_HIP(hipGetLastError());
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    // install, as nk_set_rough does (the tables now belong to the context)
+    d.Fr = Fr;
+    ctx->g_sweep = 0;
+    d.specularity = ctx->rb_spec; d.true_spec = ctx->rb_ts; d.spec_map = (const int32_t *)ctx->rb_map; d.roulette = ctx->rb_roul;
+    d.roul_lut = lut; d.roul_nlut = nlut; d.degen_j2 = nullptr;
+    for (void *p : {(void *)ctx->rb_spec, (void *)ctx->rb_roul, (void *)ctx->rb_ts, (void *)ctx->rb_map}) ctx->allocs.push_back(p);
+    ctx->rb_spec = ctx->rb_roul = nullptr; ctx->rb_ts = nullptr; ctx->rb_map = nullptr;
+    nk_rough_build_free(ctx, false);
+    for (int i = 0; i < Fr; ++i) ctx->host_facets[ctx->rb_facet[(size_t)i]].rough = i;
+    ctx->rb_Fr = 0;
+    return nk_patch_facets(ctx);
+}
+int nk_rough_download(nk_ctx *ctx, double *specularity, uint8_t *true_spec, int32_t *spec_map, double *roulette) {
+    NK_ARG(ctx && ctx->d.Fr > 0, "nk_rough_download: no rough tables");
+    NK_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)ctx->d.Fr * ctx->d.M;
+    if (specularity) NK_HIP(hipMemcpy(specularity, ctx->d.specularity, n * 8, hipMemcpyDeviceToHost));
+    if (true_spec) NK_HIP(hipMemcpy(true_spec, ctx->d.true_spec, n, hipMemcpyDeviceToHost));
+    if (spec_map) NK_HIP(hipMemcpy(spec_map, ctx->d.spec_map, n * 4, hipMemcpyDeviceToHost));
+    if (roulette) NK_HIP(hipMemcpy(roulette, ctx->d.roulette, n * 8, hipMemcpyDeviceToHost));
+    return NK_OK;
+}
+int nk_build_enter_prob(nk_ctx *ctx, int32_t R, const double *normal_in, const double *thickness, double dt, double *out) {
+    NK_ARG(ctx && R > 0 && normal_in && thickness && out && ctx->have_material, "nk_build_enter_prob: bad arguments");
+    NK_HIP(hipSetDevice(ctx->device));
+    NkDev &d = ctx->d;
+    const size_t n = (size_t)R * d.M;
+    NK_BUF(double, dn, normal_in, (int64_t)R * 3); NK_BUF(double, dth, thickness, R); NK_BUF(double, dout, nullptr, (int64_t)n);
+    k_enter_prob<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>(R, d.M, ctx->d_vg, dn.p, dth.p, dt, dout.p);
+    NK_HIP(hipGetLastError());
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    NK_HIP(dout.get(out, (int64_t)n));
     return NK_OK;
 }

@@ -1294,3 +1294,89 @@ __global__ __launch_bounds__(NK_WG) void k_specular_pairs(int M, const NkSpecMod
         if ((int64_t)at < cap) { pin[at] = a_orig; pout[at] = (int)o.pad; }
     }
 }
+
+// ---- the rough-facet tables on the device: calculate_fbz_specularity (Population.py:852-877), the specular
+// map of find_specular_correspondences (:1457), diffuse_scat_probability (:879-939), built in the layout nk_set_rough uploads.
+// The pairs of one normal (k_specular_pairs, still on the device) against the facets that share it: in-modes become truly
+// specular, the map keeps the smallest out-mode, and what every pair takes out of its out-mode's diffuse creation rate
+// (D_total * specularity of the in-mode, :912-925) is summed per out-mode.
+__device__ __forceinline__ double nk_spec0(const double *v, const double *k2, int J, int m, double nx, double ny, double nz, double eta,
+                                           double &vdn) {
+    const double vx = v[3 * m], vy = v[3 * m + 1], vz = v[3 * m + 2];
+    vdn = nx * vx + ny * vy + nz * vz;
+    const double vn = sqrt(vx * vx + vy * vy + vz * vz);
+    const double c = vdn / vn, e = 2.0 * eta * c;
+    const double sp = exp(-(e * e) * k2[m / J]);               // exp(-(2 eta cos)^2 k^2), :873-875
+    return isnan(sp) ? 0.0 : sp;
+}
+__global__ __launch_bounds__(NK_WG) void k_rough_pairs(int M, int J, const double *v, const double *k2, int64_t npairs, const int32_t *pin,
+                                                      const int32_t *pout, int nf, const int32_t *fidx, const double *nin,
+                                                      const double *eta, uint8_t *true_spec, unsigned int *spec_map, double *sub) {
+    const int64_t p = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
+    if (p >= npairs) return;
+    const int a = pin[p], b = pout[p];
+    for (int k = 0; k < nf; ++k) {
+        const int f = fidx[k];
+        double vdn;
+        const double sp = nk_spec0(v, k2, J, a, nin[3 * f], nin[3 * f + 1], nin[3 * f + 2], eta[f], vdn);
+        true_spec[(int64_t)f * M + a] = 1;
+        atomicMin(spec_map + (int64_t)f * M + a, (unsigned int)b);
+        atomicAdd(sub + (int64_t)f * M + b, (vdn < 0.0 ? -vdn : 0.0) * sp);
+    }
+}
+// per (facet, mode): specularity = true_specular * spec0 (:1459); creation rate = max(v.n, 0) - what the pairs took, rounded to
+// ten decimals (np.around, :933)
+__global__ __launch_bounds__(NK_WG) void k_rough_finish(int Fr, int M, int J, const double *v, const double *k2, const double *nin,
+                                                       const double *eta, const uint8_t *true_spec, int32_t *spec_map, const double *sub,
+                                                       double *specularity, double *rate) {
+    const int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
+    if (i >= (int64_t)Fr * M) return;
+    const int f = (int)(i / M), m = (int)(i - (int64_t)f * M);
+    double vdn;
+    const double sp = nk_spec0(v, k2, J, m, nin[3 * f], nin[3 * f + 1], nin[3 * f + 2], eta[f], vdn);
+    specularity[i] = true_spec[i] ? sp : 0.0;
+    if (!true_spec[i]) spec_map[i] = -1;
+    const double c = (vdn > 0.0 ? vdn : 0.0) - sub[i];
+    rate[i] = rint(c * 1e10) / 1e10;
+}
+// creation_roulette = cumsum(rate) / max(cumsum) per facet (:938-939), the running sum in np.cumsum's own order: one wave per
+// facet reads 64 rates at a time (coalesced) and every lane adds them up one by one, keeping the sum at its own position.
+__global__ __launch_bounds__(64) void k_rough_cumsum(int M, double *rate_roul) {
+    double *r = rate_roul + (int64_t)blockIdx.x * M;
+    const int lane = threadIdx.x;
+    double run = 0.0, mx = -__builtin_inf();
+    for (int m0 = 0; m0 < M; m0 += 64) {
+        const double val = m0 + lane < M ? r[m0 + lane] : 0.0;
+        double mine = 0.0;
+        for (int k = 0; k < 64; ++k) {
+            run += __shfl(val, k, 64);
+            if (k == lane) mine = run;
+            if (m0 + k < M) mx = fmax(mx, run);
+        }
+        if (m0 + lane < M) r[m0 + lane] = mine;
+    }
+    for (int m = lane; m < M; m += 64) r[m] = r[m] / mx;
+}
+// bucket index of the roulette search (nk_reflect): lut[f][k] = first position with roulette >= k / nlut * last
+__global__ __launch_bounds__(NK_WG) void k_rough_lut(int Fr, int M, int nlut, const double *roul, int32_t *lut) {
+    const int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
+    if (i >= (int64_t)Fr * (nlut + 1)) return;
+    const int f = (int)(i / (nlut + 1)), k = (int)(i - (int64_t)f * (nlut + 1));
+    const double *ro = roul + (int64_t)f * M;
+    if (k == nlut) { lut[i] = M; return; }
+    const double thr = ((double)k / (double)nlut) * ro[M - 1];
+    lut[i] = nk_ss_left(ro, M, thr);
+}
+__global__ void k_fill_u32(unsigned int *p, int64_t n, unsigned int v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+// enter_probability (Population.py:146-161): p[r, m] = max(0, v . n_in) * dt / thickness_r
+__global__ __launch_bounds__(NK_WG) void k_enter_prob(int R, int M, const double *v, const double *nin, const double *thick, double dt,
+                                                     double *out) {
+    const int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
+    if (i >= (int64_t)R * M) return;
+    const int r = (int)(i / M), m = (int)(i - (int64_t)r * M);
+    const double p = (nin[3 * r] * v[3 * m] + nin[3 * r + 1] * v[3 * m + 1] + nin[3 * r + 2] * v[3 * m + 2]) * dt / thick[r];
+    out[i] = p < 0.0 ? 0.0 : p;
+}

@@ -77,7 +77,8 @@ EXPORTS = ['nk_device_count', 'nk_create', 'nk_destroy', 'nk_last_error', 'nk_se
            'nk_init_boundaries', 'nk_step', 'nk_download_particles', 'nk_get_subvol_temperature',
            'nk_set_subvol_temperature', 'nk_get_step', 'nk_get_timing', 'nk_comm_unique_id', 'nk_comm_init',
            'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2', 'nk_calibrate_stream',
-           'nk_specular_begin', 'nk_specular_pairs', 'nk_specular_end']
+           'nk_specular_begin', 'nk_specular_pairs', 'nk_specular_end', 'nk_rough_begin', 'nk_rough_pairs', 'nk_rough_finish',
+           'nk_rough_download', 'nk_build_enter_prob']
 
 _lib = None
 
@@ -121,6 +122,11 @@ def load_library():
     L.nk_specular_begin.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp]
     L.nk_specular_pairs.argtypes = [C.c_void_p, c_dp, C.c_double, C.c_int64, c_ip, c_ip, C.POINTER(C.c_int64)]
     L.nk_specular_end.argtypes = [C.c_void_p]
+    L.nk_rough_begin.argtypes = [C.c_void_p, C.c_int32, c_ip, c_dp, c_dp, c_dp]
+    L.nk_rough_pairs.argtypes = [C.c_void_p, C.c_int32, c_ip]
+    L.nk_rough_finish.argtypes = [C.c_void_p]
+    L.nk_rough_download.argtypes = [C.c_void_p, c_dp, c_up, c_ip, c_dp]
+    L.nk_build_enter_prob.argtypes = [C.c_void_p, C.c_int32, c_dp, c_dp, C.c_double, c_dp]
     _lib = L
     return L
 
@@ -376,6 +382,34 @@ class Engine(object):
 
     def specular_end(self):
         self._ck(self.L.nk_specular_end(self.h), 'nk_specular_end')
+
+    # ---- rough-facet tables built on the device (between specular_begin and specular_end; 'velocity' model)
+    def rough_begin(self, facets, normal_in, eta, k_norm):
+        f, n, e, k = _i(facets), _d(normal_in), _d(eta), _d(k_norm)
+        self._rough_Fr = f.shape[0]
+        self._ck(self.L.nk_rough_begin(self.h, f.shape[0], _p(f, c_ip), _p(n), _p(e), _p(k)), 'nk_rough_begin')
+
+    def rough_pairs(self, rough_facet_indices):
+        """The pairs of the last specular_pairs call (still on the device) for the rough facets that share its normal."""
+        f = _i(rough_facet_indices)
+        self._ck(self.L.nk_rough_pairs(self.h, f.shape[0], _p(f, c_ip)), 'nk_rough_pairs')
+
+    def rough_finish(self):
+        self._ck(self.L.nk_rough_finish(self.h), 'nk_rough_finish')
+
+    def rough_download(self):
+        """(specularity, true_spec, spec_map, roulette), each [Fr, M]."""
+        Fr, M = self._rough_Fr, self.M
+        sp, ts = np.zeros((Fr, M)), np.zeros((Fr, M), dtype=np.uint8)
+        sm, ro = np.zeros((Fr, M), dtype=np.int32), np.zeros((Fr, M))
+        self._ck(self.L.nk_rough_download(self.h, _p(sp), _p(ts, c_up), _p(sm, c_ip), _p(ro)), 'nk_rough_download')
+        return sp, ts, sm, ro
+
+    def build_enter_prob(self, normal_in, thickness, dt):
+        n, t = _d(normal_in), _d(thickness)
+        out = np.zeros((t.shape[0], self.M))
+        self._ck(self.L.nk_build_enter_prob(self.h, t.shape[0], _p(n), _p(t), float(dt), _p(out)), 'nk_build_enter_prob')
+        return out
 
     def calibrate_stream(self, launches=3):
         """Known-traffic sweeps for counter calibration; returns (bytes_read, bytes_written) per launch."""

@@ -194,24 +194,50 @@ class Population(Constants):
             self.creation_roulette = np.zeros((0, Q * J))
             self.degeneracies, self.degen_index = ST.find_degeneracies(phonon)
             return
-        spec0 = ST.fbz_specularity(geometry, phonon, self.rough_facets, self.rough_facets_values)
         self.k_model = self.scat_model in ('k', 'wavevector', 'wave_vector')
-        if self.k_model:
-            self.correspondent_modes, self.true_specular = ST.specular_correspondences_k(geometry, phonon, self.rough_facets)
-        elif self.scat_model in ('v', 'vel', 'velocity', 'groupvel', 'group_vel'):
-            self.correspondent_modes, self.true_specular = ST.specular_correspondences_velocity(
-                geometry, phonon, self.rough_facets,
-                engine=(self.engine if hasattr(self.engine, 'specular_begin') else None))   # pair search on the GPU
-        else:
+        self._rough_on_device = False
+        if not self.k_model and self.scat_model not in ('v', 'vel', 'velocity', 'groupvel', 'group_vel'):
             raise Exception('Invalid --bound_scat')
-        self.specularity = self.true_specular.astype(int) * spec0                  # Population.py:1459
-        self.spec_map = ST.specular_map(self.correspondent_modes, geometry, self.rough_facets, Q, J)
         self.degeneracies, self.degen_index = ST.find_degeneracies(phonon)
-        self.creation_rate, self.creation_roulette = ST.diffuse_roulette(
-            geometry, phonon, self.rough_facets, self.specularity, self.correspondent_modes, self.scat_model, self.degeneracies)
+        if not self.k_model and hasattr(self.engine, 'rough_begin'):
+            # 'velocity' model with a device engine: the tables are built in HBM and stay there; the host
+            # keeps the pairs.  specularity / true_specular / spec_map / creation_roulette: see rough_tables()
+            self._upload_material_and_mesh(geometry, phonon)
+            self.correspondent_modes = ST.rough_tables_device(self.engine, geometry, phonon, self.rough_facets, self.rough_facets_values)
+            self._rough_on_device = True
+            self.specularity = self.true_specular = self.spec_map = self.creation_roulette = None
+        else:
+            spec0 = ST.fbz_specularity(geometry, phonon, self.rough_facets, self.rough_facets_values)
+            if self.k_model:
+                self.correspondent_modes, self.true_specular = ST.specular_correspondences_k(geometry, phonon, self.rough_facets)
+            else:
+                self.correspondent_modes, self.true_specular = ST.specular_correspondences_velocity(
+                    geometry, phonon, self.rough_facets,
+                    engine=(self.engine if hasattr(self.engine, 'specular_begin') else None))   # pair search on the GPU
+            self.specularity = self.true_specular.astype(int) * spec0                  # Population.py:1459
+            self.spec_map = ST.specular_map(self.correspondent_modes, geometry, self.rough_facets, Q, J)
+            self.creation_rate, self.creation_roulette = ST.diffuse_roulette(
+                geometry, phonon, self.rough_facets, self.specularity, self.correspondent_modes, self.scat_model, self.degeneracies)
         if self.rank == 0 and self.results_folder_name:
             np.savetxt(os.path.join(self.results_folder_name, 'specular_correspondences.txt'), self.correspondent_modes,
                        fmt='%.3f %.3f %.3f %d %d %d %d')                            # Population.py:1461
+
+    def _upload_material_and_mesh(self, geometry, phonon):
+        """nk_set_material + nk_set_mesh, once (the device builders of the set-up tables need them before the rest)."""
+        if not getattr(self, '_tables_uploaded', False):
+            self.engine.set_material(phonon.tables() if hasattr(phonon, 'tables') else _phonon_tables(phonon))
+            self.engine.set_mesh(geometry.tables() if hasattr(geometry, 'tables') else _geometry_tables(geometry))
+            self._tables_uploaded = True
+
+    def rough_tables(self):
+        """(specularity, true_specular, spec_map, creation_roulette) as (Fr, Q*J) arrays: copied back from the device when
+        they were built there."""
+        if getattr(self, '_rough_on_device', False):
+            sp, ts, sm, ro = self.engine.rough_download()
+            return sp, ts.astype(bool), sm, ro
+        Q, J = self._ph.omega.shape
+        return (self.specularity.reshape(-1, Q * J), self.true_specular.reshape(-1, Q * J), self.spec_map.reshape(-1, Q * J),
+                self.creation_roulette)
 
     def initialise_reservoirs(self, geometry, phonon):
         """Population.py:323-354."""
@@ -224,7 +250,13 @@ class Population(Constants):
         self.res_facet_temperature[mask_temp] = self.res_bound_values[mask_temp]
         if mask_flux.any():
             self.res_facet_temperature[mask_flux] = self.res_bound_values[mask_temp].mean()
-        self.enter_prob = ST.enter_probability(geometry, phonon, self.res_facet, self.particle_density, self.dt)
+        if hasattr(self.engine, 'build_enter_prob'):                # enter_probability (Population.py:146-161) on the device
+            self._upload_material_and_mesh(geometry, phonon)
+            thick = phonon.number_of_active_modes / (self.particle_density * geometry.facets_area[self.res_facet])
+            Q, J = phonon.omega.shape
+            self.enter_prob = self.engine.build_enter_prob(-geometry.facets_normal[self.res_facet, :], thick, self.dt).reshape(-1, Q, J)
+        else:
+            self.enter_prob = ST.enter_probability(geometry, phonon, self.res_facet, self.particle_density, self.dt)
         self.res_counter = self.rng.random(self.enter_prob.shape)                   # Population.py:343
         self.N_leaving = np.sum(self.enter_prob, axis=(1, 2)).round().astype(int)
         self.res_energy_balance = np.zeros(self.n_of_reservoirs)
@@ -382,8 +414,7 @@ class Population(Constants):
 
     def _configure_engine(self, geometry, phonon):
         eng = self.engine
-        eng.set_material(phonon.tables() if hasattr(phonon, 'tables') else _phonon_tables(phonon))
-        eng.set_mesh(geometry.tables() if hasattr(geometry, 'tables') else _geometry_tables(geometry))
+        self._upload_material_and_mesh(geometry, phonon)
         if geometry.subvol_type == 'slice' and self.temp_interp_type in ('nearest', 'linear'):
             kind, axis, interp = 0, geometry.slice_axis, (1 if self.temp_interp_type == 'linear' else 0)
         elif self.temp_interp_type == 'nearest':
@@ -406,7 +437,7 @@ class Population(Constants):
                                self.res_counter.reshape(-1, Q * J),
                                gen={'constant': 0, 'fixed_rate': 1, 'one_to_one': 2}[self.res_gen],
                                n_leaving=(self.N_leaving if self.res_gen == 'one_to_one' else None))
-        if self.rough_facets.shape[0] > 0:
+        if self.rough_facets.shape[0] > 0 and not getattr(self, '_rough_on_device', False):
             degen_j2 = None
             if getattr(self, 'k_model', False):
                 # 'k' model: a specular out-mode with a degenerate partner lands on the pair's second branch with

@@ -6,7 +6,9 @@ Host-side NumPy restatements of the reference's one-off builders in classes/Popu
   find_specular_correspondences ('velocity' model) :1241-1454, specular_function :1457
   diffuse_scat_probability     :879-939
   find_degeneracies            :1017-1040
-The 'k' (wavevector) reflection model of :1058-1239 is not built yet.
+  find_specular_correspondences ('k' model)        :1058-1239
+With an engine the 'velocity' tables are built on the device (`rough_tables_device`): pair search, specularity, specular map,
+creation rates and roulette never leave HBM; the NumPy functions below are their CPU statements, pinned to the goldens.
 """
 import numpy as np
 
@@ -133,13 +135,48 @@ def specular_correspondences_velocity(geometry, phonon, rough_facets, crit=1e-3,
 
 def _corr_rows(n, pi, po, in_modes, out_modes, v_ref, true_spec, inv_normals, i_n):
     """Rows of correspondent_modes for one normal in the reference's order (by sorted reflected-vx of the in-mode, then
-    ascending out index within it) and the true_specular mask of the facets that share the normal."""
+    ascending out index within it) and the true_specular mask of the facets that share the normal (None: not wanted)."""
     key = np.lexsort((po, np.argsort(np.argsort(v_ref[:, 0], kind='stable'))[pi])) if pi.size else np.zeros(0, dtype=int)
     pi, po = pi[key], po[key]
     im, om_ = in_modes[pi], out_modes[po]
-    for fct in np.nonzero(inv_normals == i_n)[0]:
-        true_spec[fct, im[:, 0], im[:, 1]] = True
+    if true_spec is not None:
+        for fct in np.nonzero(inv_normals == i_n)[0]:
+            true_spec[fct, im[:, 0], im[:, 1]] = True
     return np.hstack((np.tile(n, (im.shape[0], 1)), im, om_))
+
+
+def rough_tables_device(engine, geometry, phonon, rough_facets, eta, crit=1e-3):
+    """The 'velocity' reflection tables built and kept on the device (nk_rough_begin / nk_rough_pairs / nk_rough_finish):
+    for every distinct normal the pair search (nk_specular_pairs) and, straight from the device-resident pairs, the
+    truly-specular mask, the specular map and what the pairs take out of the diffuse creation rates; then specularity,
+    rates, roulette and its bucket index for all facets at once.  Only the pairs come back to the host (they are the rows
+    of `correspondent_modes`, which the reference also writes to specular_correspondences.txt)."""
+    rough_facets = np.asarray(rough_facets)
+    normals = -np.round(geometry.facets_normal[rough_facets, :], decimals=10)
+    normals, inv_normals = np.unique(normals, axis=0, return_inverse=True)
+    inv_normals = np.asarray(inv_normals).ravel()
+    v = phonon.group_vel
+    Q, J = phonon.omega.shape
+    k_grid = phonon.q_to_k(np.absolute(1 / (2 * phonon.data_mesh)))
+    delta_omega = np.sum((v * k_grid) ** 2, axis=2) ** 0.5
+    k_norm = np.sum(phonon.wavevectors ** 2, axis=1) ** 0.5
+    engine.specular_begin(v.reshape(-1, 3), phonon.omega.ravel(), delta_omega.ravel())
+    engine.rough_begin(rough_facets, -geometry.facets_normal[rough_facets, :], np.asarray(eta, dtype=float).ravel(), k_norm)
+    rows = []
+    for i_n, n in enumerate(normals):
+        vdn = np.sum(v * n, axis=2)
+        in_modes = np.vstack(np.nonzero(vdn < 0)).T
+        out_modes = np.vstack(np.nonzero(vdn > 0)).T
+        v_in = v[in_modes[:, 0], in_modes[:, 1], :]
+        v_ref = v_in - 2 * n * np.sum(v_in * n, axis=1, keepdims=True)
+        gi, go = engine.specular_pairs(n, crit)
+        engine.rough_pairs(np.nonzero(inv_normals == i_n)[0])
+        pi = np.searchsorted(in_modes[:, 0] * J + in_modes[:, 1], gi)
+        po = np.searchsorted(out_modes[:, 0] * J + out_modes[:, 1], go)
+        rows.append(_corr_rows(n, pi, po, in_modes, out_modes, v_ref, None, inv_normals, i_n))
+    engine.rough_finish()
+    engine.specular_end()
+    return np.vstack(rows) if rows else np.zeros((0, 7))
 
 
 def specular_correspondences_k(geometry, phonon, rough_facets):
