@@ -1,5 +1,13 @@
 # Memory-latency counters of k_sweep (developer probe): separate --pmc passes, kernel-trace only.
-# (A TCC_EA0_*_LEVEL pass was tried once and never returned; it is not run here.)
+# Not run here: a pass with the TCC_EA0_*_LEVEL counters (TCC_EA0_RDREQ_LEVEL, _WRREQ_LEVEL: queue-depth accumulators of the
+# L2's memory side).  Round 1 tried one such pass once; the call ended at gpurun's time limit with nothing under gpurun_out/ --
+# no rocprofv3 log, no counter CSV (the box was killed before the merge), so the evidence ends there.  What is known: the
+# counters are listed for gfx950 (rocprofv3 -L: gpurun_out/counters.txt:2357-2400), the TCC block has 4 slots per pass
+# (MI355X_MICROARCH.md, PMC slots) and that pass asked for more than 4 TCC counters next to SQ ones, which makes rocprofv3
+# replay the workload in several passes; bench.py re-enqueues persistent kernels back to back, and every other multi-pass
+# request made since has been split by hand into passes of <= 4 TCC counters (scripts/profile_round.sh) and returned.  The
+# hang was not reproduced on purpose: a hung profiling pass costs a GPU-box strike.  If those counters are needed: ONE
+# counter per pass, `timeout -k 10 120` around the command, a 2-step bench (`--steps 2 --warmup 1 --repeats 1`).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 B="python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline"
