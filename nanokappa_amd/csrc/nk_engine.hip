@@ -1068,6 +1068,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     d.part = nk_want_part(ctx) ? 1 : 0;
     d.nseg = (int32_t)nseg;
     d.nlmax = d.M > 0 ? (int32_t)((d.M + nseg - 1) / nseg) : 1;
+    NK_ARG(d.nlmax < (1 << 14), "too many modes per segment for k_emit's packed entry word: use more particles (segments) or fewer modes");
     {   // bits of the stored mode index; the rest of the 32-bit word holds facet + 1
         const int64_t maxidx = d.part ? d.nlmax - 1 : (d.M > 0 ? d.M - 1 : 0);
         int lb = 1;

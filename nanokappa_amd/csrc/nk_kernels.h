@@ -393,9 +393,10 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                     const int e = e0 + k * 64 + lane;
                     int c = 0, cmine = 0;
                     double cv = 0.0, prob = 0.0;
-                    unsigned int rm32 = 0;
+                    unsigned int rm32 = 0, rl = 0;
                     if (e < nent) {
                         const int r = e / sm.nl, l = e - r * sm.nl;
+                        rl = ((unsigned int)r << 12) | ((unsigned int)l << 18);      // c < 4096, R <= 64, l < 2^14
                         const int64_t rm = (int64_t)r * d.M + ((int64_t)l * d.nseg + seg);
                         const int64_t at = ((int64_t)seg * d.R + r) * d.nlmax + l;
                         prob = d.ep_p[at];
@@ -406,7 +407,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                     unsigned int v = (unsigned int)cmine;
 #pragma unroll
                     for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
-                    sp_cnt[k * 64 + lane] = (unsigned int)c;
+                    sp_cnt[k * 64 + lane] = (unsigned int)c | rl;
                     sp_rm[k * 64 + lane] = rm32;
                     sp_cv[k * 64 + lane] = cv;
                     sp_pr[k * 64 + lane] = prob;
@@ -420,7 +421,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                 const int j = spj + lane;
                 if (j >= spn) continue;
                 int64_t rm;
-                int level;
+                int level, r, idx;
                 double prob = 0.0, cval = 0.0;
                 uint64_t o2o = 0;
                 if (d.res_gen == 2) {
@@ -428,12 +429,18 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                     rm = (int64_t)((recd >> 12) & 0xFFFFFFFull);
                     level = 0;                              // 'one_to_one': entry time uniform in the step
                     o2o = recd >> 40;
+                    r = (int)((uint32_t)rm / (uint32_t)d.M);                        // rm < 2^28
+                    const int mode = (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
+                    idx = d.part ? (int)((uint32_t)mode / (uint32_t)d.nseg) : mode;
                 } else {
                     // the entry this particle belongs to: the last one whose exclusive prefix is <= j
                     int lo = 0, hi = NK_EMIT_CHUNK;
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)sp_pref[mid] <= j) lo = mid; else hi = mid; }
-                    const int q = j - (int)sp_pref[lo], c = (int)sp_cnt[lo];
+                    const unsigned int cw = sp_cnt[lo];
+                    const int q = j - (int)sp_pref[lo], c = (int)(cw & 0xFFFu);
+                    r = (int)((cw >> 12) & 0x3Fu);
                     rm = (int64_t)sp_rm[lo];
+                    idx = d.part ? (int)(cw >> 18) : (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
                     cval = sp_cv[lo];
                     prob = sp_pr[lo];
                     // the q-th level this rank owns, counted down from c (nk_emit_entry's order)
@@ -445,9 +452,6 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                         level = (int)(top - (uint32_t)q * n);
                     }
                 }
-                const int r = (int)((uint32_t)rm / (uint32_t)d.M);              // rm < 2^28
-                const int mode = (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
-                const int idx = d.part ? (int)((uint32_t)mode / (uint32_t)d.nseg) : mode;
                 const NkMode *rec = sm.rec + idx;
                 const double4 ra = *reinterpret_cast<const double4 *>(rec);
                 const double E0 = rec->E0;
@@ -456,9 +460,10 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                 double uf, us, ur, ut;
                 nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
                 nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
+                const double iprob = level > 0 ? nk_rcp(prob) : 0.0;
                 const double dt_in = (level == 0) ? d.dt * ut                               // one_to_one :482
-                                   : (level == 1) ? d.dt * (1.0 - (cval / prob))
-                                                  : d.dt * (1.0 - ((double)(level - 1) + ut) / prob);
+                                   : (level == 1) ? d.dt * (1.0 - cval * iprob)
+                                                  : d.dt * (1.0 - ((double)(level - 1) + ut) * iprob);
                 double x0, y0, z0;
                 if (GEOM == 1 && d.res_lds) nk_sample_res_face(L.rf_off, L.rf_cdf, L.rf_verts, r, uf, us, ur, x0, y0, z0);
                 else nk_sample_res_face(d.res_face_off, d.res_face_cdf, d.res_face_verts, r, uf, us, ur, x0, y0, z0);
