@@ -1479,6 +1479,10 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
             }
             int32_t zero4[4] = {0, 0, 0, 0};
             NK_HIP(hipMemcpy(d.halt, zero4, 16, hipMemcpyHostToDevice));
+            if (hw[2] && d.nranks > 1) {
+                ctx->err = "nk_step: a segment could not take its migrating particles on this rank (the ranks would no longer halt together); reserve more capacity";
+                return NK_ERR_CAPACITY;
+            }
             if (hw[2]) {                                 // migrants that did not fit: they do now
                 k_deliver<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(d);
                 NK_HIP(hipGetLastError());

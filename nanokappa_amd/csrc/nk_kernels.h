@@ -930,9 +930,10 @@ __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
         if (lane == 0) {
             d.seg_count[seg] = count + n;
             d.mig_n[seg] = 0;
-            // room for the next step: its emission and about as many migrants again
+            // room for the next TWO steps (emission and about as many migrants again): the request travels with the next step's
+            // tally vector, so that every rank halts at the same step
             const int bound = d.R > 0 ? d.seg_bound[seg] : 0;
-            if ((int64_t)count + n + bound + 2 * n + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt, 1);
+            if ((int64_t)count + n + 2 * (bound + 2 * n) + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
             if (2 * n > d.mig_cap) atomicOr(d.halt + 3, 1);
         }
     }

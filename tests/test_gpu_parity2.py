@@ -103,12 +103,14 @@ def test_long_run_vs_oracle(case):
     compare_by_pid(eng.download(), sim)
 
 
-def test_store_grows_by_itself(monkeypatch):
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
+def test_store_grows_by_itself(case, monkeypatch):
     """Six times the entry rate into a store with hardly any head room (NK_TIGHT_STORE): the ensemble outgrows it several
     times over.  nk_step must stop before a step that could drop a particle, grow the segments on the device and carry
-    on -- the run equals the oracle's throughout."""
+    on -- the run equals the oracle's throughout.  'ttrrp': with rough walls the particles also change segment (a
+    reflection changes the mode), through inboxes that must keep up."""
     monkeypatch.setenv('NK_TIGHT_STORE', '1')
-    ct = case_tables('ttp')
+    ct = case_tables(case)
     pos, mode, occ, counter = random_population(ct, 20000, seed=9)
     sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=3, cap=600000, emit_scale=6.0)
     eng = make_engine(ct, pos, mode, occ, counter, seed=3, emit_scale=6.0)
