@@ -83,6 +83,9 @@ struct NkLds {
 // geom: 0 = no ray-casting tables, 1 = planes/faces/facets staged in LDS, 2 = read from global memory (large meshes)
 // nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged); kind: 0 plain, 1 + k_emit's scratch,
 // 2 + the sweep's mode records and output ring, 3 the same with particle ids
+#ifndef NK_LREC_STRIDE
+#define NK_LREC_STRIDE 5     // 16-byte units between the LDS copies of two mode records: 4 = packed (64 B), 5 spreads the banks
+#endif
 #ifndef NK_OUT_RING
 #define NK_OUT_RING 0        // 1: finished particles go through an LDS ring and leave in whole aligned tiles (NkOut below)
 #endif
@@ -94,7 +97,7 @@ __host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int 
     int Fcl = geom == 1 ? Fc : 0;
     size_t nd = (size_t)S + (size_t)((rbfP + 1) & ~1) + 3 * S + ((3 * S) & 1) + 4 * (size_t)S + NK_NREP * S + NK_NREP * 3 * S + 4 * R +
                 (size_t)Fl * NK_FACE_DOUBLES + (size_t)Pl * NK_PLANE_DOUBLES + 2 * (size_t)R + 10 * (size_t)nrf +
-                (emit ? 2 * (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (size_t)(NK_WG / 64) * (NK_LREC * 8 + NK_ORING * (kind == 3 ? 6 : 5)) : 0) + 4;
+                (emit ? 2 * (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (size_t)(NK_WG / 64) * (NK_LREC * 2 * NK_LREC_STRIDE + NK_ORING * (kind == 3 ? 6 : 5)) : 0) + 4;
     size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) +
                    (size_t)(NK_NREP * S + R + 1 + (R + 1) + (emit ? 3 * (NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (NK_WG / 64) * NK_ORING : 0)) * 4 + 32;
     return (bytes + 15) & ~(size_t)15;
@@ -127,7 +130,7 @@ __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem
     if (EMIT) { L.sp_cv = p; p += (NK_WG / 64) * NK_EMIT_CHUNK; L.sp_pr = p; p += (NK_WG / 64) * NK_EMIT_CHUNK; } else L.sp_cv = L.sp_pr = nullptr;
     p += ((size_t)(p - (double *)smem) & 1);           // keep the records and the facet table 16-byte aligned
     if (KIND >= 2) {
-        L.lrec = p; p += (NK_WG / 64) * NK_LREC * 8;
+        L.lrec = p; p += (NK_WG / 64) * NK_LREC * 2 * NK_LREC_STRIDE;
         L.oring = p; p += (NK_WG / 64) * NK_ORING * (KIND == 3 ? 6 : 5);
     } else { L.lrec = nullptr; L.oring = nullptr; }
     NkFacet *facets = (NkFacet *)p;
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
     const int rep = lane & (NK_NREP - 1);
     const unsigned long long lower = (1ull << lane) - 1ull;
     const uint32_t lbmask = (1u << d.lb) - 1u;
-    double4 *lrec = reinterpret_cast<double4 *>(L.lrec) + wave * NK_LREC * 2;
+    double2 *lrec = reinterpret_cast<double2 *>(L.lrec) + wave * NK_LREC * NK_LREC_STRIDE;
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
@@ -605,7 +608,8 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
             if (lane < sm.nl) {
                 const double4 *g = reinterpret_cast<const double4 *>(sm.rec + lane);
                 const double4 a = g[0], b = g[1];
-                lrec[2 * lane] = a; lrec[2 * lane + 1] = b;
+                double2 *q = lrec + lane * NK_LREC_STRIDE;
+                q[0] = make_double2(a.x, a.y); q[1] = make_double2(a.z, a.w); q[2] = make_double2(b.x, b.y); q[3] = make_double2(b.z, b.w);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
@@ -649,7 +653,11 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 w0 &= ~NK_NEWBORN;
                 const int idx = act ? (int)(w0 & lbmask) : 0;
                 double4 ra, rb;                                                      // {omega, v} {E0, tau rows}
-                if (use_lrec) { ra = lrec[2 * idx]; rb = lrec[2 * idx + 1]; }
+                if (use_lrec) {
+                    const double2 *q = lrec + idx * NK_LREC_STRIDE;
+                    const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                    ra = make_double4(q0.x, q0.y, q1.x, q1.y); rb = make_double4(q2.x, q2.y, q3.x, q3.y);
+                }
                 else { const double4 *g = reinterpret_cast<const double4 *>(sm.rec + idx); ra = g[0]; rb = g[1]; }
                 omega = ra.x; vx = ra.y; vy = ra.z; vz = ra.w; E0 = rb.x;
 #ifdef NK_STAMPS
@@ -718,9 +726,11 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
 #else
                     if (use_lrec && (int)((uint32_t)p.mode - q * (uint32_t)sm.mstride) == sm.moff) {
 #endif
-                        const double4 ra = lrec[2 * q];
+                        const double2 *lq = lrec + q * NK_LREC_STRIDE;
+                        const double2 l0 = lq[0], l1 = lq[1];
+                        const double4 ra = make_double4(l0.x, l0.y, l1.x, l1.y);
                         p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
-                        p.E0 = reinterpret_cast<const double *>(lrec)[8 * q + 4];
+                        p.E0 = lq[2].x;
                     } else {
                         const NkMode *rec = d.modetab + p.mode;
                         const double4 ra = *reinterpret_cast<const double4 *>(rec);
@@ -729,9 +739,11 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                     }
                 } else {
                     if (use_lrec) {
-                        const double4 ra = lrec[2 * idx0];
+                        const double2 *lq = lrec + idx0 * NK_LREC_STRIDE;
+                        const double2 l0 = lq[0], l1 = lq[1];
+                        const double4 ra = make_double4(l0.x, l0.y, l1.x, l1.y);
                         p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
-                        p.E0 = reinterpret_cast<const double *>(lrec)[8 * idx0 + 4];
+                        p.E0 = lq[2].x;
                     } else {
                         const double4 ra = *reinterpret_cast<const double4 *>(sm.rec + idx0);
                         p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
