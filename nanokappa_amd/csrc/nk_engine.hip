@@ -1695,6 +1695,25 @@ int nk_calibrate_stream(nk_ctx *ctx, int32_t launches, int64_t *bytes_read, int6
     for (int k = 0; k < launches; ++k) k_cal_stream<<<nk_sweep_grid(ctx), NK_WG, 0, ctx->stream>>>(ctx->d);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
+    if (const char *pc = getenv("NK_PROBE_COPY")) {      // developer probe: copy floor of the sweep's wave structure
+        hipEvent_t e0, e1;
+        NK_HIP(hipEventCreate(&e0)); NK_HIP(hipEventCreate(&e1));
+        const int g = ctx->g_sweep > 0 ? ctx->g_sweep : ctx->num_cu * 3;
+        for (int w = 8; w <= 16; w += 8) {
+            if (atoi(pc) != w && atoi(pc) != 0) continue;
+            for (int rep = 0; rep < 3; ++rep) {
+                NK_HIP(hipEventRecord(e0, ctx->stream));
+                for (int k = 0; k < 10; ++k) { if (w == 8) k_probe_copy<8><<<g, NK_WG, 0, ctx->stream>>>(ctx->d); else k_probe_copy<16><<<g, NK_WG, 0, ctx->stream>>>(ctx->d); }
+                NK_HIP(hipEventRecord(e1, ctx->stream));
+                NK_HIP(hipStreamSynchronize(ctx->stream));
+                float ms = 0.f;
+                hipEventElapsedTime(&ms, e0, e1);
+                fprintf(stderr, "[nanokappa_hip] copy probe, %d-byte accesses: %.1f us per pass over %lld particles (%.2f TB/s)\n", w, 100.0 * ms,
+                        (long long)ns, 88.0 * ns / (ms * 1e-4) / 1e12);
+            }
+        }
+        hipEventDestroy(e0); hipEventDestroy(e1);
+    }
     if (bytes_read) *bytes_read = ns * 44;
     if (bytes_written) *bytes_written = ns * 32;
     return NK_OK;

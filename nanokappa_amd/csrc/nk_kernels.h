@@ -1245,6 +1245,41 @@ __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
         }
     }
 }
+// Developer probe (NK_PROBE_COPY=8|16 + nk_calibrate_stream): the sweep's wave-per-segment tile loop with one tile prefetched,
+// copying the particle state in place -- the bandwidth floor of that structure with 8-byte (one particle per lane) or 16-byte
+// (two particles per lane) accesses.
+template <int W>
+__global__ __launch_bounds__(NK_WG, 3) void k_probe_copy(NkDev d) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * (NK_WG / 64);
+    constexpr int PPL = W / 8;                         // particles per lane
+    for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg] & ~(64 * PPL - 1);        // whole tiles only (a probe)
+        if (PPL == 1) {
+            double xN = 0, yN = 0, zN = 0, oN = 0, nN = 0; uint32_t wN = 0;
+            if (count > 0) { const int64_t i = base + lane; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; oN = d.occ[i]; nN = d.nts[i]; wN = d.w0[i]; }
+            for (int r = 0; r < count; r += 64) {
+                const double x = xN, y = yN, z = zN, o = oN, n = nN; const uint32_t w = wN;
+                if (r + 64 < count) { const int64_t i = base + r + 64 + lane; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; oN = d.occ[i]; nN = d.nts[i]; wN = d.w0[i]; }
+                const int64_t i = base + r + lane;
+                d.x[i] = x + 1e-300; d.y[i] = y; d.z[i] = z; d.occ[i] = o; d.nts[i] = n; d.w0[i] = w;
+            }
+        } else {
+            double2 xN = {0, 0}, yN = {0, 0}, zN = {0, 0}, oN = {0, 0}, nN = {0, 0}; uint2 wN = {0, 0};
+            double2 *X = (double2 *)(d.x + base), *Y = (double2 *)(d.y + base), *Z = (double2 *)(d.z + base), *O = (double2 *)(d.occ + base),
+                    *N = (double2 *)(d.nts + base);
+            uint2 *Wp = (uint2 *)(d.w0 + base);
+            if (count > 0) { xN = X[lane]; yN = Y[lane]; zN = Z[lane]; oN = O[lane]; nN = N[lane]; wN = Wp[lane]; }
+            for (int r = 0; r < count / 2; r += 64) {
+                const double2 x = xN, y = yN, z = zN, o = oN, n = nN; const uint2 w = wN;
+                if (r + 64 < count / 2) { const int i = r + 64 + lane; xN = X[i]; yN = Y[i]; zN = Z[i]; oN = O[i]; nN = N[i]; wN = Wp[i]; }
+                const int i = r + lane;
+                X[i] = make_double2(x.x + 1e-300, x.y); Y[i] = y; Z[i] = z; O[i] = o; N[i] = n; Wp[i] = w;
+            }
+        }
+    }
+}
 __global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *out) {
     double a, b;
     nk_uniform2_dev(seed, pid, step, tag, a, b);
