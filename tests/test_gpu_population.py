@@ -1,5 +1,13 @@
 """End-to-end Population runs on the GPU against the reference's statistical goldens
-(tests/golden/stats_*.npz: 8 seeds x 1e5 particles x 1000 steps of the reference itself)."""
+(tests/golden/stats_*.npz: 8 seeds x 1e5 particles x 1000 steps of the reference itself).
+
+The criterion, stated once (engine and reference use different random number generators, so this is a two-sample test):
+the difference of the two means against its standard error, se^2 = var_ref / n_ref + var_gpu / n_gpu,
+  |mean_gpu - mean_ref| < 3 se   for every scalar tested (each subvolume temperature, the heat flux, kappa),
+and the particle count within 1 %.  SURVEY 8d words it as "within 2 sigma_seed of the oracle mean", sigma_seed being the
+scatter of ONE run: with n_ref = 8 and n_gpu = 4, 3 se = 1.8 sigma_seed -- the test here is the tighter of the two.  Where
+many quantities are tested at once with 4 + 4 runs (the 18 + 18 of the grid case) the bound is 4 se, with the variance
+pooled over the statistically equivalent subvolumes: at 3 se one of 36 such tests would fail by chance in one run of ten."""
 import os
 import sys
 
@@ -49,7 +57,7 @@ def test_statistical_parity_with_reference(case, tmp_path):
     """Same configuration as the reference goldens (C1a / C1b of SURVEY 8d, 729 x 6 synthetic Si; 'film' and 'wire' are
     BASELINE configs 3 and 4 in small -- the wire's 400 triangles go through the face-tree ray caster): per-subvolume
     temperature, heat flux, kappa and particle count, averaged over steps 500-1000, must lie within the
-    reference's seed-to-seed scatter (criterion of SURVEY 8d: 2 sigma on T / phi / kappa, 1 % on N_p)."""
+    reference's seed-to-seed scatter (criterion: module docstring -- 3 standard errors of the difference, 1 % on N_p)."""
     g = golden('stats_' + case)
     Tr, phir, kr, Npr = window_stats(g['rows'])
     seeds = [101, 102, 103, 104]
@@ -80,7 +88,8 @@ def test_statistical_parity_with_reference(case, tmp_path):
 def test_large_ensemble_agrees_with_reference_mean():
     """BASELINE config 2's topology at 3e6 particles (30x the reference runs): its own noise is far below the
     reference's seed-to-seed scatter, so flux and kappa must sit on the mean of the 8 reference runs within the
-    standard error of that mean (3 sigma) -- 'kappa within 2 sigma of the CPU reference' at scale.  The temperatures of
+    standard error of that mean (3 standard errors, the module's criterion) -- the north star's 'kappa within 2 sigma of the
+    CPU reference' at scale.  The temperatures of
     the slices next to the reservoirs move by 0.01 K with the number of particles (both ways: 3e4 -> 300.469, 1e5 ->
     300.475, 3e6 -> 300.465 in the first slice; at 1e5 particles 32 engine runs give 300.4752 +- 0.0002 against the
     reference's 300.4748 +- 0.0007, scripts/nbias_probe.py) -- the 'constant' generator's entry times depend on
