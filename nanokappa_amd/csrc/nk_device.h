@@ -8,8 +8,8 @@
 // Modes are PARTITIONED over the segments: mode m belongs to segment m % nseg and is stored as the local index m / nseg
 // (a few bits).  A segment therefore only ever touches its own few dozen 64-byte mode records (they sit contiguously in a
 // permuted copy of the mode table and stay in L1/L2), and it emits the reservoir particles of its own modes itself: no
-// spawn list, no global atomics, no gathers across an 11 MB table.  (With rough facets a reflection changes the mode, so
-// those configurations store the global mode index and gather from the plain table, as before; emission is still local.)
+// spawn list, no global atomics, no gathers across an 11 MB table.  (With rough facets a reflection changes the mode: such a
+// particle finishes its step where it is and then migrates to the owning segment through that segment's inbox, k_deliver.)
 // Small read-only tables (planes, faces, facets, per-slice {centre, T, slope, 1/T}) and the tally bins live in LDS.
 //
 // Reference semantics cited as file:line under the reference checkout (classes/Population.py etc.).

@@ -15,7 +15,7 @@ def shard_range(n, rank, nranks):
 
 def emission_owner(rm, level, step, nranks):
     """Rank that creates the `level`-th particle of reservoir-mode entry `rm` at `step`.  Every rank advances all
-    reservoir counters identically and keeps only its own entries (k_emit_count in csrc/nk_kernels.h)."""
+    reservoir counters identically and keeps only its own entries (nk_emit_entry / k_emit in csrc/nk_kernels.h)."""
     return (rm + level + step) % nranks
 
 
