@@ -125,16 +125,19 @@ static inline size_t nk_lds(const nk_ctx *ctx, bool geom, int kind = 0) {
     } while (0)
 static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
 // The sweep is instantiated per (table placement, rough facets, RBF temperatures, particle ids, split): run STMT with
-// KERNEL bound to the one that matches.  Rough facets draw random numbers per particle, so they imply ids.
-#define NK_SWEEP_CASE(G, R, B, P, S, STMT) { auto KERNEL = k_sweep<G, R, B, P, S>; STMT; }
-#define NK_SWEEP_CASE_S(G, R, B, P, split, STMT) { if (split) NK_SWEEP_CASE(G, R, B, P, true, STMT) else NK_SWEEP_CASE(G, R, B, P, false, STMT) }
-#define NK_SWEEP_CASE_RP(G, B, rough, pid, split, STMT)                                               \
-    { if (rough) NK_SWEEP_CASE_S(G, true, B, true, split, STMT) else if (pid) NK_SWEEP_CASE_S(G, false, B, true, split, STMT) else NK_SWEEP_CASE_S(G, false, B, false, split, STMT) }
-#define NK_SWEEP_DISPATCH(gm, rough, rbf, pid, split, STMT)                                           \
+// KERNEL bound to the one that matches.  Rough facets draw random numbers per particle, so they imply ids.  The last
+// parameter says where the mode records are read from (LDS copies of the segment's share, or the table in HBM).
+#define NK_SWEEP_CASE(G, R, B, P, S, lrec, STMT) { if (lrec) { auto KERNEL = k_sweep<G, R, B, P, S, true>; STMT; } else { auto KERNEL = k_sweep<G, R, B, P, S, false>; STMT; } }
+#define NK_SWEEP_CASE_S(G, R, B, P, split, lrec, STMT) { if (split) NK_SWEEP_CASE(G, R, B, P, true, lrec, STMT) else NK_SWEEP_CASE(G, R, B, P, false, lrec, STMT) }
+#define NK_SWEEP_CASE_RP(G, B, rough, pid, split, lrec, STMT)                                         \
+    { if (rough) NK_SWEEP_CASE_S(G, true, B, true, split, lrec, STMT) else if (pid) NK_SWEEP_CASE_S(G, false, B, true, split, lrec, STMT) else NK_SWEEP_CASE_S(G, false, B, false, split, lrec, STMT) }
+#define NK_SWEEP_DISPATCH(gm, rough, rbf, pid, split, lrec, STMT)                                     \
     do {                                                                                               \
-        if ((gm) == 1) { if (rbf) NK_SWEEP_CASE_RP(1, true, rough, pid, split, STMT) else NK_SWEEP_CASE_RP(1, false, rough, pid, split, STMT) }   \
-        else { if (rbf) NK_SWEEP_CASE_RP(2, true, rough, pid, split, STMT) else NK_SWEEP_CASE_RP(2, false, rough, pid, split, STMT) }             \
+        if ((gm) == 1) { if (rbf) NK_SWEEP_CASE_RP(1, true, rough, pid, split, lrec, STMT) else NK_SWEEP_CASE_RP(1, false, rough, pid, split, lrec, STMT) }   \
+        else { if (rbf) NK_SWEEP_CASE_RP(2, true, rough, pid, split, lrec, STMT) else NK_SWEEP_CASE_RP(2, false, rough, pid, split, lrec, STMT) }             \
     } while (0)
+// the sweep keeps its segments' mode records in LDS when the modes are partitioned over the segments and a segment's share fits
+static inline bool nk_want_lrec(const nk_ctx *ctx) { return ctx->d.part && ctx->d.nlmax <= NK_LREC; }
 // k_events, the same way
 #define NK_EVENTS_CASE(G, R, B, P, STMT) { auto KERNEL = k_events<G, R, B, P>; STMT; }
 #define NK_EVENTS_CASE_RP(G, B, rough, pid, STMT)                                                     \
@@ -1019,12 +1022,13 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     if (!(ctx->have_material && ctx->have_mesh && ctx->have_sv)) return ctx->num_cu * NK_SWEEP_OCC;
     const int gm_ = nk_geom_mode(ctx);
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx), split_ = nk_want_split(ctx);
-    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4) | (split_ << 5);
+    const bool lrec_ = nk_want_lrec(ctx);
+    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4) | (split_ << 5) | (lrec_ << 6);
     if (ctx->g_sweep == 0 || ctx->g_sweep_key != key) {
         const size_t lds_w = nk_lds(ctx, true, pid_ ? 3 : 2);
         int per_cu = 0;
         hipError_t e_ = hipSuccess;
-        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
+        NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, lrec_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
         if (e_ != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
         if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
@@ -1319,6 +1323,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, d.pid ? 3 : 2), lds_e = nk_lds(ctx, true, 1);
     const int gm_ = nk_geom_mode(ctx);
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = d.pid != nullptr, split_ = d.qx != nullptr;
+    const bool lrec_ = nk_want_lrec(ctx);
     (void)nk_sweep_blocks(ctx);
     const int g_sweep = ctx->g_sweep < (d.nseg + 3) / 4 ? ctx->g_sweep : (d.nseg + 3) / 4;
     const int g_emit = ctx->num_cu * 8 < (d.nseg + 3) / 4 ? ctx->num_cu * 8 : (d.nseg + 3) / 4;
@@ -1354,7 +1359,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
         {
             const int rl = pending ? 1 : 0;
-            NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux)));
+            NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, lrec_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux)));
             if (split_) NK_EVENTS_DISPATCH(gm_, rough_, rbf_, pid_, (KERNEL<<<g_ev, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, g_sweep)));
         }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));

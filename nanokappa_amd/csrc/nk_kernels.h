@@ -560,6 +560,14 @@ struct NkOut {
     }
 };
 
+// LDS copies of mode records are read through pointers that carry the LDS address space in their type.  With plain
+// pointers the compiler merges "record from LDS" and "record from the table in HBM" into one FLAT load behind a selected
+// pointer; a flat load counts in vmcnt, which retires in order, so waiting for the record would also wait for the next
+// tile's prefetch issued just before it -- the prefetch would hide nothing.
+typedef double nk_v2d __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) nk_v2d *NkLdsRec;
+__device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLdsRec)(const void *)q; }
+
 // The sweep: persistent WAVES, each taking segments w, w + n_waves, ...  A wave owns its segment, so the loop needs no
 // workgroup barrier: the four waves of a workgroup only share the read-only tables and the tally bins (LDS atomics).
 // Per segment ONE loop over 64-particle tiles (the particles that were there, then the newborn ones k_emit appended), and
@@ -584,7 +592,7 @@ struct NkOut {
 #ifndef NK_SWEEP_OCC_SPLIT
 #define NK_SWEEP_OCC_SPLIT 4
 #endif
-template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT>
+template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC>
 __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || ROUGH || RBF) ? 2 : NK_SWEEP_OCC)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
@@ -603,7 +611,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
         const int count = d.seg_count[seg] + nnew;
         if (lane == 0 && nnew > 0) atomicAdd(&L.bins.misc[0], (unsigned int)nnew);          // "emitted" column
         const NkSegModes sm = nk_seg_modes(d, seg);
-        const bool use_lrec = d.part && sm.nl <= NK_LREC;
+        constexpr bool use_lrec = LREC;             // host: the modes are partitioned and every segment's share fits (nk_want_lrec)
         if (use_lrec) {
             if (lane < sm.nl) {
                 const double4 *g = reinterpret_cast<const double4 *>(sm.rec + lane);
@@ -654,8 +662,8 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 const int idx = act ? (int)(w0 & lbmask) : 0;
                 double4 ra, rb;                                                      // {omega, v} {E0, tau rows}
                 if (use_lrec) {
-                    const double2 *q = lrec + idx * NK_LREC_STRIDE;
-                    const double2 q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
+                    const NkLdsRec q = nk_lds_rec(lrec + idx * NK_LREC_STRIDE);
+                    const nk_v2d q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3];
                     ra = make_double4(q0.x, q0.y, q1.x, q1.y); rb = make_double4(q2.x, q2.y, q3.x, q3.y);
                 }
                 else { const double4 *g = reinterpret_cast<const double4 *>(sm.rec + idx); ra = g[0]; rb = g[1]; }
@@ -726,8 +734,8 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
 #else
                     if (use_lrec && (int)((uint32_t)p.mode - q * (uint32_t)sm.mstride) == sm.moff) {
 #endif
-                        const double2 *lq = lrec + q * NK_LREC_STRIDE;
-                        const double2 l0 = lq[0], l1 = lq[1];
+                        const NkLdsRec lq = nk_lds_rec(lrec + q * NK_LREC_STRIDE);
+                        const nk_v2d l0 = lq[0], l1 = lq[1];
                         const double4 ra = make_double4(l0.x, l0.y, l1.x, l1.y);
                         p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                         p.E0 = lq[2].x;
@@ -739,8 +747,8 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                     }
                 } else {
                     if (use_lrec) {
-                        const double2 *lq = lrec + idx0 * NK_LREC_STRIDE;
-                        const double2 l0 = lq[0], l1 = lq[1];
+                        const NkLdsRec lq = nk_lds_rec(lrec + idx0 * NK_LREC_STRIDE);
+                        const nk_v2d l0 = lq[0], l1 = lq[1];
                         const double4 ra = make_double4(l0.x, l0.y, l1.x, l1.y);
                         p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                         p.E0 = lq[2].x;
