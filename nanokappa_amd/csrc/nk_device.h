@@ -162,7 +162,8 @@ struct NkDev {
     double *qx, *qy, *qz, *qocc, *qnts;
     uint32_t *qw0;
     uint64_t *qpid;
-    int32_t *seg_evq;                 // [nseg] entries in each segment's queue
+    int32_t *seg_evq;                 // [2 nseg + 1] entries in each segment's queue, then their exclusive prefix sums (k_events_begin)
+    int32_t *ev_ticket;               // next entry of the concatenated queues to hand out (k_events)
     // ---- migration (rough facets: a reflection changes a particle's mode, hence the segment that owns it)
     double2 *mig_buf;                 // [nseg * mig_cap * 4] 64-byte records {x, y} {z, occ} {nts, pid} {w0, -, -, -}
     int32_t *mig_n;                   // [nseg] records waiting in each segment's inbox (k_deliver empties them every step)
@@ -578,17 +579,22 @@ __device__ __forceinline__ NkRayF nk_ray_f32(double x, double y, double z, doubl
     r.ex = r.cx * fabsf(r.ix); r.ey = r.cy * fabsf(r.iy); r.ez = r.cz * fabsf(r.iz);
     return r;
 }
-// Does the ray cross the box lo = (b0.x, b0.y, b0.z), hi = (b0.w, b1.x, b1.y) before tmax ?
+// Does the ray cross the box lo = (lx, ly, lz), hi = (hx, hy, hz) before tmax ?  Written without branches (four of these run
+// per visit, and a branch per axis costs more scalar bookkeeping than the arithmetic it skips): per axis both answers are
+// formed -- the slab's entry / exit distances, and for a ray parallel to the slab whether it lies outside -- and selected.
 __device__ __forceinline__ bool nk_ray_box(float lx, float ly, float lz, float hx, float hy, float hz, const NkRayF &r, float tmax) {
-    float t0 = 0.0f, t1 = tmax;
-    bool miss = false;
-    if (r.px) { const float a = (lx - r.x) * r.ix, b = (hx - r.x) * r.ix; t0 = fmaxf(t0, fminf(a, b) - r.ex); t1 = fminf(t1, fmaxf(a, b) + r.ex); }
-    else miss |= (r.x < lx - r.cx) | (r.x > hx + r.cx);
-    if (r.py) { const float a = (ly - r.y) * r.iy, b = (hy - r.y) * r.iy; t0 = fmaxf(t0, fminf(a, b) - r.ey); t1 = fminf(t1, fmaxf(a, b) + r.ey); }
-    else miss |= (r.y < ly - r.cy) | (r.y > hy + r.cy);
-    if (r.pz) { const float a = (lz - r.z) * r.iz, b = (hz - r.z) * r.iz; t0 = fmaxf(t0, fminf(a, b) - r.ez); t1 = fminf(t1, fmaxf(a, b) + r.ez); }
-    else miss |= (r.z < lz - r.cz) | (r.z > hz + r.cz);
-    return !miss && t0 <= t1;
+    const float inf = __builtin_inff();
+    const float ax = (lx - r.x) * r.ix, bx = (hx - r.x) * r.ix;
+    const float ay = (ly - r.y) * r.iy, by = (hy - r.y) * r.iy;
+    const float az = (lz - r.z) * r.iz, bz = (hz - r.z) * r.iz;
+    const float nx = r.px ? fminf(ax, bx) - r.ex : -inf, fx = r.px ? fmaxf(ax, bx) + r.ex : inf;
+    const float ny = r.py ? fminf(ay, by) - r.ey : -inf, fy = r.py ? fmaxf(ay, by) + r.ey : inf;
+    const float nz = r.pz ? fminf(az, bz) - r.ez : -inf, fz = r.pz ? fmaxf(az, bz) + r.ez : inf;
+    const float t0 = fmaxf(fmaxf(0.0f, nx), fmaxf(ny, nz)), t1 = fminf(fminf(tmax, fx), fminf(fy, fz));
+    const int out = ((int)!r.px & ((int)(r.x < lx - r.cx) | (int)(r.x > hx + r.cx))) |
+                    ((int)!r.py & ((int)(r.y < ly - r.cy) | (int)(r.y > hy + r.cy))) |
+                    ((int)!r.pz & ((int)(r.z < lz - r.cz) | (int)(r.z > hz + r.cz)));
+    return (out == 0) & (t0 <= t1);
 }
 // The four faces of one leaf against one ray (same arithmetic and the same rounding as nk_fb_planes).
 __device__ __forceinline__ void nk_tree_leaf(const double *tree_faces, int leaf, double tol, double x, double y, double z,
@@ -639,68 +645,98 @@ __device__ __forceinline__ int nk_tree_skip(const NkDev &d, int facet, double cx
     // every face: |x.n_g + k_g| <= dist + dn r + dk and |v.n_g| >= vn - dn |v|  =>  |t_g| < tol / 2
     return ((dist + dn * r + dk) * 1.000001 + 1e-300 < 0.5 * d.tol * (vn - dn * vv)) ? facet : NK_TREE_NO_SKIP;
 }
+// The walk as a state machine, one visit per step: k_events keeps a wave's lanes at different points of different walks.
+// A visit is either a family's four boxes (nk_walk_boxes: ends with the choice of the next node, which is a leaf when the
+// family is on level 0 -- the walk then holds it in `leaf` and waits) or that leaf's four faces (nk_walk_leaf).  The two
+// are separate so that a wave can run the boxes of the lanes that have boxes to do and the faces of the lanes that wait at
+// a leaf as two passes of their own, each with many lanes, instead of both with few.
+struct NkWalk {
+    NkRayF rf;
+    NkHit h;
+    int l, fam;
+    uint32_t todo;                      // bits 4l .. 4l + 3: siblings of the current family of level l still to visit
+    int leaf;                           // >= 0: the leaf the walk stands at (its faces are due), -1: none
+    bool enter;
+#ifdef NK_TREE_STATS
+    int n_enter, n_leaf;
+#endif
+};
+__device__ __forceinline__ void nk_walk_begin(const NkDev &d, NkWalk &w, double x, double y, double z, double vx, double vy, double vz) {
+    w.h.t = __builtin_inf(); w.h.face = 0x7fffffff; w.h.facet = -1;
+    w.rf = nk_ray_f32(x, y, z, vx, vy, vz, d.tree_bound);
+    w.l = d.tree_top; w.fam = 0; w.todo = 0u; w.enter = true; w.leaf = -1;
+#ifdef NK_TREE_STATS
+    w.n_enter = w.n_leaf = 0;
+#endif
+}
+// the boxes of the family the walk stands at (if it has just entered it), then the next node; true when the walk is over
+// (w.h holds the hit).  Not to be called while w.leaf >= 0.
+__device__ __forceinline__ bool nk_walk_boxes(const NkDev &d, int skip, NkWalk &w) {
+    const int NL = d.tree_leaves;
+    int l = w.l;
+    if (w.enter) {                      // the four boxes of family `fam` of level l, requested together
+#ifdef NK_TREE_STATS
+        ++w.n_enter;
+#endif
+        int base = d.tree_base[0];
+#pragma unroll
+        for (int k = 1; k < NK_TREE_LEVELS; ++k) base = (l == k) ? d.tree_base[k] : base;
+        const int cnt = (NL + (1 << (2 * l)) - 1) >> (2 * l);
+        const float4 *B = reinterpret_cast<const float4 *>(d.tree_boxes + (size_t)((base >> 2) + w.fam) * NK_TREE_FAMILY_FLOATS);
+        float4 b[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) b[k] = B[k];
+        int4 tg = make_int4(-1, -1, -1, -1);             // facet tags, read only by a ray that starts on a large facet
+        if (skip != NK_TREE_NO_SKIP) tg = reinterpret_cast<const int4 *>(d.tree_tags)[(base >> 2) + w.fam];
+        // the best hit so far as a float that is not below it
+        float tmax = (float)w.h.t;                       // inf stays inf
+        tmax += tmax * 1.1920929e-07f;
+        const int f4 = 4 * w.fam;
+        const uint32_t m = ((uint32_t)((f4 + 0 < cnt) & (tg.x != skip) & nk_ray_box(b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, w.rf, tmax))) |
+                           ((uint32_t)((f4 + 1 < cnt) & (tg.y != skip) & nk_ray_box(b[1].z, b[1].w, b[2].x, b[2].y, b[2].z, b[2].w, w.rf, tmax)) << 1) |
+                           ((uint32_t)((f4 + 2 < cnt) & (tg.z != skip) & nk_ray_box(b[3].x, b[3].y, b[3].z, b[3].w, b[4].x, b[4].y, w.rf, tmax)) << 2) |
+                           ((uint32_t)((f4 + 3 < cnt) & (tg.w != skip) & nk_ray_box(b[4].z, b[4].w, b[5].x, b[5].y, b[5].z, b[5].w, w.rf, tmax)) << 3);
+        w.todo = (w.todo & ~(0xFu << (4 * l))) | (m << (4 * l));
+        w.enter = false;
+    }
+    uint32_t m = (w.todo >> (4 * l)) & 0xFu;
+    while (m == 0) {                    // family done: back to the nearest ancestor's family that has a sibling left
+        if (l == d.tree_top) return true;
+        ++l;
+        w.fam >>= 2;
+        m = (w.todo >> (4 * l)) & 0xFu;
+    }
+    w.l = l;
+    const int c = __builtin_ctz(m);
+    w.todo &= ~(1u << (4 * l + c));
+    const int node = 4 * w.fam + c;
+    if (l > 0) { w.l = l - 1; w.fam = node; w.enter = true; }
+    else w.leaf = node;
+    return false;
+}
+// the faces of the leaf the walk stands at
+__device__ __forceinline__ void nk_walk_leaf(const NkDev &d, NkWalk &w, double x, double y, double z, double vx, double vy, double vz) {
+    nk_tree_leaf(d.tree_faces, w.leaf, d.tol, x, y, z, vx, vy, vz, w.h);
+    w.leaf = -1;
+#ifdef NK_TREE_STATS
+    ++w.n_leaf;
+#endif
+}
+// one visit of either kind
+__device__ __forceinline__ bool nk_walk_step(const NkDev &d, int skip, NkWalk &w, double x, double y, double z, double vx, double vy, double vz) {
+    if (w.leaf >= 0) { nk_walk_leaf(d, w, x, y, z, vx, vy, vz); return false; }
+    return nk_walk_boxes(d, skip, w);
+}
 __device__ __forceinline__ void nk_find_boundary_tree(const NkDev &d, int skip, double x, double y, double z, double vx,
                                                       double vy, double vz, double &tc, int &fc) {
-    const float *boxes = d.tree_boxes;
-    NkHit h = {__builtin_inf(), 0x7fffffff, -1};
-    const NkRayF rf = nk_ray_f32(x, y, z, vx, vy, vz, d.tree_bound);
-    const int top = d.tree_top, NL = d.tree_leaves;
-    int l = top, fam = 0;
-    uint32_t todo = 0;                  // bits 4l .. 4l + 3: siblings of the current family of level l still to visit
-    bool enter = true;
+    NkWalk w;
+    nk_walk_begin(d, w, x, y, z, vx, vy, vz);
+    while (!nk_walk_step(d, skip, w, x, y, z, vx, vy, vz)) { }
+    tc = w.h.t;
+    fc = w.h.facet;
 #ifdef NK_TREE_STATS
-    int n_enter = 0, n_leaf = 0;
-#endif
-    for (;;) {
-        if (enter) {                    // the four boxes of family `fam` of level l, requested together
-#ifdef NK_TREE_STATS
-            ++n_enter;
-#endif
-            int base = d.tree_base[0];
-#pragma unroll
-            for (int k = 1; k < NK_TREE_LEVELS; ++k) base = (l == k) ? d.tree_base[k] : base;
-            const int cnt = (NL + (1 << (2 * l)) - 1) >> (2 * l);
-            const float4 *B = reinterpret_cast<const float4 *>(boxes + (size_t)((base >> 2) + fam) * NK_TREE_FAMILY_FLOATS);
-            float4 b[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) b[k] = B[k];
-            int4 tg = make_int4(-1, -1, -1, -1);             // facet tags, read only by a ray that starts on a large facet
-            if (skip != NK_TREE_NO_SKIP) tg = reinterpret_cast<const int4 *>(d.tree_tags)[(base >> 2) + fam];
-            const int tag0 = tg.x, tag1 = tg.y, tag2 = tg.z, tag3 = tg.w;
-            // the best hit so far as a float that is not below it
-            float tmax = (float)h.t;                       // inf stays inf
-            tmax += tmax * 1.1920929e-07f;
-            uint32_t m = 0;
-            if (4 * fam + 0 < cnt && tag0 != skip && nk_ray_box(b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, rf, tmax)) m |= 1u;
-            if (4 * fam + 1 < cnt && tag1 != skip && nk_ray_box(b[1].z, b[1].w, b[2].x, b[2].y, b[2].z, b[2].w, rf, tmax)) m |= 2u;
-            if (4 * fam + 2 < cnt && tag2 != skip && nk_ray_box(b[3].x, b[3].y, b[3].z, b[3].w, b[4].x, b[4].y, rf, tmax)) m |= 4u;
-            if (4 * fam + 3 < cnt && tag3 != skip && nk_ray_box(b[4].z, b[4].w, b[5].x, b[5].y, b[5].z, b[5].w, rf, tmax)) m |= 8u;
-            todo = (todo & ~(0xFu << (4 * l))) | (m << (4 * l));
-            enter = false;
-        }
-        const uint32_t m = (todo >> (4 * l)) & 0xFu;
-        if (m == 0) {                   // family done: back to the parent's family
-            if (l == top) break;
-            ++l;
-            fam >>= 2;
-            continue;
-        }
-        const int c = __builtin_ctz(m);
-        todo &= ~(1u << (4 * l + c));
-        const int node = 4 * fam + c;
-        if (l > 0) { --l; fam = node; enter = true; }
-        else {
-            nk_tree_leaf(d.tree_faces, node, d.tol, x, y, z, vx, vy, vz, h);
-#ifdef NK_TREE_STATS
-            ++n_leaf;
-#endif
-        }
-    }
-    tc = h.t;
-    fc = h.facet;
-#ifdef NK_TREE_STATS
-    tc = (double)n_enter;       // developer probe (make stats): visits instead of the hit
-    fc = n_leaf;
+    tc = (double)w.n_enter;     // developer probe (make stats): visits instead of the hit
+    fc = w.n_leaf;
 #endif
 }
 
@@ -788,55 +824,57 @@ struct NkParticle {
 #define NK_EV_DONE 0
 #define NK_EV_DEAD 1
 #define NK_EV_MORE 2
+// The event in two halves around the ray cast (k_events runs the casts of a wave's lanes as interleaved walks):
+// nk_event_pre: absorption (returns NK_EV_DEAD) or the particle moved to the wall and sent off again (returns NK_EV_MORE:
+// a ray cast from (p.x, p.y, p.z) along (p.vx, p.vy, p.vz) is due); nk_event_post: the cast's result (tc, fcn) -> NK_EV_MORE
+// (the next wall is inside this step as well) or NK_EV_DONE (remainder drifted, particle final).
 template <bool ROUGH, bool RBF = true>
-__device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double *planes, const double *faces,
-                                            const NkFacet *facets, const NkSvTab &tb, const double *resT, NkBins &b,
-                                            NkParticle &p, double &cts, uint32_t &ev, uint64_t pid, uint32_t step) {
+__device__ __forceinline__ int nk_event_pre(const NkDev &d, const NkFacet *facets, const NkSvTab &tb, const double *resT, NkBins &b,
+                                            NkParticle &p, double &cts, uint32_t ev, uint64_t pid, uint32_t step) {
     const double dt = d.dt;
-    {
-        int fi = p.facet < 0 ? d.Fc - 1 : p.facet;          // a miss indexes the last facet
-        const NkFacet fc = facets[fi];
-        if (fc.bc == 'T' || fc.bc == 'F') {                 // I. absorbed by a reservoir, Population.py:1568-1608
-            int r = p.facet < 0 ? -1 : fc.res;
-            if (r >= 0) {
-                const double n0 = d.T_ref_local ? nk_be(p.omega * d.c_hk, p.E0, resT[2 * r + 1], d.invT0)
-                                                : nk_occupation(d, d.T_ref, p.omega, p.E0);
-                double e = d.hbar * p.omega * (p.occ - n0);
-                const double evn = e * nk_rcp(p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz);      // e / (v . n), :1602
-                atomicAdd(&b.nleave[r], 1u);
-                atomicAdd(&b.resb[4 * r + 0], -e);
-                atomicAdd(&b.resb[4 * r + 1], evn * p.vx);
-                atomicAdd(&b.resb[4 * r + 2], evn * p.vy);
-                atomicAdd(&b.resb[4 * r + 3], evn * p.vz);
-            }
-            return NK_EV_DEAD;
+    int fi = p.facet < 0 ? d.Fc - 1 : p.facet;          // a miss indexes the last facet
+    const NkFacet fc = facets[fi];
+    if (fc.bc == 'T' || fc.bc == 'F') {                 // I. absorbed by a reservoir, Population.py:1568-1608
+        int r = p.facet < 0 ? -1 : fc.res;
+        if (r >= 0) {
+            const double n0 = d.T_ref_local ? nk_be(p.omega * d.c_hk, p.E0, resT[2 * r + 1], d.invT0)
+                                            : nk_occupation(d, d.T_ref, p.omega, p.E0);
+            double e = d.hbar * p.omega * (p.occ - n0);
+            const double evn = e * nk_rcp(p.vx * fc.nx + p.vy * fc.ny + p.vz * fc.nz);      // e / (v . n), :1602
+            atomicAdd(&b.nleave[r], 1u);
+            atomicAdd(&b.resb[4 * r + 0], -e);
+            atomicAdd(&b.resb[4 * r + 1], evn * p.vx);
+            atomicAdd(&b.resb[4 * r + 2], evn * p.vy);
+            atomicAdd(&b.resb[4 * r + 3], evn * p.vz);
         }
-        double tcol = p.nts * dt;
-        double cx = p.x + p.vx * tcol, cy = p.y + p.vy * tcol, cz = p.z + p.vz * tcol;
-        // consumed fraction of the step, Population.py:1482 / :1514: |x_col - x_prev| / |v dt| with x_prev = the
-        // start-of-step position for a first event (:1472-1474), else the current position.  Both points lie on
-        // the ray x + s v, so the quotient is |nts + 1| resp. |nts| exactly; evaluated in that closed form (it
-        // differs from the reference's sqrt/sqrt/divide by rounding only, and saves two square roots and a divide).
-        cts += (cts == 0.0) ? fabs(p.nts + 1.0) : fabs(p.nts);
-        if (fc.bc == 'P') {                                                      // II. periodic, :1463-1489
-            p.x = cx + fc.tx; p.y = cy + fc.ty; p.z = cz + fc.tz;   // t = centroid(partner) - centroid(this)
-        } else if (ROUGH) {                                                      // III. rough, :1491-1544
-            double r0, r1;
-            nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);
-            p.x = cx; p.y = cy; p.z = cz;
-            int mo; double no, oo, eo;
-            nk_reflect<RBF>(d, tb, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, p.E0, r0, r1, r1, mo, no, oo, eo);
-            p.mode = mo; p.occ = no; p.omega = oo; p.E0 = eo;
-            const NkMode *rec = d.modetab + mo;
-            p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
-        }
-        double tc; int fcn;
-        if (NG > 0) nk_find_boundary_tree(d, NK_TREE_NO_SKIP, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);   // (walls are small facets)
-        else nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
-        p.nts = tc / dt;
-        p.facet = fcn;
-        if (++ev > 4096u) cts = 1.0;                         // the reference would spin
+        return NK_EV_DEAD;
     }
+    double tcol = p.nts * dt;
+    double cx = p.x + p.vx * tcol, cy = p.y + p.vy * tcol, cz = p.z + p.vz * tcol;
+    // consumed fraction of the step, Population.py:1482 / :1514: |x_col - x_prev| / |v dt| with x_prev = the
+    // start-of-step position for a first event (:1472-1474), else the current position.  Both points lie on
+    // the ray x + s v, so the quotient is |nts + 1| resp. |nts| exactly; evaluated in that closed form (it
+    // differs from the reference's sqrt/sqrt/divide by rounding only, and saves two square roots and a divide).
+    cts += (cts == 0.0) ? fabs(p.nts + 1.0) : fabs(p.nts);
+    if (fc.bc == 'P') {                                                      // II. periodic, :1463-1489
+        p.x = cx + fc.tx; p.y = cy + fc.ty; p.z = cz + fc.tz;   // t = centroid(partner) - centroid(this)
+    } else if (ROUGH) {                                                      // III. rough, :1491-1544
+        double r0, r1;
+        nk_uniform2_dev(d.seed, pid, step, NK_TAG_REFLECT + ev, r0, r1);
+        p.x = cx; p.y = cy; p.z = cz;
+        int mo; double no, oo, eo;
+        nk_reflect<RBF>(d, tb, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, p.E0, r0, r1, r1, mo, no, oo, eo);
+        p.mode = mo; p.occ = no; p.omega = oo; p.E0 = eo;
+        const NkMode *rec = d.modetab + mo;
+        p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
+    }
+    return NK_EV_MORE;
+}
+__device__ __forceinline__ int nk_event_post(const NkDev &d, NkParticle &p, double &cts, uint32_t &ev, double tc, int fcn) {
+    const double dt = d.dt;
+    p.nts = tc / dt;
+    p.facet = fcn;
+    if (++ev > 4096u) cts = 1.0;                         // the reference would spin
     if (cts < 1.0) {
         const double rem = 1.0 - cts;
         if (rem > p.nts) return NK_EV_MORE;                  // the next wall is inside this step as well
@@ -844,6 +882,16 @@ __device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double
         p.nts -= rem;
     }
     return NK_EV_DONE;
+}
+template <bool ROUGH, bool RBF = true>
+__device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double *planes, const double *faces,
+                                            const NkFacet *facets, const NkSvTab &tb, const double *resT, NkBins &b,
+                                            NkParticle &p, double &cts, uint32_t &ev, uint64_t pid, uint32_t step) {
+    if (nk_event_pre<ROUGH, RBF>(d, facets, tb, resT, b, p, cts, ev, pid, step) == NK_EV_DEAD) return NK_EV_DEAD;
+    double tc; int fcn;
+    if (NG > 0) nk_find_boundary_tree(d, NK_TREE_NO_SKIP, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);   // (walls are small facets)
+    else nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
+    return nk_event_post(d, p, cts, ev, tc, fcn);
 }
 
 // Population.calculate_energy's per-particle part (Population.py:704-717) + the heat-flux sum (:734-736).

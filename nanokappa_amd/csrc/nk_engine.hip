@@ -247,7 +247,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.stamps = nullptr;
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
     ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
-    // bookkeeping words in device memory: halt[4], overflow, ticket
+    // bookkeeping words in device memory: halt[4], overflow, ticket, ev_ticket
     const int32_t *p32 = nullptr;
     int rc;
     if ((rc = nk_upload<int32_t>(ctx, nullptr, 16, &p32))) {
@@ -258,6 +258,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.halt = (int32_t *)p32;
     ctx->d.overflow = (int32_t *)p32 + 4;
     ctx->d.ticket = (int32_t *)p32 + 5;
+    ctx->d.ev_ticket = (int32_t *)p32 + 6;
     *out = ctx;
     return NK_OK;
 }
@@ -1113,7 +1114,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         NK_PALLOC(double, qocc, pd, d.cap); NK_PALLOC(double, qnts, pd, d.cap);
         NK_PALLOC(uint32_t, qw0, pw, d.cap);
         if (d.pid) NK_PALLOC(uint64_t, qpid, pu, d.cap);
-        NK_PALLOC(int32_t, seg_evq, pi, d.nseg);
+        NK_PALLOC(int32_t, seg_evq, pi, 2 * (size_t)d.nseg + 1);
     }
 #ifdef NK_STAMPS
     { const unsigned long long *ps; int rc_ = nk_upload<unsigned long long>(ctx, nullptr, (size_t)d.nseg * 8, &ps, true); if (rc_) return rc_; d.stamps = (unsigned long long *)ps; }
@@ -1187,7 +1188,7 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
         NK_PALLOC(double, qocc, pd, d.cap); NK_PALLOC(double, qnts, pd, d.cap);
         NK_PALLOC(uint32_t, qw0, pw, d.cap);
         if (old.pid) NK_PALLOC(uint64_t, qpid, pu, d.cap);
-        NK_PALLOC(int32_t, seg_evq, pi, d.nseg);
+        NK_PALLOC(int32_t, seg_evq, pi, 2 * (size_t)d.nseg + 1);
     }
 #undef NK_PALLOC
     if (rc) {                                            // out of memory: keep the old store
@@ -1327,7 +1328,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     (void)nk_sweep_blocks(ctx);
     const int g_sweep = ctx->g_sweep < (d.nseg + 3) / 4 ? ctx->g_sweep : (d.nseg + 3) / 4;
     const int g_emit = ctx->num_cu * 8 < (d.nseg + 3) / 4 ? ctx->num_cu * 8 : (d.nseg + 3) / 4;
-    const int g_ev = split_ ? g_emit : 0;                // k_events: one wave per segment like the others
+    const int g_ev = split_ ? ctx->num_cu * NK_EVENTS_OCC : 0;   // k_events: resident waves drawing from all queues
     const int rows = g_sweep + g_ev;
     const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the batch
     if (ctx->evpool.empty()) {                           // events are created once and reused
@@ -1360,7 +1361,11 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         {
             const int rl = pending ? 1 : 0;
             NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, lrec_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux)));
-            if (split_) NK_EVENTS_DISPATCH(gm_, rough_, rbf_, pid_, (KERNEL<<<g_ev, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, g_sweep)));
+            if (split_) {
+                k_events_begin<<<1, 1024, 0, ctx->stream>>>(d);
+                NK_EVENTS_DISPATCH(gm_, rough_, rbf_, pid_, (KERNEL<<<g_ev, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, g_sweep)));
+                k_events_end<<<(d.nseg + 255) / 256, 256, 0, ctx->stream>>>(d);
+            }
         }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
         double *hrow = ctx->hist + (size_t)s * HROW;
@@ -1391,6 +1396,19 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         double tot = 0; for (int k = 0; k < 6; ++k) tot += sum[k];
         fprintf(stderr, "[stamps] cycles per tile: arrive %.0f  relax+drift %.0f  tally+store %.0f  pack/merge %.0f  event %.0f  event tally/store/repack %.0f  | total %.0f (tiles %.0f)\n",
                 sum[0] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[4] / sum[6], sum[5] / sum[6], tot / sum[6], sum[6]);
+        if (d.qx) {                                     // split sweep: k_events' per-segment clocks (words 3-5)
+            std::vector<double> cyc, wk, qq, ps;
+            for (int sgm = 0; sgm < d.nseg; ++sgm) {
+                cyc.push_back((double)st[(size_t)sgm * 8 + 3]); wk.push_back((double)st[(size_t)sgm * 8 + 4]);
+                qq.push_back((double)(st[(size_t)sgm * 8 + 5] >> 32)); ps.push_back((double)(st[(size_t)sgm * 8 + 5] & 0xffffffffull));
+            }
+            auto stat = [](std::vector<double> v, const char *nm) {
+                std::sort(v.begin(), v.end());
+                double sm = 0; for (double x : v) sm += x;
+                fprintf(stderr, "[stamps] k_events per segment %s: min %.0f  median %.0f  mean %.0f  p99 %.0f  max %.0f\n", nm, v.front(), v[v.size() / 2], sm / v.size(), v[(size_t)(v.size() * 0.99)], v.back());
+            };
+            stat(cyc, "cycles"); stat(wk, "cycles in walks"); stat(qq, "queue entries"); stat(ps, "walk passes");
+        }
     }
 #endif
     int32_t nd = 0;

@@ -820,14 +820,62 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
     nk_lds_flush(d, L, blockIdx.x);
 }
 
-// The events of a split sweep: one wave per segment works its queue off, 64 entries at a time, every lane looping over its
-// particle's events (Population.py:1546-1683; few particles have more than one), then tally and append to the segment.
-// Lean enough for four waves per SIMD: the tree walks (chains of dependent loads) are what the extra residency is for.
+// The events of a split sweep (Population.py:1546-1683), at four waves per SIMD: the tree walks are chains of dependent loads.
 #ifndef NK_EVENTS_OCC
 #define NK_EVENTS_OCC 4          // measured on the 5000-triangle wire (ms per step): 2 -> 7.7, 3 -> 7.2, 4 -> 5.9-6.2, 5 -> 6.4, 6 -> 7.1, 8 -> 11.3
 #endif
 // (Tried on the 5000-triangle wire and dropped: one workgroup of 1024 threads per CU that stages the face tree's boxes in LDS
 // -- 6.00 against 6.03 ms per step; the walk's box reads are not what the events wait for.)
+// Two imbalances shape it.  Lanes finish their walks after very different numbers of visits (5000-triangle wire: 13-27 per
+// ray, 31-59 for the slowest of 64), so a wave does not work in batches of 64: every lane is a small state machine (NEED an
+// entry -> PRE: the event up to the ray cast -> WALK: one visit per pass -> POST: the cast's result, then either another
+// event or tally + append), and the lanes that are through take new entries while the others keep walking; the pre / post
+// / refill blocks only run when the walking lanes have dropped to NK_EVENTS_LOW (or no entries are left), so they run
+// with many lanes and the walk loop stays full.  And segments own different modes, hence see different event rates
+// (5e7 particles in 4096 segments: 353 to 1181 queue entries, mean 668), so waves do not own segments here: the queues are
+// one concatenated list (prefix sums by k_events_begin) that all waves draw from through a ticket counter; a finished
+// particle takes its slot in its segment with an atomic on the segment's count.  k_events_end closes the step per segment.
+#ifndef NK_EVENTS_LOW
+#define NK_EVENTS_LOW 8
+#endif
+#ifndef NK_EVENTS_LEAVES
+#define NK_EVENTS_LEAVES 32      // lanes waiting at a leaf that make a faces pass worth its instructions
+#endif
+#define NK_PH_NEED 0
+#define NK_PH_PRE 1
+#define NK_PH_WALK 2
+#define NK_PH_POST 3
+__global__ __launch_bounds__(1024) void k_events_begin(NkDev d) {
+    __shared__ int part[1024];
+    if (d.halt[0]) return;
+    const int t = threadIdx.x, per = (d.nseg + 1023) / 1024;
+    const int lo = t * per, hi = lo + per < d.nseg ? lo + per : d.nseg;
+    int s = 0;
+    for (int i = lo; i < hi; ++i) s += d.seg_evq[i];
+    part[t] = s;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {              // inclusive scan of the 1024 partial sums
+        const int v = t >= o ? part[t - o] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    int run = t > 0 ? part[t - 1] : 0;
+    int32_t *pf = d.seg_evq + d.nseg;
+    for (int i = lo; i < hi; ++i) { pf[i] = run; run += d.seg_evq[i]; }
+    if (t == 1023) pf[d.nseg] = part[1023];
+    if (t == 0) *d.ev_ticket = 0;
+}
+__global__ __launch_bounds__(256) void k_events_end(NkDev d) {
+    if (d.halt[0]) return;
+    const int seg = blockIdx.x * blockDim.x + threadIdx.x;
+    if (seg >= d.nseg) return;
+    int w = d.seg_count[seg];
+    if (w > d.segcap) { w = d.segcap; d.seg_count[seg] = w; }          // (the surplus was dropped and flagged by k_events)
+    d.seg_evq[seg] = 0;
+    // could the next step overflow this segment?  then nothing after this step runs until the host has grown the store
+    if (d.R > 0 && (int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+}
 template <int GEOM, bool ROUGH, bool RBF, bool PID>
 __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32_t step, int flags, int row0) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -835,45 +883,102 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
     NkLds L;
     nk_lds_setup<GEOM, 0>(d, smem, L);
     const bool do_flux = (flags & 1) != 0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int rep = lane & (NK_NREP - 1);
     const unsigned long long lower = (1ull << lane) - 1ull;
     const uint32_t lbmask = (1u << d.lb) - 1u;
-    const int wpb = blockDim.x >> 6, nwaves = gridDim.x * wpb;
-    for (int seg = blockIdx.x * wpb + wave; seg < d.nseg; seg += nwaves) {
-        const int q = d.seg_evq[seg];
-        const int64_t base = (int64_t)seg * d.segcap;
-        const NkSegModes sm = nk_seg_modes(d, seg);
-        int w = d.seg_count[seg];
-        for (int j0 = 0; j0 < q; j0 += NK_TILE) {
-            const int j = j0 + lane;
-            const bool act = j < q;
-            NkParticle p;
-            uint32_t w0 = 0u, evc = 0u;
-            unsigned long long pid = 0;
-            double cts = 0.0;
-            int st = NK_EV_DEAD;
-            p.x = p.y = p.z = p.occ = p.nts = 0.0;
-            if (act) {
-                const int64_t i = base + j;
-                p.x = d.qx[i]; p.y = d.qy[i]; p.z = d.qz[i]; p.occ = d.qocc[i]; p.nts = d.qnts[i]; w0 = d.qw0[i];
-                if (PID) pid = d.qpid[i];
+    const bool tree = GEOM == 2 && d.NG > 0;
+    const int32_t *pf = d.seg_evq + d.nseg;           // exclusive prefix sums of the queue lengths
+    const int total = pf[d.nseg];
+    bool more = total > 0;                            // entries may be left to hand out
+    int phase = NK_PH_NEED;
+    NkParticle p;
+    NkWalk W;
+    uint32_t evc = 0u;
+    unsigned long long pid = 0;
+    double cts = 0.0;
+    int idx0 = 0, seg = 0;
+    p.x = p.y = p.z = p.occ = p.nts = p.omega = p.E0 = p.vx = p.vy = p.vz = 0.0; p.mode = 0; p.facet = -1;
+    nk_walk_begin(d, W, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0);
+#ifdef NK_STAMPS
+    unsigned long long st_t0, st_walk = 0, st_pass = 0, st_got = 0;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");
+#endif
+    for (;;) {
+        // ---- lanes without a particle take the next entries of the concatenated queues
+        if (more) {
+            const unsigned long long mN = __ballot(phase == NK_PH_NEED);
+            if (mN != 0ull) {
+                const int n = __popcll(mN);
+                int g0 = 0;
+                if (lane == 0) g0 = atomicAdd(d.ev_ticket, n);
+                g0 = __builtin_amdgcn_readfirstlane(g0);
+                if (g0 + n >= total) more = false;
+                const int g = g0 + __popcll(mN & lower);
+                if (phase == NK_PH_NEED && g < total) {
+                    int lo = 0, hi = d.nseg;              // the segment whose queue holds entry g: the last one with pf[s] <= g
+                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pf[mid] <= g) lo = mid; else hi = mid; }
+                    seg = lo;
+                    const int64_t i = (int64_t)seg * d.segcap + (g - pf[seg]);
+                    p.x = d.qx[i]; p.y = d.qy[i]; p.z = d.qz[i]; p.occ = d.qocc[i]; p.nts = d.qnts[i];
+                    const uint32_t w0 = d.qw0[i];
+                    if (PID) pid = d.qpid[i];
+                    idx0 = (int)(w0 & lbmask);
+                    p.mode = d.part ? idx0 * d.nseg + seg : idx0;
+                    const NkMode *rec = d.modetab + p.mode;
+                    const double4 ra = *reinterpret_cast<const double4 *>(rec);
+                    p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                    p.E0 = rec->E0;
+                    p.facet = (int)(w0 >> d.lb) - 1;
+                    cts = 0.0; evc = 0u;
+                    phase = NK_PH_PRE;
+#ifdef NK_STAMPS
+                    st_got += 1;
+#endif
+                }
             }
-            const int idx0 = (int)(w0 & lbmask);
-            p.mode = idx0 * sm.mstride + sm.moff;
-            {
-                const NkMode *rec = d.modetab + p.mode;
-                const double4 ra = *reinterpret_cast<const double4 *>(rec);
-                p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
-                p.E0 = rec->E0;
+        }
+        // ---- the event up to its ray cast
+        if (phase == NK_PH_PRE) {
+            const int st = nk_event_pre<ROUGH, RBF>(d, L.facets, L.tb, L.resT, L.bins, p, cts, evc, pid, step);
+            if (st == NK_EV_DEAD) phase = NK_PH_NEED;
+            else if (tree) { nk_walk_begin(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz); phase = NK_PH_WALK; }
+            else {
+                nk_find_boundary(L.planes, L.faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, W.h.t, W.h.facet);
+                phase = NK_PH_POST;
             }
-            p.facet = (int)(w0 >> d.lb) - 1;
-            if (act) {
-                do st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, pid, step);
-                while (st == NK_EV_MORE);
+        }
+        // ---- the walks, until few enough lanes are left in one (all of them, once no entries are left)
+        {
+            const int low = more ? NK_EVENTS_LOW : 0;
+#ifdef NK_STAMPS
+            unsigned long long st_a, st_b;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_a)::"memory");
+#endif
+            for (;;) {
+                const unsigned long long mW = __ballot(phase == NK_PH_WALK), mL = __ballot(phase == NK_PH_WALK && W.leaf >= 0);
+                const int nw = __popcll(mW), nl = __popcll(mL);
+                if (nw <= low) break;
+                // the faces once enough lanes wait at a leaf (or none has boxes to do), else the boxes
+                if (nl >= NK_EVENTS_LEAVES || nl == nw) { if (phase == NK_PH_WALK && W.leaf >= 0) nk_walk_leaf(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz); }
+                else if (phase == NK_PH_WALK && W.leaf < 0 && nk_walk_boxes(d, NK_TREE_NO_SKIP, W)) phase = NK_PH_POST;
+#ifdef NK_STAMPS
+                st_pass += 1;
+#endif
             }
-            const bool alive = act && st == NK_EV_DONE;
-            if (alive) nk_tally_one(d, L.tb, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.E0, p.vx, p.vy, p.vz, do_flux, rep);
+#ifdef NK_STAMPS
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_b)::"memory");
+            st_walk += st_b - st_a;
+#endif
+        }
+        // ---- the cast's result: another event, or the particle is final
+        bool fin = false;
+        if (phase == NK_PH_POST) {
+            const int st = nk_event_post(d, p, cts, evc, W.h.t, W.h.facet);
+            if (st == NK_EV_MORE) phase = NK_PH_PRE; else { fin = true; phase = NK_PH_NEED; }
+        }
+        if (fin) {
+            nk_tally_one(d, L.tb, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.E0, p.vx, p.vy, p.vz, do_flux, rep);
             bool stay = true;
             uint32_t idxe = (uint32_t)idx0;
             if (ROUGH) {
@@ -881,18 +986,14 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                 else idxe = (uint32_t)p.mode;
             }
             const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
-            const bool home = alive && stay, away = alive && !stay;
-            const unsigned long long mA = __ballot(home);
-            if (home) {
-                const int o = w + __popcll(mA & lower);
+            if (stay) {                                   // its slot in its segment
+                const int o = atomicAdd(d.seg_count + seg, 1);
                 if (o < d.segcap) {
-                    const int64_t i = base + o;
+                    const int64_t i = (int64_t)seg * d.segcap + o;
                     d.x[i] = p.x; d.y[i] = p.y; d.z[i] = p.z; d.occ[i] = p.occ; d.nts[i] = p.nts; d.w0[i] = w0e;
                     if (PID) d.pid[i] = pid;
                 } else atomicOr(d.overflow, 4);
-            }
-            w += __popcll(mA);
-            if (ROUGH && away) {
+            } else {                                      // (ROUGH) one 64-byte record into the inbox of the segment that owns the new mode
                 const int dst = (int)((uint32_t)p.mode - idxe * (uint32_t)d.nseg);
                 const int at = atomicAdd(d.mig_n + dst, 1);
                 if (at < d.mig_cap) {
@@ -903,12 +1004,19 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                 } else atomicOr(d.overflow, 32);
             }
         }
-        if (lane == 0) {
-            d.seg_count[seg] = w < d.segcap ? w : d.segcap;
-            d.seg_evq[seg] = 0;
-            if (d.R > 0 && (int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+        if (!more && __ballot(phase != NK_PH_NEED) == 0ull) break;
+    }
+#ifdef NK_STAMPS
+    if (lane == 0 && d.stamps) {                      // developer build: this wave's clocks (words 3-5 of a row of its own)
+        unsigned long long t1;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+        const int wv = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
+        if (wv < d.nseg) {
+            unsigned long long *o = d.stamps + (int64_t)wv * 8;
+            o[3] = t1 - st_t0; o[4] = st_walk; o[5] = (st_got << 32) | st_pass;
         }
     }
+#endif
     nk_lds_flush(d, L, row0 + blockIdx.x);
 }
 
