@@ -182,6 +182,18 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
                         const uint64_t *pid, uint64_t pid_offset);
 /* Population.timesteps_to_boundary for the whole population (Population.py:310-314) */
 int nk_init_boundaries(nk_ctx *ctx);
+/* Population.initialise_all_particles on the device (Population.py:186-321), instead of nk_reserve + nk_upload_particles, for
+ * the common case: modes tiled over the particle ids (initialise_modes, :127-144: particle p has mode unique_modes[p %
+ * n_unique], flat indices q * J + j of the active modes), ids pid_lo .. pid_lo + N - 1, positions uniform in the solid
+ * (Mesh.sample_volume, Mesh.py:890-904; sv_first NULL = 'random_domain') or uniform in the subvolume the particle's index
+ * belongs to (sv_first[S + 1] ascending from 0: index i in [sv_first[s], sv_first[s + 1]) lies in subvolume s =
+ * 'random_subvol', :222-246), occupations Bose-Einstein at the subvolume's temperature (:280).  Needs nk_set_material,
+ * nk_set_mesh (with the volume tables), nk_set_subvolumes and the boundary-condition tables; nk_init_boundaries follows. */
+int nk_init_particles(nk_ctx *ctx, int64_t N, int64_t capacity, uint64_t pid_lo, const int32_t *unique_modes, int64_t n_unique,
+                      const int64_t *sv_first);
+/* calculate_energy and the heat-flux sums of the particles where they stand, before normalisation (Population.py:704-717,
+ * :734-736; the reference's t = 0 row): E_raw[S], N_sv[S], flux_raw[S * 3].  This rank's particles only. */
+int nk_tally_state(nk_ctx *ctx, double *E_raw, double *N_sv, double *flux_raw);
 /* Population.run_timestep x nsteps (Population.py:1724-1769) without the file output.  The particle store grows by
  * itself (on the device, nothing is dropped) when the ensemble outgrows it, like the reference's arrays do; NK_ERR_CAPACITY
  * only if that growth fails (out of memory), with the state of the last completed step intact. */

@@ -36,6 +36,7 @@
 #define NK_TAG_EMIT 0x10000u
 #define NK_TAG_RESAMP 0x20000u
 #define NK_TAG_DICE 0x30000u
+#define NK_TAG_INIT 0x40000u      // k_init_particles: 3 tags per draw of a position
 
 struct __attribute__((aligned(16))) NkFacet {   // 96 bytes
     double cx, cy, cz;    // centroid

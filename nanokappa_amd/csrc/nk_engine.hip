@@ -1055,7 +1055,13 @@ static int64_t nk_spawn_bound(const nk_ctx *ctx, int nseg) {
 
 // (Re)allocate the particle store for `capacity` particles, `max_seg` of them at most in one segment when the modes are
 // partitioned (0 = unknown: even spread assumed).
-static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode = nullptr, int64_t N = 0) {
+// particles of the tiled rule (particle p has mode umodes[p % nu]) per unique mode, for p in [pid_lo, pid_lo + N)
+static inline int64_t nk_tiled_count(int64_t u, int64_t nu, int64_t pid_lo, int64_t N) {
+    const int64_t first = pid_lo % nu;
+    return N / nu + (((u - first + nu) % nu) < N % nu ? 1 : 0);
+}
+static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode = nullptr, int64_t N = 0,
+                              const int32_t *umodes = nullptr, int64_t nu = 0, int64_t pid_lo = 0) {
     NkDev &d = ctx->d;
     { int rc0 = nk_entry_tables_drop(ctx, true); if (rc0) return rc0; }
     for (void *p : ctx->pallocs) hipFree(p);
@@ -1082,9 +1088,10 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         d.lb = lb;
     }
     int64_t segcap = (capacity + nseg - 1) / nseg;
-    if (d.part && mode && N > 0) {                       // room for the fullest segment of this population + a step's arrivals
+    if (d.part && (mode || umodes) && N > 0) {           // room for the fullest segment of this population + a step's arrivals
         std::vector<int64_t> per((size_t)nseg, 0);
-        for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0) per[(size_t)(mode[i] % nseg)] += 1;
+        if (mode) { for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0) per[(size_t)(mode[i] % nseg)] += 1; }
+        else for (int64_t u = 0; u < nu; ++u) per[(size_t)(umodes[u] % nseg)] += nk_tiled_count(u, nu, pid_lo, N);
         int64_t mx = 0;
         for (int64_t v : per) mx = std::max(mx, v);
         segcap = std::max(segcap, mx + mx / 4 + 64);
@@ -1643,6 +1650,62 @@ struct NkDevBuf {
 };
 #define NK_BUF(T, name, src, count) NkDevBuf<T> name(src, count); NK_HIP(name.err)
 extern "C" {
+
+// Population.initialise_all_particles on the device (k_init_particles): N particles with ids pid_lo .. pid_lo + N - 1, modes
+// tiled over the ids, positions uniform in the solid ('random_domain': sv_first NULL) or in the subvolume the index
+// belongs to ('random_subvol': sv_first[S + 1], ascending, sv_first[0] = 0).  Replaces nk_reserve + nk_upload_particles.
+int nk_init_particles(nk_ctx *ctx, int64_t N, int64_t capacity, uint64_t pid_lo, const int32_t *unique_modes, int64_t n_unique,
+                      const int64_t *sv_first) {
+    NK_ARG(ctx && N >= 0 && unique_modes && n_unique > 0, "nk_init_particles: bad arguments");
+    NK_ARG(ctx->have_material && ctx->have_mesh && ctx->have_sv, "nk_init_particles: set the material, the mesh and the subvolumes first");
+    NkDev &d = ctx->d;
+    NK_ARG(d.nS > 0, "nk_init_particles: the mesh was set without its volume tables (simplices)");
+    NK_ARG(nk_want_part(ctx), "nk_init_particles: needs the mode-partitioned store");
+    for (int64_t u = 0; u < n_unique; ++u) NK_ARG(unique_modes[u] >= 0 && unique_modes[u] < d.M, "nk_init_particles: mode index out of range");
+    NK_HIP(hipSetDevice(ctx->device));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = nk_alloc_particles(ctx, std::max<int64_t>(capacity, N + N / 2 + 65536), nullptr, N, unique_modes, n_unique, (int64_t)(pid_lo % (uint64_t)n_unique));
+    if (rc) return rc;
+    NK_BUF(int32_t, um, unique_modes, n_unique);
+    NK_BUF(int64_t, sf, sv_first, sv_first ? d.S + 1 : 0);
+    NK_HIP(hipMemsetAsync(d.seg_count, 0, (size_t)d.nseg * sizeof(int32_t), ctx->stream));
+    int32_t zero6[6] = {0, 0, 0, 0, 0, 0};
+    NK_HIP(hipMemcpyAsync(d.halt, zero6, 24, hipMemcpyHostToDevice, ctx->stream));     // halt[4], overflow, ticket
+    if (N > 0) k_init_particles<<<ctx->num_cu * 8, NK_WG, nk_lds(ctx, false), ctx->stream>>>(d, N, pid_lo, um.p, (int32_t)n_unique, sv_first ? sf.p : nullptr);
+    NK_HIP(hipGetLastError());
+    int32_t ovf = 0;
+    NK_HIP(hipMemcpyAsync(&ovf, d.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    NK_ARG(ovf == 0, "nk_init_particles: a segment overflowed (internal sizing error)");
+    ctx->pending_relax = false;
+    return NK_OK;
+}
+
+// The tallies of the particles where they stand (the t = 0 row of the reference: calculate_energy and the flux sums before
+// normalisation, Population.py:704-717, :734-736): E_raw[S], N[S], flux_raw[3 S] (subvolume-major).  This rank's particles only.
+int nk_tally_state(nk_ctx *ctx, double *E_raw, double *N_sv, double *flux_raw) {
+    NK_ARG(ctx && E_raw && N_sv && flux_raw, "nk_tally_state: bad arguments");
+    int rc = nk_check_ready(ctx);
+    if (rc) return rc;
+    NK_HIP(hipSetDevice(ctx->device));
+    NkDev &d = ctx->d;
+    if (ctx->pending_relax) {                          // the state the caller means includes the deferred relaxation
+        k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(d, 0);
+        ctx->pending_relax = false;
+    }
+    const int g = nk_sweep_grid(ctx);
+    NK_BUF(double, acc, nullptr, d.NB + 1);
+    k_tally_state<<<g, NK_WG, nk_lds(ctx, false), ctx->stream>>>(d);
+    k_reduce<<<d.NB, NK_WG, 0, ctx->stream>>>(d, g, acc.p, nullptr, 1, 0);
+    NK_HIP(hipGetLastError());
+    std::vector<double> h((size_t)d.NB + 1);
+    NK_HIP(hipMemcpyAsync(h.data(), acc.p, h.size() * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    const int S = d.S;
+    for (int s_ = 0; s_ < S; ++s_) { E_raw[s_] = h[(size_t)s_]; N_sv[s_] = h[(size_t)S + s_]; }
+    for (int k = 0; k < 3 * S; ++k) flux_raw[k] = h[(size_t)2 * S + k];
+    return NK_OK;
+}
 
 int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x, const double *v, double *xc, double *tc, int32_t *fc) {
     NK_ARG(ctx && ctx->have_mesh && ctx->have_sv && n > 0 && x && v, "nk_find_boundary: bad arguments");

@@ -1229,6 +1229,71 @@ __device__ __forceinline__ uint64_t nk_state_key(int mode, double x, double y, d
     return k;
 }
 
+// Population.initialise_all_particles on the device (Population.py:186-321) for the common case: modes tiled over the
+// particle index (:127-144, at least one particle per mode and subvolume), positions 'random_domain' (one draw of
+// Mesh.sample_volume, Mesh.py:890-904) or 'random_subvol' (the particle index fixes the subvolume -- sv_first[s] is the first
+// index of subvolume s's share, :222-246 -- and draws are repeated until one falls into it), occupation = Bose-Einstein
+// at the temperature of the subvolume the particle is in (:280).  A particle takes the next free slot of the segment that
+// owns its mode (cursor = seg_count, zeroed before the launch).
+__global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, uint64_t pid_lo, const int32_t *umodes, int32_t nu,
+                                                          const int64_t *sv_first) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    NkLds L;
+    nk_lds_setup<0, 0>(d, smem, L);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint64_t pid = pid_lo + (uint64_t)i;
+        const int mode = umodes[pid % (uint64_t)nu];
+        const int seg = mode % d.nseg, idx = mode / d.nseg;
+        int want = -1;                                // random_subvol: the subvolume this index belongs to
+        if (sv_first) { int lo = 0, hi = d.S; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sv_first[mid] <= i) lo = mid; else hi = mid; } want = lo; }
+        double x = 0.0, y = 0.0, z = 0.0;
+        int s = 0;
+        for (uint32_t t = 0; t < 4096u; ++t) {         // (a subvolume holds at least 1 / 4096 of the volume, or keeps the last draw)
+            double u[6];
+            nk_uniform2_dev(d.seed, pid, 0u, NK_TAG_INIT + 3u * t + 0u, u[0], u[1]);
+            nk_uniform2_dev(d.seed, pid, 0u, NK_TAG_INIT + 3u * t + 1u, u[2], u[3]);
+            nk_uniform2_dev(d.seed, pid, 0u, NK_TAG_INIT + 3u * t + 2u, u[4], u[5]);
+            int sx = nk_ss_right(d.simplex_cdf, d.nS, u[0]);
+            sx = sx > d.nS - 1 ? d.nS - 1 : sx;
+            double a[4], asum = 0.0;
+            for (int q = 0; q < 4; ++q) { a[q] = -log(u[1 + q]); asum += a[q]; }
+            const double *sp = d.simplex_pts + 12 * (int64_t)sx;
+            x = y = z = 0.0;
+            for (int q = 0; q < 4; ++q) { const double wq = a[q] / asum; x += wq * sp[3 * q]; y += wq * sp[3 * q + 1]; z += wq * sp[3 * q + 2]; }
+            s = nk_classify(d, L.tb, x, y, z);
+            if (want < 0 || s == want) break;
+        }
+        const NkMode *rec = d.modetab + mode;
+        const double occ = nk_occupation(d, L.tb.Tsv[s], rec->omega, rec->E0);
+        const int slot = atomicAdd(d.seg_count + seg, 1);
+        if (slot < d.segcap) {
+            const int64_t o = (int64_t)seg * d.segcap + slot;
+            d.x[o] = x; d.y[o] = y; d.z[o] = z; d.occ[o] = occ; d.nts[o] = 0.0; d.w0[o] = (uint32_t)idx;
+            if (d.pid) d.pid[o] = pid;
+        } else atomicOr(d.overflow, 2);
+    }
+}
+// calculate_energy + the heat-flux sums of the particles where they stand (Population.py:704-717, :734-736): the t = 0 row.
+__global__ __launch_bounds__(NK_WG) void k_tally_state(NkDev d) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    NkLds L;
+    nk_lds_setup<0, 0>(d, smem, L);
+    const uint32_t lbmask = (1u << d.lb) - 1u;
+    const int rep = threadIdx.x & (NK_NREP - 1);
+    for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg];
+        const NkSegModes sm = nk_seg_modes(d, seg);
+        for (int k = threadIdx.x; k < count; k += NK_WG) {
+            const int64_t i = base + k;
+            const NkMode *rec = sm.rec + (d.w0[i] & lbmask);
+            nk_tally_one(d, L.tb, L.bins, d.x[i], d.y[i], d.z[i], d.occ[i], rec->omega, rec->E0, rec->vx, rec->vy, rec->vz, true, rep);
+        }
+    }
+    nk_lds_flush(d, L, blockIdx.x);
+}
+
 // contains_check (Population.py:1712-1722) + Mesh.sample_volume (Mesh.py:890-904)
 template <int GEOM>
 __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {

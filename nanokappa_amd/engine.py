@@ -78,7 +78,7 @@ EXPORTS = ['nk_device_count', 'nk_create', 'nk_destroy', 'nk_last_error', 'nk_se
            'nk_set_subvol_temperature', 'nk_get_step', 'nk_get_timing', 'nk_comm_unique_id', 'nk_comm_init',
            'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2', 'nk_calibrate_stream',
            'nk_specular_begin', 'nk_specular_pairs', 'nk_specular_end', 'nk_rough_begin', 'nk_rough_pairs', 'nk_rough_finish',
-           'nk_rough_download', 'nk_build_enter_prob']
+           'nk_rough_download', 'nk_build_enter_prob', 'nk_init_particles', 'nk_tally_state']
 
 _lib = None
 
@@ -104,6 +104,8 @@ def load_library():
     L.nk_reserve.argtypes = [C.c_void_p, C.c_int64]
     L.nk_upload_particles.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_ip, c_u64p, C.c_uint64]
     L.nk_init_boundaries.argtypes = [C.c_void_p]
+    L.nk_init_particles.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, c_ip, C.c_int64, C.POINTER(C.c_int64)]
+    L.nk_tally_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
     L.nk_step.argtypes = [C.c_void_p, C.c_int32, C.POINTER(nk_tally)]
     L.nk_download_particles.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_ip, c_u64p,
                                         C.POINTER(C.c_int64)]
@@ -318,6 +320,20 @@ class Engine(object):
 
     def init_boundaries(self):
         self._ck(self.L.nk_init_boundaries(self.h), 'nk_init_boundaries')
+
+    def init_particles(self, n, capacity, pid_lo, unique_modes, sv_first=None):
+        """initialise_all_particles on the device (tiled modes; sv_first: first particle index of every subvolume's share)."""
+        um = _i(unique_modes)
+        sf = None if sv_first is None else np.ascontiguousarray(sv_first, dtype=np.int64)
+        self._ck(self.L.nk_init_particles(self.h, int(n), int(capacity), int(pid_lo), um.ctypes.data_as(c_ip), um.shape[0],
+                                          None if sf is None else sf.ctypes.data_as(C.POINTER(C.c_int64))), 'nk_init_particles')
+
+    def tally_state(self):
+        """E_raw[S], N_sv[S], flux_raw[S, 3] of the particles where they stand (this rank's)."""
+        S = self.S
+        E, N, F = np.zeros(S), np.zeros(S), np.zeros((S, 3))
+        self._ck(self.L.nk_tally_state(self.h, E.ctypes.data_as(c_dp), N.ctypes.data_as(c_dp), F.ctypes.data_as(c_dp)), 'nk_tally_state')
+        return E, N, F
 
     def step(self, nsteps=1):
         """Run nsteps timesteps; returns a dict of per-step arrays (see nk_tally in the header)."""

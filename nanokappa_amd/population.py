@@ -149,20 +149,33 @@ class Population(Constants):
         self.pid_lo, hi = self._shard(self.N_total)
         self.N_local = hi - self.pid_lo
         self.prng = np.random.default_rng([self.seed, 7919, self.rank])
-        pos, modes, occ = self.initialise_all_particles(geometry, phonon)
+        on_device = self._init_on_device(geometry, phonon)
+        if on_device:                      # the common case is generated by the engine (nk_init_particles): nothing to upload
+            self.subvol_temperature = self._assign_subvol_temperatures(geometry)
+        else:
+            pos, modes, occ = self.initialise_all_particles(geometry, phonon)
 
         self._configure_engine(geometry, phonon)
         if comm is not None:               # nk_comm_init decides what one rank needs (rank / nranks; NK_FORCE_COMM)
             self.engine.comm_init(comm[0], self.rank, self.nranks)
         J = phonon.number_of_branches
-        self.engine.reserve(int(1.5 * pos.shape[0]) + 65536)
-        self.engine.upload(pos, (modes[:, 0] * J + modes[:, 1]).astype(np.int32), occ, pid_offset=self.pid_lo)
+        if on_device:
+            um = np.vstack(np.where(~phonon.inactive_modes_mask)).T
+            self.unique_modes = um
+            self.engine.init_particles(self.N_local, int(1.5 * self.N_local) + 65536, self.pid_lo,
+                                       (um[:, 0] * J + um[:, 1]).astype(np.int32), self._subvol_shares(geometry))
+        else:
+            self.engine.reserve(int(1.5 * pos.shape[0]) + 65536)
+            self.engine.upload(pos, (modes[:, 0] * J + modes[:, 1]).astype(np.int32), occ, pid_offset=self.pid_lo)
         print('Getting first boundary collisions...')
         self.engine.init_boundaries()
 
         print('Initialising local quantities...')
-        self._initial_tallies(geometry, phonon, pos, modes, occ)
-        del pos, modes, occ
+        if on_device:
+            self._finish_initial_tallies(geometry, phonon, *self.engine.tally_state())
+        else:
+            self._initial_tallies(geometry, phonon, pos, modes, occ)
+            del pos, modes, occ
 
         self.conv_crit = float(args.conv_crit[0])
         self.conv_count_min = int(args.conv_crit[1])
@@ -261,6 +274,26 @@ class Population(Constants):
         self.N_leaving = np.sum(self.enter_prob, axis=(1, 2)).round().astype(int)
         self.res_energy_balance = np.zeros(self.n_of_reservoirs)
         self.res_heat_flux = np.zeros((self.n_of_reservoirs, 3))
+
+    def _init_on_device(self, geometry, phonon):
+        """Can the engine create the particles itself (nk_init_particles)?  Tiled modes (Population.py:127-144 with at least
+        one particle per mode and subvolume) and uniform positions in the solid or per subvolume; NK_HOST_INIT=1 keeps the
+        host path (initialise_all_particles + upload), which every other case takes."""
+        if os.environ.get('NK_HOST_INIT') or os.environ.get('NK_NO_PARTITION') or not hasattr(self.engine, 'init_particles'):
+            return False
+        if self.args.part_dist[0] not in ('random_domain', 'random_subvol') or self.particles_pmps < 1:
+            return False
+        return getattr(geometry.mesh, 'n_of_simplices', 0) > 0 and hasattr(geometry.mesh, 'simplices_points')
+
+    def _subvol_shares(self, geometry):
+        """'random_subvol' (Population.py:222-246): the first particle index of every subvolume's share, ceil(N vol_i / vol)
+        particles each, cut off at N; None for 'random_domain'."""
+        if self.args.part_dist[0] != 'random_subvol':
+            return None
+        vol = np.asarray(geometry.subvol_volume, dtype=float)
+        n = np.ceil(self.N_local * vol / (vol.sum() - vol[self.empty_subvols].sum())).astype(np.int64)
+        n[self.empty_subvols] = 0
+        return np.minimum(np.concatenate(([0], np.cumsum(n))), self.N_local).astype(np.int64)
 
     def initialise_modes(self, phonon):
         """Population.py:127-144: tiled unique modes when there is at least one particle per mode and subvolume."""
@@ -474,6 +507,17 @@ class Population(Constants):
         self.subvol_heat_flux = self._normalise_flux(phonon, flux_raw, self.subvol_N_p)
         self.calculate_kappa(geometry)
         del self.subvol_id
+
+    def _finish_initial_tallies(self, geometry, phonon, E_raw, N_sv, flux_raw):
+        """The same from the engine's tally of the particles it created (nk_tally_state: this rank's sums)."""
+        w = self.nranks
+        self.subvol_N_p = np.rint(N_sv).astype(np.int64) * w
+        self.N_p = int(self.subvol_N_p.sum())
+        ref = phonon.crystal_energy_function(self.subvol_temperature) if self.T_reference == 'local' else self.ref_en_density
+        self.total_energy = float(E_raw.sum()) * w
+        self.subvol_energy = self._normalise_energy(phonon, E_raw * w, self.subvol_N_p) + ref
+        self.subvol_heat_flux = self._normalise_flux(phonon, flux_raw * w, self.subvol_N_p)
+        self.calculate_kappa(geometry)
 
     # ----------------------------------------------------------------------------- normalisation
     def _norm(self, phonon, N_sv):

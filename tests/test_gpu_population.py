@@ -112,6 +112,63 @@ def test_large_ensemble_agrees_with_reference_mean():
     assert abs(Npm[0] / 30.0 / Npr.mean() - 1) < 0.005
 
 
+@pytest.mark.parametrize('case,dist', [('ttrrp', 'random_subvol'), ('ttp', 'random_domain')])
+def test_particles_created_on_the_device(case, dist, monkeypatch):
+    """nk_init_particles against the host's initialise_all_particles (Population.py:186-321): the modes are the tiled rule's
+    multiset, every subvolume holds its share ('random_subvol': exactly ceil(N vol / V), Population.py:222-246), every particle
+    lies in the solid with the Bose-Einstein occupation of its subvolume's temperature (:280), and the t = 0 tallies
+    (nk_tally_state) equal the host's sums over the downloaded particles."""
+    n = 200000                 # more than one particle per mode and subvolume: the tiled rule
+    pop, geo, ph = build_population(case, n, 11, None, extra=['--part_dist', dist, '--temp_dist', 'linear'])
+    assert pop._init_on_device(geo, ph)
+    p = pop.engine.download()
+    x, m, occ = p['positions'], p['mode'], p['occupation']
+    assert x.shape[0] == n
+    J = ph.number_of_branches
+    um = np.vstack(np.where(~ph.inactive_modes_mask)).T
+    flat = um[:, 0] * J + um[:, 1]
+    want = flat[np.arange(n) % flat.shape[0]]                                                 # :127-144
+    if case == 'ttrrp':        # rough facets: ids are kept, so particle by particle
+        assert np.array_equal(np.sort(p['pid']), np.arange(n)) and np.array_equal(m[np.argsort(p['pid'])], want)
+    else:
+        assert np.array_equal(np.bincount(m, minlength=ph.omega.size), np.bincount(want, minlength=ph.omega.size))
+    assert np.all(geo.mesh.contains(x))
+    sv = geo.subvol_classifier.predict(x)
+    counts = np.bincount(sv, minlength=geo.n_of_subvols)
+    if dist == 'random_subvol':
+        vol = np.asarray(geo.subvol_volume, dtype=float)
+        first = np.minimum(np.concatenate(([0], np.cumsum(np.ceil(n * vol / vol.sum()).astype(int)))), n)
+        assert np.array_equal(counts, np.diff(first))
+    else:
+        assert np.all(np.abs(counts - n / geo.n_of_subvols) < 6 * np.sqrt(n / geo.n_of_subvols))
+    T = np.asarray(pop.engine.subvol_temperature())
+    assert T.max() - T.min() > 1.0                                                           # 'linear': the subvolumes differ
+    om = ph.omega[m // J, m % J]
+    np.testing.assert_allclose(occ, ph.calculate_occupation(T[sv], om), rtol=1e-11)
+    # the t = 0 row: host sums over the same particles (at the creation temperatures every deviation is zero by construction,
+    # so the comparison is made against reference temperatures 3 K lower)
+    E0, N0, F0 = pop.engine.tally_state()
+    assert np.array_equal(N0, counts.astype(float)) and np.abs(E0).max() <= 1e-9 * (pop.hbar * om * occ).sum() / geo.n_of_subvols
+    pop.engine.set_subvol_temperature(T - 3.0)
+    E, N, F = pop.engine.tally_state()
+    pop.engine.set_subvol_temperature(T)
+    e = pop.hbar * om * (occ - ph.calculate_occupation(T[sv] - 3.0, om))
+    assert np.array_equal(N, counts.astype(float))
+    np.testing.assert_allclose(E, np.bincount(sv, weights=e, minlength=geo.n_of_subvols), rtol=1e-9, atol=1e-12 * np.abs(e).sum())
+    v = ph.group_vel[m // J, m % J, :]
+    for k in range(3):
+        ref = np.bincount(sv, weights=v[:, k] * e, minlength=geo.n_of_subvols)
+        np.testing.assert_allclose(F[:, k], ref, rtol=1e-9, atol=1e-12 * np.abs(v[:, k] * e).sum())
+    pop.run(5, geo, ph)
+    assert abs(pop.N_p - n) < 0.1 * n
+    pop.engine.close()
+    # the host path still does the same job
+    monkeypatch.setenv('NK_HOST_INIT', '1')
+    pop2, geo2, ph2 = build_population(case, 20000, 11, None, extra=['--part_dist', dist])
+    assert not pop2._init_on_device(geo2, ph2) and pop2.engine.download()['positions'].shape[0] == 20000
+    pop2.engine.close()
+
+
 def test_part_dist_center_subvol():
     """--part_dist center_subvol: every subvolume's share of the particles starts at its centre."""
     pop, geo, ph = build_population('ttp', 20000, 3, None, extra=['--part_dist', 'center_subvol'])
