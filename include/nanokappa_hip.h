@@ -231,7 +231,7 @@ int nk_calibrate_stream(nk_ctx *ctx, int32_t launches, int64_t *bytes_read, int6
  * (Population.py:1241-1454) for one surface normal.  group_vel [M*3], omega [M], delta_omega [M] (the grid tolerance
  * of :1245-1247) are uploaded by nk_specular_begin; nk_specular_pairs returns every (in-mode, out-mode) pair of flat
  * mode indices, unordered, for the (rounded, inward) normal; *n_pairs receives the count (call again with a larger
- * `cap` when it exceeds it). */
+ * `cap` when it exceeds it).  pair_in = pair_out = NULL: the pairs stay on the device (for nk_rough_pairs), none returned. */
 int nk_specular_begin(nk_ctx *ctx, int64_t M, const double *group_vel, const double *omega, const double *delta_omega);
 int nk_specular_pairs(nk_ctx *ctx, const double *normal /* [3] */, double crit, int64_t cap, int32_t *pair_in,
                       int32_t *pair_out, int64_t *n_pairs);

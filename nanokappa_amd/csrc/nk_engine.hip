@@ -1864,7 +1864,7 @@ int nk_specular_begin(nk_ctx *ctx, int64_t M, const double *group_vel, const dou
 }
 int nk_specular_pairs(nk_ctx *ctx, const double *normal, double crit, int64_t cap, int32_t *pair_in, int32_t *pair_out,
                       int64_t *n_pairs) {
-    NK_ARG(ctx && normal && n_pairs && cap >= 0 && (cap == 0 || (pair_in && pair_out)), "nk_specular_pairs: bad arguments");
+    NK_ARG(ctx && normal && n_pairs && cap >= 0 && ((pair_in != nullptr) == (pair_out != nullptr)), "nk_specular_pairs: bad arguments");
     NK_ARG(ctx->spec_M > 0, "nk_specular_pairs: call nk_specular_begin first");
     NK_HIP(hipSetDevice(ctx->device));
     const int M = (int)ctx->spec_M;
@@ -1889,7 +1889,7 @@ int nk_specular_pairs(nk_ctx *ctx, const double *normal, double crit, int64_t ca
     *n_pairs = (int64_t)n;
     const int64_t got = (int64_t)n < cap ? (int64_t)n : cap;
     ctx->spec_last = (int64_t)n <= cap ? (int64_t)n : -1;      // -1: truncated, the caller asks again with more room
-    if (got > 0) {
+    if (got > 0 && pair_in) {                          // (NULL arrays: the pairs stay on the device for nk_rough_pairs)
         NK_HIP(hipMemcpy(pair_in, ctx->spec_in, (size_t)got * 4, hipMemcpyDeviceToHost));
         NK_HIP(hipMemcpy(pair_out, ctx->spec_out, (size_t)got * 4, hipMemcpyDeviceToHost));
     }

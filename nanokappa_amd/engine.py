@@ -383,18 +383,22 @@ class Engine(object):
         self._ck(self.L.nk_specular_begin(self.h, om.shape[0], _p(v), _p(om), _p(dl)), 'nk_specular_begin')
         self._spec_M = om.shape[0]
 
-    def specular_pairs(self, normal, crit=1e-3):
-        """(in, out) flat mode indices of every specular pair for one normal, unordered."""
+    def specular_pairs(self, normal, crit=1e-3, download=True):
+        """(in, out) flat mode indices of every specular pair for one normal, unordered.  download=False: the pairs stay on
+        the device for nk_rough_pairs and nothing is returned."""
         nrm = _d(np.asarray(normal, dtype=float))
-        cap = 4 * self._spec_M
+        cap = getattr(self, '_spec_cap', 4 * self._spec_M)
         while True:
-            pi, po = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
             n = C.c_int64(0)
-            self._ck(self.L.nk_specular_pairs(self.h, _p(nrm), float(crit), cap, _p(pi, c_ip), _p(po, c_ip), C.byref(n)),
-                     'nk_specular_pairs')
+            if download:
+                pi, po = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
+                self._ck(self.L.nk_specular_pairs(self.h, _p(nrm), float(crit), cap, _p(pi, c_ip), _p(po, c_ip), C.byref(n)),
+                         'nk_specular_pairs')
+            else:
+                self._ck(self.L.nk_specular_pairs(self.h, _p(nrm), float(crit), cap, None, None, C.byref(n)), 'nk_specular_pairs')
             if n.value <= cap:
-                return pi[:n.value].astype(np.int64), po[:n.value].astype(np.int64)
-            cap = int(n.value)
+                return (pi[:n.value].astype(np.int64), po[:n.value].astype(np.int64)) if download else None
+            cap = self._spec_cap = int(n.value)
 
     def specular_end(self):
         self._ck(self.L.nk_specular_end(self.h), 'nk_specular_end')

@@ -216,7 +216,10 @@ class Population(Constants):
             # 'velocity' model with a device engine: the tables are built in HBM and stay there; the host
             # keeps the pairs.  specularity / true_specular / spec_map / creation_roulette: see rough_tables()
             self._upload_material_and_mesh(geometry, phonon)
-            self.correspondent_modes = ST.rough_tables_device(self.engine, geometry, phonon, self.rough_facets, self.rough_facets_values)
+            # the pairs only come back (and are sorted into the reference's order) when their file is going to be written
+            self._corr = ST.rough_tables_device(self.engine, geometry, phonon, self.rough_facets, self.rough_facets_values,
+                                                want_rows=bool(self.rank == 0 and self.results_folder_name))
+            self._corr_src = (geometry, phonon)
             self._rough_on_device = True
             self.specularity = self.true_specular = self.spec_map = self.creation_roulette = None
         else:
@@ -234,6 +237,17 @@ class Population(Constants):
         if self.rank == 0 and self.results_folder_name:
             np.savetxt(os.path.join(self.results_folder_name, 'specular_correspondences.txt'), self.correspondent_modes,
                        fmt='%.3f %.3f %.3f %d %d %d %d')                            # Population.py:1461
+
+    @property
+    def correspondent_modes(self):
+        """(K,7) n(3) q_in j_in q_out j_out (Population.py:1241-1454); with device-built tables fetched on first use."""
+        if self._corr is None and getattr(self, '_rough_on_device', False):
+            self._corr = ST.specular_rows_device(self.engine, self._corr_src[0], self._corr_src[1], self.rough_facets)
+        return self._corr
+
+    @correspondent_modes.setter
+    def correspondent_modes(self, rows):
+        self._corr = rows
 
     def _upload_material_and_mesh(self, geometry, phonon):
         """nk_set_material + nk_set_mesh, once (the device builders of the set-up tables need them before the rest)."""

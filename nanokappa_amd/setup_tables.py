@@ -145,36 +145,73 @@ def _corr_rows(n, pi, po, in_modes, out_modes, v_ref, true_spec, inv_normals, i_
     return np.hstack((np.tile(n, (im.shape[0], 1)), im, om_))
 
 
-def rough_tables_device(engine, geometry, phonon, rough_facets, eta, crit=1e-3):
+def _distinct_normals(geometry, rough_facets):
+    normals = -np.round(geometry.facets_normal[np.asarray(rough_facets), :], decimals=10)
+    normals, inv_normals = np.unique(normals, axis=0, return_inverse=True)
+    return normals, np.asarray(inv_normals).ravel()
+
+
+def _pair_rows(engine, phonon, normals, inv_normals, i_n, crit, after_pairs=None):
+    """correspondent_modes rows of one normal from the device's pair search (after_pairs: called between the search and the
+    download of the next one, while the pairs are still on the device)."""
+    v = phonon.group_vel
+    J = phonon.omega.shape[1]
+    n = normals[i_n]
+    vdn = np.sum(v * n, axis=2)
+    in_modes = np.vstack(np.nonzero(vdn < 0)).T
+    out_modes = np.vstack(np.nonzero(vdn > 0)).T
+    v_in = v[in_modes[:, 0], in_modes[:, 1], :]
+    v_ref = v_in - 2 * n * np.sum(v_in * n, axis=1, keepdims=True)
+    gi, go = engine.specular_pairs(n, crit)
+    if after_pairs is not None:
+        after_pairs()
+    pi = np.searchsorted(in_modes[:, 0] * J + in_modes[:, 1], gi)
+    po = np.searchsorted(out_modes[:, 0] * J + out_modes[:, 1], go)
+    return _corr_rows(n, pi, po, in_modes, out_modes, v_ref, None, inv_normals, i_n)
+
+
+def _spec_begin(engine, phonon):
+    v = phonon.group_vel
+    k_grid = phonon.q_to_k(np.absolute(1 / (2 * phonon.data_mesh)))
+    delta_omega = np.sum((v * k_grid) ** 2, axis=2) ** 0.5
+    engine.specular_begin(v.reshape(-1, 3), phonon.omega.ravel(), delta_omega.ravel())
+
+
+def rough_tables_device(engine, geometry, phonon, rough_facets, eta, crit=1e-3, want_rows=True):
     """The 'velocity' reflection tables built and kept on the device (nk_rough_begin / nk_rough_pairs / nk_rough_finish):
     for every distinct normal the pair search (nk_specular_pairs) and, straight from the device-resident pairs, the
     truly-specular mask, the specular map and what the pairs take out of the diffuse creation rates; then specularity,
-    rates, roulette and its bucket index for all facets at once.  Only the pairs come back to the host (they are the rows
-    of `correspondent_modes`, which the reference also writes to specular_correspondences.txt)."""
+    rates, roulette and its bucket index for all facets at once.  Only the pairs come back to the host, and only when
+    wanted (they are the rows of `correspondent_modes`, which the reference writes to specular_correspondences.txt; on a
+    mesh with a thousand distinct normals sorting them into the reference's order is most of the set-up time):
+    returns the rows, or None (specular_rows_device builds them later)."""
     rough_facets = np.asarray(rough_facets)
-    normals = -np.round(geometry.facets_normal[rough_facets, :], decimals=10)
-    normals, inv_normals = np.unique(normals, axis=0, return_inverse=True)
-    inv_normals = np.asarray(inv_normals).ravel()
-    v = phonon.group_vel
-    Q, J = phonon.omega.shape
-    k_grid = phonon.q_to_k(np.absolute(1 / (2 * phonon.data_mesh)))
-    delta_omega = np.sum((v * k_grid) ** 2, axis=2) ** 0.5
+    normals, inv_normals = _distinct_normals(geometry, rough_facets)
     k_norm = np.sum(phonon.wavevectors ** 2, axis=1) ** 0.5
-    engine.specular_begin(v.reshape(-1, 3), phonon.omega.ravel(), delta_omega.ravel())
+    _spec_begin(engine, phonon)
     engine.rough_begin(rough_facets, -geometry.facets_normal[rough_facets, :], np.asarray(eta, dtype=float).ravel(), k_norm)
+    order = np.argsort(inv_normals, kind='stable')                   # the rough facets of every normal, in one pass
+    first = np.searchsorted(inv_normals[order], np.arange(normals.shape[0] + 1))
     rows = []
-    for i_n, n in enumerate(normals):
-        vdn = np.sum(v * n, axis=2)
-        in_modes = np.vstack(np.nonzero(vdn < 0)).T
-        out_modes = np.vstack(np.nonzero(vdn > 0)).T
-        v_in = v[in_modes[:, 0], in_modes[:, 1], :]
-        v_ref = v_in - 2 * n * np.sum(v_in * n, axis=1, keepdims=True)
-        gi, go = engine.specular_pairs(n, crit)
-        engine.rough_pairs(np.nonzero(inv_normals == i_n)[0])
-        pi = np.searchsorted(in_modes[:, 0] * J + in_modes[:, 1], gi)
-        po = np.searchsorted(out_modes[:, 0] * J + out_modes[:, 1], go)
-        rows.append(_corr_rows(n, pi, po, in_modes, out_modes, v_ref, None, inv_normals, i_n))
+    for i_n in range(normals.shape[0]):
+        share = order[first[i_n]:first[i_n + 1]]
+        if want_rows:
+            rows.append(_pair_rows(engine, phonon, normals, inv_normals, i_n, crit, after_pairs=lambda: engine.rough_pairs(share)))
+        else:
+            engine.specular_pairs(normals[i_n], crit, download=False)
+            engine.rough_pairs(share)
     engine.rough_finish()
+    engine.specular_end()
+    if not want_rows:
+        return None
+    return np.vstack(rows) if rows else np.zeros((0, 7))
+
+
+def specular_rows_device(engine, geometry, phonon, rough_facets, crit=1e-3):
+    """`correspondent_modes` (K,7) alone, from the device's pair search (for rough_tables_device(want_rows=False) callers)."""
+    normals, inv_normals = _distinct_normals(geometry, rough_facets)
+    _spec_begin(engine, phonon)
+    rows = [_pair_rows(engine, phonon, normals, inv_normals, i_n, crit) for i_n in range(normals.shape[0])]
     engine.specular_end()
     return np.vstack(rows) if rows else np.zeros((0, 7))
 
