@@ -1,13 +1,12 @@
 # Memory-latency counters of k_sweep (developer probe): separate --pmc passes, kernel-trace only.
-# Not run here: a pass with the TCC_EA0_*_LEVEL counters (TCC_EA0_RDREQ_LEVEL, _WRREQ_LEVEL: queue-depth accumulators of the
-# L2's memory side).  Round 1 tried one such pass once; the call ended at gpurun's time limit with nothing under gpurun_out/ --
-# no rocprofv3 log, no counter CSV (the box was killed before the merge), so the evidence ends there.  What is known: the
-# counters are listed for gfx950 (rocprofv3 -L: gpurun_out/counters.txt:2357-2400), the TCC block has 4 slots per pass
-# (MI355X_MICROARCH.md, PMC slots) and that pass asked for more than 4 TCC counters next to SQ ones, which makes rocprofv3
-# replay the workload in several passes; bench.py re-enqueues persistent kernels back to back, and every other multi-pass
-# request made since has been split by hand into passes of <= 4 TCC counters (scripts/profile_round.sh) and returned.  The
-# hang was not reproduced on purpose: a hung profiling pass costs a GPU-box strike.  If those counters are needed: ONE
-# counter per pass, `timeout -k 10 120` around the command, a 2-step bench (`--steps 2 --warmup 1 --repeats 1`).
+# Not run here: a pass with the TCC_EA0_*_LEVEL counters (queue-depth accumulators of the L2's memory side).  Round 1 tried one
+# such pass once and the call ended at gpurun's time limit with nothing under gpurun_out/.  Round 2 met the same ending with
+# evidence (gpurun_out/pmc_events/g1.log, scripts/pmc_events.sh): a pass that asks ONE block for more counters than it has
+# (there: four TA counters) fails at once in rocprofiler_create_counter_config -- "Request exceeds the capabilities of the
+# hardware to collect" --, rocprofv3 aborts, and the aborted process then sits in the tool's own signal handler
+# ("rocprofv3 finalizing after signal 6...") until the box's silence limit kills it.  It is not a GPU hang and not specific
+# to the _LEVEL counters; the round-1 pass asked the TCC block for more than its slots.  Rule: at most two counters per
+# hardware block and pass (SQ takes more), and `timeout -k 5 150` around every rocprofv3 --pmc command.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 B="python3 $R/bench.py --steps 12 --warmup 4 --no-cpu-baseline"
