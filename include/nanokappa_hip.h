@@ -249,6 +249,14 @@ int nk_specular_end(nk_ctx *ctx);
 int nk_rough_begin(nk_ctx *ctx, int32_t Fr, const int32_t *facet, const double *normal_in, const double *eta, const double *k_norm);
 int nk_rough_pairs(nk_ctx *ctx, int32_t nf, const int32_t *fidx);
 int nk_rough_finish(nk_ctx *ctx);
+/* The 'k' / wavevector reflection model (Population.py:1056-1240) through the same calls: after nk_specular_begin,
+ * nk_kspec_begin uploads the wavevectors [Q*3] with Phonon.k_to_q / q_to_k as row-major 3 x 3 matrices (q = k . k_to_q,
+ * k = q . q_to_k) and tol[3] = q_to_k(|1 / (2 mesh)|); nk_kspec_pairs is nk_specular_pairs for that model (one partner per
+ * in-mode); nk_rough_finish_k also averages the creation rates of the degenerate branches (find_degeneracies :1017-1040:
+ * nd rows q, j1, j2, applied in order, :926-930) and installs degen_j2 [M] (as in nk_rough) for the reflection's coin flip. */
+int nk_kspec_begin(nk_ctx *ctx, int64_t Q, const double *wavevectors, const double *k_to_q, const double *q_to_k, const double *tol);
+int nk_kspec_pairs(nk_ctx *ctx, const double *normal /* [3] */, int64_t cap, int32_t *pair_in, int32_t *pair_out, int64_t *n_pairs);
+int nk_rough_finish_k(nk_ctx *ctx, int32_t nd, const int32_t *degen /* [nd*3] */, const int32_t *degen_j2 /* [M] or NULL */);
 int nk_rough_download(nk_ctx *ctx, double *specularity, uint8_t *true_spec, int32_t *spec_map, double *roulette);
 /* enter_probability (Population.py:146-161) on the device: out[r*M + m] = max(0, v_m . n_in_r) * dt / thickness_r */
 int nk_build_enter_prob(nk_ctx *ctx, int32_t R, const double *normal_in, const double *thickness, double dt, double *out);

@@ -50,6 +50,9 @@ struct nk_ctx {
     NkSpecMode *spec_modes = nullptr;
     int32_t *spec_in = nullptr, *spec_out = nullptr;
     unsigned long long *spec_count = nullptr;
+    double *ks_kv = nullptr, *ks_mat = nullptr;   // 'k' model pair search: wavevectors [Q*3]; k_to_q, q_to_k, tol (21 doubles)
+    double ks_tol[3] = {0, 0, 0};
+    int64_t ks_Q = 0;
     int64_t spec_cap = 0;
     int64_t spec_last = 0;            // pairs of the last nk_specular_pairs call (still on the device)
     // rough tables under construction on the device (nk_rough_begin .. nk_rough_finish)
@@ -1822,8 +1825,9 @@ int nk_uniform2(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double
 static void nk_specular_free(nk_ctx *ctx) {
     for (void *p : {(void *)ctx->spec_v, (void *)ctx->spec_om, (void *)ctx->spec_dl, (void *)ctx->spec_modes,
                     (void *)ctx->spec_in, (void *)ctx->spec_out, (void *)ctx->spec_count, (void *)ctx->spec_svx,
-                    (void *)ctx->spec_rank})
+                    (void *)ctx->spec_rank, (void *)ctx->ks_kv, (void *)ctx->ks_mat})
         if (p) hipFree(p);
+    ctx->ks_kv = ctx->ks_mat = nullptr; ctx->ks_Q = 0;
     ctx->spec_v = ctx->spec_om = ctx->spec_dl = ctx->spec_svx = nullptr;
     ctx->spec_rank = nullptr;
     ctx->spec_modes = nullptr; ctx->spec_in = ctx->spec_out = nullptr; ctx->spec_count = nullptr;
@@ -1895,6 +1899,54 @@ int nk_specular_pairs(nk_ctx *ctx, const double *normal, double crit, int64_t ca
     }
     return NK_OK;
 }
+// 'k' / wavevector model (Population.py:1056-1240): the same calls as the 'velocity' search, between nk_specular_begin and
+// nk_specular_end; the pairs land where nk_rough_pairs expects them.
+int nk_kspec_begin(nk_ctx *ctx, int64_t Q, const double *wavevectors, const double *k_to_q, const double *q_to_k, const double *tol) {
+    NK_ARG(ctx && Q > 0 && wavevectors && k_to_q && q_to_k && tol, "nk_kspec_begin: bad arguments");
+    NK_ARG(ctx->spec_M > 0 && ctx->spec_M % Q == 0, "nk_kspec_begin: call nk_specular_begin first (M = Q x J modes)");
+    NK_HIP(hipSetDevice(ctx->device));
+    if (ctx->ks_kv) hipFree(ctx->ks_kv);
+    if (ctx->ks_mat) hipFree(ctx->ks_mat);
+    ctx->ks_kv = ctx->ks_mat = nullptr;
+    NK_HIP(hipMalloc((void **)&ctx->ks_kv, (size_t)Q * 24));
+    NK_HIP(hipMalloc((void **)&ctx->ks_mat, 18 * 8));
+    NK_HIP(hipMemcpy(ctx->ks_kv, wavevectors, (size_t)Q * 24, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ctx->ks_mat, k_to_q, 72, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ctx->ks_mat + 9, q_to_k, 72, hipMemcpyHostToDevice));
+    for (int c = 0; c < 3; ++c) ctx->ks_tol[c] = tol[c];
+    ctx->ks_Q = Q;
+    return NK_OK;
+}
+int nk_kspec_pairs(nk_ctx *ctx, const double *normal, int64_t cap, int32_t *pair_in, int32_t *pair_out, int64_t *n_pairs) {
+    NK_ARG(ctx && normal && n_pairs && cap >= 0 && ((pair_in != nullptr) == (pair_out != nullptr)), "nk_kspec_pairs: bad arguments");
+    NK_ARG(ctx->ks_Q > 0 && ctx->spec_M > 0, "nk_kspec_pairs: call nk_specular_begin and nk_kspec_begin first");
+    NK_HIP(hipSetDevice(ctx->device));
+    const int Q = (int)ctx->ks_Q, J = (int)(ctx->spec_M / ctx->ks_Q);
+    if (cap > ctx->spec_cap) {
+        if (ctx->spec_in) hipFree(ctx->spec_in);
+        if (ctx->spec_out) hipFree(ctx->spec_out);
+        ctx->spec_in = ctx->spec_out = nullptr;
+        NK_HIP(hipMalloc((void **)&ctx->spec_in, (size_t)cap * 4));
+        NK_HIP(hipMalloc((void **)&ctx->spec_out, (size_t)cap * 4));
+        ctx->spec_cap = cap;
+    }
+    NK_HIP(hipMemsetAsync(ctx->spec_count, 0, 8, ctx->stream));
+    k_kspec_pairs<<<(Q + NK_WG - 1) / NK_WG, NK_WG, 0, ctx->stream>>>(Q, J, ctx->spec_v, ctx->spec_om, ctx->ks_kv, ctx->ks_mat, ctx->ks_mat + 9,
+                                                                      ctx->ks_tol[0], ctx->ks_tol[1], ctx->ks_tol[2], normal[0], normal[1], normal[2],
+                                                                      cap, ctx->spec_in, ctx->spec_out, ctx->spec_count);
+    NK_HIP(hipGetLastError());
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    unsigned long long n = 0;
+    NK_HIP(hipMemcpy(&n, ctx->spec_count, 8, hipMemcpyDeviceToHost));
+    *n_pairs = (int64_t)n;
+    const int64_t got = (int64_t)n < cap ? (int64_t)n : cap;
+    ctx->spec_last = (int64_t)n <= cap ? (int64_t)n : -1;
+    if (got > 0 && pair_in) {
+        NK_HIP(hipMemcpy(pair_in, ctx->spec_in, (size_t)got * 4, hipMemcpyDeviceToHost));
+        NK_HIP(hipMemcpy(pair_out, ctx->spec_out, (size_t)got * 4, hipMemcpyDeviceToHost));
+    }
+    return NK_OK;
+}
 int nk_specular_end(nk_ctx *ctx) {
     NK_ARG(ctx, "nk_specular_end: NULL context");
     NK_HIP(hipSetDevice(ctx->device));
@@ -1955,15 +2007,30 @@ int nk_rough_pairs(nk_ctx *ctx, int32_t nf, const int32_t *fidx) {
     NK_HIP(hipStreamSynchronize(ctx->stream));
     return NK_OK;
 }
-int nk_rough_finish(nk_ctx *ctx) {
+int nk_rough_finish(nk_ctx *ctx) { return nk_rough_finish_k(ctx, 0, nullptr, nullptr); }
+// the same with the 'k' model's degenerate branches (find_degeneracies, Population.py:1017-1040: rows q, j1, j2): their
+// creation rates are averaged (:926-930) and the reflection flips a coin between them (:963-969; degen_j2 [M] as in nk_rough)
+int nk_rough_finish_k(nk_ctx *ctx, int32_t nd, const int32_t *degen, const int32_t *degen_j2) {
     NK_ARG(ctx && ctx->rb_Fr > 0 && ctx->spec_v, "nk_rough_finish: call nk_rough_begin (inside nk_specular_begin .. end) first");
+    NK_ARG(nd >= 0 && (nd == 0 || degen), "nk_rough_finish_k: bad arguments");
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     const int Fr = ctx->rb_Fr;
     const size_t n = (size_t)Fr * d.M;
     k_rough_finish<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>(Fr, d.M, d.J, ctx->spec_v, ctx->rb_k2, ctx->rb_nin, ctx->rb_eta,
                                                                               ctx->rb_ts, (int32_t *)ctx->rb_map, ctx->rb_sub, ctx->rb_spec,
-                                                                              ctx->rb_roul);
+                                                                              ctx->rb_roul, nd == 0 ? 1 : 0);
+    const int32_t *dj2 = nullptr;
+    if (nd > 0) {
+        for (int i = 0; i < nd; ++i)
+            NK_ARG(degen[3 * i] >= 0 && degen[3 * i] < d.M / d.J && degen[3 * i + 1] >= 0 && degen[3 * i + 1] < d.J && degen[3 * i + 2] >= 0 &&
+                       degen[3 * i + 2] < d.J, "nk_rough_finish_k: degeneracy row out of range");
+        NK_BUF(int32_t, dg, degen, (int64_t)nd * 3);
+        k_rough_degen<<<(Fr + 63) / 64, 64, 0, ctx->stream>>>(Fr, d.M, d.J, nd, dg.p, ctx->rb_roul);
+        k_rough_round<<<(int)((n + NK_WG - 1) / NK_WG), NK_WG, 0, ctx->stream>>>((int64_t)n, ctx->rb_roul);
+        NK_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (degen_j2) NK_UP(degen_j2, (size_t)d.M, &dj2);
     k_rough_cumsum<<<Fr, 64, 0, ctx->stream>>>(d.M, ctx->rb_roul);
     int nlut = 1024;
     while (nlut < 65536 && (int64_t)nlut * 4 < d.M) nlut *= 2;
@@ -1977,7 +2044,7 @@ int nk_rough_finish(nk_ctx *ctx) {
     d.Fr = Fr;
     ctx->g_sweep = 0;
     d.specularity = ctx->rb_spec; d.true_spec = ctx->rb_ts; d.spec_map = (const int32_t *)ctx->rb_map; d.roulette = ctx->rb_roul;
-    d.roul_lut = lut; d.roul_nlut = nlut; d.degen_j2 = nullptr;
+    d.roul_lut = lut; d.roul_nlut = nlut; d.degen_j2 = dj2;
     for (void *p : {(void *)ctx->rb_spec, (void *)ctx->rb_roul, (void *)ctx->rb_ts, (void *)ctx->rb_map}) ctx->allocs.push_back(p);
     ctx->rb_spec = ctx->rb_roul = nullptr; ctx->rb_ts = nullptr; ctx->rb_map = nullptr;
     nk_rough_build_free(ctx, false);

@@ -1562,7 +1562,7 @@ __global__ __launch_bounds__(NK_WG) void k_rough_pairs(int M, int J, const doubl
 // ten decimals (np.around, :933)
 __global__ __launch_bounds__(NK_WG) void k_rough_finish(int Fr, int M, int J, const double *v, const double *k2, const double *nin,
                                                        const double *eta, const uint8_t *true_spec, int32_t *spec_map, const double *sub,
-                                                       double *specularity, double *rate) {
+                                                       double *specularity, double *rate, int round_now) {
     const int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= (int64_t)Fr * M) return;
     const int f = (int)(i / M), m = (int)(i - (int64_t)f * M);
@@ -1571,7 +1571,104 @@ __global__ __launch_bounds__(NK_WG) void k_rough_finish(int Fr, int M, int J, co
     specularity[i] = true_spec[i] ? sp : 0.0;
     if (!true_spec[i]) spec_map[i] = -1;
     const double c = (vdn > 0.0 ? vdn : 0.0) - sub[i];
-    rate[i] = rint(c * 1e10) / 1e10;
+    rate[i] = round_now ? rint(c * 1e10) / 1e10 : c;
+}
+// find_specular_correspondences, 'k' / wavevector model (Population.py:1056-1240), for one normal: one thread per q-point.
+// An in-mode (q, j) is specular when the mirrored wavevector k - 2 n (k.n) is the shortest of its 27 reciprocal-lattice
+// neighbours (a normal process: Phonon.find_min_k's first pass ends at the zero displacement, Phonon.py:209-247, with its
+// first-minimum rule in np.meshgrid's 'xy' order), lies within half a grid step (per axis) of the nearest grid point,
+// that point has an outgoing branch, and of the outgoing branches whose frequency interval overlaps the in-mode's the one
+// with the smallest relative frequency difference is taken (the first of equals).  The nearest grid point is searched
+// over ALL q-points, staged through LDS in tiles (what scipy's NearestNDInterpolator answers).
+// a2q, q2k: row-major 3 x 3, q = k . a2q and k = q . q2k (Phonon.k_to_q / q_to_k).
+__global__ __launch_bounds__(NK_WG) void k_kspec_pairs(int Q, int J, const double *v, const double *om, const double *kv, const double *a2q,
+                                                       const double *q2k, double tx, double ty, double tz, double nx, double ny, double nz,
+                                                       int64_t cap, int32_t *pin, int32_t *pout, unsigned long long *count) {
+    // The normal-process test is a comparison of norms that TIE on the zone boundary; which of the equals is a hair smaller
+    // is decided by how the reference's NumPy rounds: np.dot goes through dgemm, whose kernels accumulate
+    // fma(a2, b2, fma(a1, b1, a0 b0)); element-wise products and np.linalg.norm do not fuse.  The same operations here.
+#pragma clang fp contract(off)
+    __shared__ double tile[NK_WG * 3];
+    const int q = blockIdx.x * NK_WG + threadIdx.x;
+    bool act = q < Q;
+    double kx = 0, ky = 0, kz = 0;
+    if (act) {
+        bool any_in = false;
+        for (int j = 0; j < J; ++j) { const double *vv = v + ((int64_t)q * J + j) * 3; any_in |= (vv[0] * nx + vv[1] * ny + vv[2] * nz) < 0.0; }
+        act = any_in;
+        const double s = kv[3 * q] * nx + kv[3 * q + 1] * ny + kv[3 * q + 2] * nz;
+        kx = kv[3 * q] - (2.0 * nx) * s; ky = kv[3 * q + 1] - (2.0 * ny) * s; kz = kv[3 * q + 2] - (2.0 * nz) * s;
+    }
+    if (act) {                                        // normal process: the zero displacement is the first minimum
+        const double q0 = fma(kz, a2q[6], fma(ky, a2q[3], kx * a2q[0])), q1 = fma(kz, a2q[7], fma(ky, a2q[4], kx * a2q[1])),
+                     q2 = fma(kz, a2q[8], fma(ky, a2q[5], kx * a2q[2]));
+        double best = __builtin_inf();
+        int ibest = -1;
+        for (int t = 0; t < 27; ++t) {                // np.meshgrid(a, a, a) 'xy': neighbour t = (a[j], a[i], a[k]), t = 9 i + 3 j + k
+            const double a0 = q0 + (double)((t / 3) % 3 - 1), a1 = q1 + (double)(t / 9 - 1), a2 = q2 + (double)(t % 3 - 1);
+            const double x = fma(a2, q2k[6], fma(a1, q2k[3], a0 * q2k[0])), y = fma(a2, q2k[7], fma(a1, q2k[4], a0 * q2k[1])),
+                         z = fma(a2, q2k[8], fma(a1, q2k[5], a0 * q2k[2]));
+            const double nr = sqrt((x * x + y * y) + z * z);
+            if (nr < best) { best = nr; ibest = t; }
+        }
+        act = ibest == 13;
+    }
+    // nearest grid point of the mirrored wavevector
+    double dbest = __builtin_inf();
+    int qo = 0;
+    for (int t0 = 0; t0 < Q; t0 += NK_WG) {
+        __syncthreads();
+        const int tq = t0 + threadIdx.x;
+        if (tq < Q) { tile[3 * threadIdx.x] = kv[3 * tq]; tile[3 * threadIdx.x + 1] = kv[3 * tq + 1]; tile[3 * threadIdx.x + 2] = kv[3 * tq + 2]; }
+        __syncthreads();
+        const int nt = Q - t0 < NK_WG ? Q - t0 : NK_WG;
+        if (act)
+            for (int i = 0; i < nt; ++i) {
+                const double dx = kx - tile[3 * i], dy = ky - tile[3 * i + 1], dz = kz - tile[3 * i + 2];
+                const double dd = dx * dx + dy * dy + dz * dz;
+                if (dd < dbest) { dbest = dd; qo = t0 + i; }
+            }
+    }
+    if (!act) return;
+    if (!(fabs(kx - kv[3 * qo]) < tx && fabs(ky - kv[3 * qo + 1]) < ty && fabs(kz - kv[3 * qo + 2]) < tz)) return;
+    for (int ji = 0; ji < J; ++ji) {
+        const double *vi = v + ((int64_t)q * J + ji) * 3;
+        if (!((vi[0] * nx + vi[1] * ny + vi[2] * nz) < 0.0)) continue;
+        const double io = om[(int64_t)q * J + ji];
+        const double idl = fabs(vi[0]) * tx + fabs(vi[1]) * ty + fabs(vi[2]) * tz;
+        const double iup = io + idl, idn = io - idl;
+        double dmin = __builtin_inf();
+        int br = -1;
+        for (int jo = 0; jo < J; ++jo) {
+            const double *vo = v + ((int64_t)qo * J + jo) * 3;
+            if (!((vo[0] * nx + vo[1] * ny + vo[2] * nz) > 0.0)) continue;
+            const double oo = om[(int64_t)qo * J + jo];
+            const double odl = fabs(vo[0]) * tx + fabs(vo[1]) * ty + fabs(vo[2]) * tz;
+            const double oup = oo + odl, odn = oo - odl;
+            if (!(((iup < oup ? iup : oup) - (idn > odn ? idn : odn)) > 0.0)) continue;
+            const double df = fabs((io - oo) / io);
+            if (br < 0 || df < dmin) { dmin = df; br = jo; }
+        }
+        if (br < 0) continue;
+        const unsigned long long at = atomicAdd(count, 1ull);
+        if ((int64_t)at < cap) { pin[at] = q * J + ji; pout[at] = qo * J + br; }
+    }
+}
+// 'k' model: creation rates of degenerate branches are averaged (Population.py:926-930), pair after pair in the list's order,
+// before they are rounded.  One thread per rough facet.
+__global__ void k_rough_degen(int Fr, int M, int J, int nd, const int32_t *degen, double *rate) {
+    const int f = blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= Fr) return;
+    double *r = rate + (int64_t)f * M;
+    for (int i = 0; i < nd; ++i) {
+        const int q = degen[3 * i], j1 = degen[3 * i + 1], j2 = degen[3 * i + 2];
+        const double m = (r[(int64_t)q * J + j1] + r[(int64_t)q * J + j2]) / 2.0;
+        r[(int64_t)q * J + j1] = m; r[(int64_t)q * J + j2] = m;
+    }
+}
+__global__ void k_rough_round(int64_t n, double *rate) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rate[i] = rint(rate[i] * 1e10) / 1e10;
 }
 // creation_roulette = cumsum(rate) / max(cumsum) per facet (:938-939), the running sum in np.cumsum's own order: one wave per
 // facet reads 64 rates at a time (coalesced) and every lane adds them up one by one, keeping the sum at its own position.

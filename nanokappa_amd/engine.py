@@ -78,7 +78,8 @@ EXPORTS = ['nk_device_count', 'nk_create', 'nk_destroy', 'nk_last_error', 'nk_se
            'nk_set_subvol_temperature', 'nk_get_step', 'nk_get_timing', 'nk_comm_unique_id', 'nk_comm_init',
            'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2', 'nk_calibrate_stream',
            'nk_specular_begin', 'nk_specular_pairs', 'nk_specular_end', 'nk_rough_begin', 'nk_rough_pairs', 'nk_rough_finish',
-           'nk_rough_download', 'nk_build_enter_prob', 'nk_init_particles', 'nk_tally_state']
+           'nk_rough_download', 'nk_build_enter_prob', 'nk_init_particles', 'nk_tally_state', 'nk_kspec_begin', 'nk_kspec_pairs',
+           'nk_rough_finish_k']
 
 _lib = None
 
@@ -127,6 +128,9 @@ def load_library():
     L.nk_rough_begin.argtypes = [C.c_void_p, C.c_int32, c_ip, c_dp, c_dp, c_dp]
     L.nk_rough_pairs.argtypes = [C.c_void_p, C.c_int32, c_ip]
     L.nk_rough_finish.argtypes = [C.c_void_p]
+    L.nk_rough_finish_k.argtypes = [C.c_void_p, C.c_int32, c_ip, c_ip]
+    L.nk_kspec_begin.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_dp]
+    L.nk_kspec_pairs.argtypes = [C.c_void_p, c_dp, C.c_int64, c_ip, c_ip, C.POINTER(C.c_int64)]
     L.nk_rough_download.argtypes = [C.c_void_p, c_dp, c_up, c_ip, c_dp]
     L.nk_build_enter_prob.argtypes = [C.c_void_p, C.c_int32, c_dp, c_dp, C.c_double, c_dp]
     _lib = L
@@ -414,8 +418,31 @@ class Engine(object):
         f = _i(rough_facet_indices)
         self._ck(self.L.nk_rough_pairs(self.h, f.shape[0], _p(f, c_ip)), 'nk_rough_pairs')
 
-    def rough_finish(self):
-        self._ck(self.L.nk_rough_finish(self.h), 'nk_rough_finish')
+    def rough_finish(self, degeneracies=None, degen_j2=None):
+        """degeneracies [nd, 3] (q, j1, j2) and degen_j2 [M]: the 'k' model's degenerate branches (nk_rough_finish_k)."""
+        if degeneracies is None:
+            self._ck(self.L.nk_rough_finish(self.h), 'nk_rough_finish')
+            return
+        dg = _i(np.asarray(degeneracies, dtype=np.int32).reshape(-1, 3))
+        dj = None if degen_j2 is None else _i(degen_j2)
+        self._ck(self.L.nk_rough_finish_k(self.h, dg.shape[0], _p(dg, c_ip), _p(dj, c_ip)), 'nk_rough_finish_k')
+
+    def kspec_begin(self, wavevectors, k_to_q, q_to_k, tol):
+        """'k' model pair search (after specular_begin): q = k . k_to_q, k = q . q_to_k (3 x 3), tol [3]."""
+        kv, a, b, t = _d(wavevectors), _d(np.asarray(k_to_q, dtype=float).reshape(3, 3)), _d(np.asarray(q_to_k, dtype=float).reshape(3, 3)), _d(tol)
+        self._ck(self.L.nk_kspec_begin(self.h, kv.shape[0], _p(kv), _p(a), _p(b), _p(t)), 'nk_kspec_begin')
+
+    def kspec_pairs(self, normal, download=True):
+        """(in, out) flat mode indices of the 'k' model's specular pairs for one normal (one partner per in-mode)."""
+        nrm = _d(np.asarray(normal, dtype=float))
+        cap = self._spec_M
+        n = C.c_int64(0)
+        if download:
+            pi, po = np.empty(cap, dtype=np.int32), np.empty(cap, dtype=np.int32)
+            self._ck(self.L.nk_kspec_pairs(self.h, _p(nrm), cap, _p(pi, c_ip), _p(po, c_ip), C.byref(n)), 'nk_kspec_pairs')
+            return pi[:n.value].astype(np.int64), po[:n.value].astype(np.int64)
+        self._ck(self.L.nk_kspec_pairs(self.h, _p(nrm), cap, None, None, C.byref(n)), 'nk_kspec_pairs')
+        return None
 
     def rough_download(self):
         """(specularity, true_spec, spec_map, roulette), each [Fr, M]."""

@@ -212,13 +212,18 @@ class Population(Constants):
         if not self.k_model and self.scat_model not in ('v', 'vel', 'velocity', 'groupvel', 'group_vel'):
             raise Exception('Invalid --bound_scat')
         self.degeneracies, self.degen_index = ST.find_degeneracies(phonon)
-        if not self.k_model and hasattr(self.engine, 'rough_begin'):
-            # 'velocity' model with a device engine: the tables are built in HBM and stay there; the host
-            # keeps the pairs.  specularity / true_specular / spec_map / creation_roulette: see rough_tables()
+        if hasattr(self.engine, 'rough_begin') and (not self.k_model or hasattr(self.engine, 'kspec_begin')):
+            # with a device engine the tables of both reflection models are built in HBM and stay there;
+            # specularity / true_specular / spec_map / creation_roulette: see rough_tables()
             self._upload_material_and_mesh(geometry, phonon)
             # the pairs only come back (and are sorted into the reference's order) when their file is going to be written
-            self._corr = ST.rough_tables_device(self.engine, geometry, phonon, self.rough_facets, self.rough_facets_values,
-                                                want_rows=bool(self.rank == 0 and self.results_folder_name))
+            want = bool(self.rank == 0 and self.results_folder_name)
+            if self.k_model:
+                self._corr = ST.rough_tables_device_k(self.engine, geometry, phonon, self.rough_facets, self.rough_facets_values,
+                                                      self.degeneracies, self.degen_index, want_rows=want)
+            else:
+                self._corr = ST.rough_tables_device(self.engine, geometry, phonon, self.rough_facets, self.rough_facets_values,
+                                                    want_rows=want)
             self._corr_src = (geometry, phonon)
             self._rough_on_device = True
             self.specularity = self.true_specular = self.spec_map = self.creation_roulette = None
@@ -242,7 +247,8 @@ class Population(Constants):
     def correspondent_modes(self):
         """(K,7) n(3) q_in j_in q_out j_out (Population.py:1241-1454); with device-built tables fetched on first use."""
         if self._corr is None and getattr(self, '_rough_on_device', False):
-            self._corr = ST.specular_rows_device(self.engine, self._corr_src[0], self._corr_src[1], self.rough_facets)
+            fn = ST.specular_rows_device_k if self.k_model else ST.specular_rows_device
+            self._corr = fn(self.engine, self._corr_src[0], self._corr_src[1], self.rough_facets)
         return self._corr
 
     @correspondent_modes.setter

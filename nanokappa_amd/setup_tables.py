@@ -207,6 +207,65 @@ def rough_tables_device(engine, geometry, phonon, rough_facets, eta, crit=1e-3, 
     return np.vstack(rows) if rows else np.zeros((0, 7))
 
 
+def degen_partner(phonon, degeneracies, degen_index):
+    """(Q, J) partner branch of the 'k' model's coin flip (Population.py:963-969): the third column of the degeneracy row
+    a mode belongs to, -1 for the others."""
+    Q, J = phonon.omega.shape
+    j2 = -np.ones((Q, J), dtype=np.int32)
+    di = np.asarray(degen_index).astype(int)
+    has = di > -1
+    j2[has] = np.asarray(degeneracies)[di[has], 2]
+    return j2
+
+
+def _kspec_begin(engine, phonon):
+    _spec_begin(engine, phonon)
+    R = np.asarray(phonon.reciprocal_lattice, dtype=float)
+    tol = phonon.q_to_k(np.absolute(1 / (2 * phonon.data_mesh)))
+    engine.kspec_begin(phonon.wavevectors, np.linalg.inv(R).T, R.T, tol)          # Phonon.k_to_q / q_to_k as q = k . A, k = q . B
+
+
+def _k_rows(n, gi, go, J):
+    """correspondent_modes rows of one normal, 'k' model: in (q, j) order, as np.nonzero walks the reference's table."""
+    o = np.argsort(gi, kind='stable')
+    gi, go = gi[o], go[o]
+    return np.vstack((np.ones(gi.shape[0]) * n.reshape(-1, 1), gi // J, gi % J, go // J, go % J)).T
+
+
+def rough_tables_device_k(engine, geometry, phonon, rough_facets, eta, degeneracies, degen_index, want_rows=True):
+    """rough_tables_device for the 'k' / wavevector model (Population.py:1056-1240): the pair search of every distinct normal
+    as a kernel (nk_kspec_pairs), the tables from the device-resident pairs as for the 'velocity' model, creation rates of
+    degenerate branches averaged before the roulette (:926-930)."""
+    rough_facets = np.asarray(rough_facets)
+    normals, inv_normals = _distinct_normals(geometry, rough_facets)
+    J = phonon.omega.shape[1]
+    k_norm = np.sum(phonon.wavevectors ** 2, axis=1) ** 0.5
+    _kspec_begin(engine, phonon)
+    engine.rough_begin(rough_facets, -geometry.facets_normal[rough_facets, :], np.asarray(eta, dtype=float).ravel(), k_norm)
+    order = np.argsort(inv_normals, kind='stable')
+    first = np.searchsorted(inv_normals[order], np.arange(normals.shape[0] + 1))
+    rows = []
+    for i_n in range(normals.shape[0]):
+        pairs = engine.kspec_pairs(normals[i_n], download=want_rows)
+        engine.rough_pairs(order[first[i_n]:first[i_n + 1]])
+        if want_rows:
+            rows.append(_k_rows(normals[i_n], pairs[0], pairs[1], J))
+    engine.rough_finish(degeneracies, degen_partner(phonon, degeneracies, degen_index).ravel())
+    engine.specular_end()
+    if not want_rows:
+        return None
+    return np.vstack(rows) if rows else np.zeros((0, 7))
+
+
+def specular_rows_device_k(engine, geometry, phonon, rough_facets):
+    normals, _ = _distinct_normals(geometry, rough_facets)
+    J = phonon.omega.shape[1]
+    _kspec_begin(engine, phonon)
+    rows = [_k_rows(n, *engine.kspec_pairs(n), J) for n in normals]
+    engine.specular_end()
+    return np.vstack(rows) if rows else np.zeros((0, 7))
+
+
 def specular_rows_device(engine, geometry, phonon, rough_facets, crit=1e-3):
     """`correspondent_modes` (K,7) alone, from the device's pair search (for rough_tables_device(want_rows=False) callers)."""
     normals, inv_normals = _distinct_normals(geometry, rough_facets)

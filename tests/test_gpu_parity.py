@@ -616,6 +616,60 @@ def test_two_rank_sharding_on_one_gpu(case, monkeypatch):
     assert np.array_equal(p['positions'][o1], np.concatenate([q['positions'] for q in parts])[o2])
 
 
+def test_rough_tables_of_the_k_model_built_on_device():
+    """SURVEY 8f row 1, 'k' / wavevector model (Population.py:1056-1240): the pair search as a kernel (nk_kspec_pairs) and the
+    tables built from it on the device, against the NumPy builders (pinned to the reference's goldens by
+    tests/test_host_geometry.py) and against the reference's own tables; then 10 steps of the engine on the tables it built
+    against the oracle on the host-built ones."""
+    from util import case_from_args
+    from nanokappa_amd import setup_tables as ST
+    from nanokappa_amd.engine import Engine
+    import ref_harness_args as A
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    args = initialise_parser().parse_args(A.argv_for('ttrrp', 100000) + ['--bound_scat', 'k'])
+    args.results_folder = ''
+    geo = Geometry(args)
+    ph = golden_phonon()
+    # zone-boundary q-points have several equally short images and numpy versions break the tie differently; the k model
+    # mirrors wavevectors, so it is checked on the reference's own choice (as tests/test_host_geometry.py does)
+    ph.wavevectors = golden('phonon')['wavevectors'].copy()
+    Q, J = ph.omega.shape
+    eng = Engine(0, 9)
+    eng.set_material(ph.tables())
+    eng.set_mesh(geo.tables())
+    deg, didx = ST.find_degeneracies(ph)
+    corr = ST.rough_tables_device_k(eng, geo, ph, geo.rough_facets, geo.rough_facets_values, deg, didx)
+    sp, ts, sm, ro = eng.rough_download()
+    corr_h, ts_h = ST.specular_correspondences_k(geo, ph, geo.rough_facets)
+    spec_h = ts_h.astype(int) * ST.fbz_specularity(geo, ph, geo.rough_facets, geo.rough_facets_values)
+    sm_h = ST.specular_map(corr_h, geo, geo.rough_facets, Q, J)
+    _, ro_h = ST.diffuse_roulette(geo, ph, geo.rough_facets, spec_h, corr_h, scat_model='k', degeneracies=deg)
+    assert corr.shape[0] > 1000 and np.array_equal(corr, corr_h)
+    assert np.array_equal(ts.astype(bool), ts_h.reshape(-1, Q * J))
+    assert np.array_equal(sm, sm_h.reshape(-1, Q * J))
+    assert rel_err(sp, spec_h.reshape(-1, Q * J)) < 1e-12
+    assert np.allclose(ro, ro_h, rtol=0, atol=1e-11)
+    gs = sub(golden('setup'), 'k')
+    assert np.array_equal(ts.astype(bool), gs['true_specular'].reshape(-1, Q * J))
+    assert np.allclose(ro, gs['creation_roulette'].reshape(-1, Q * J), rtol=0, atol=1e-11)
+    assert np.array_equal(ST.specular_rows_device_k(eng, geo, ph, geo.rough_facets), corr_h)
+    ct = case_from_args(A.argv_for('ttrrp', 30000), 'Si', scat_model='k')
+    pos, mode, occ, counter = random_population(ct, 20000, seed=5)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=9)
+    eng.set_subvolumes(ct['centers'], ct['volumes'], 0, ct['axis'], 1, np.full(ct['centers'].shape[0], 298.0))
+    eng.set_reservoirs(ct['res_facets'], ct['res_T'], ct['enter_prob'], counter)
+    eng.set_params(dt=1.0, particle_density=ct['particle_density'])
+    eng.upload(pos, mode, occ)
+    eng.init_boundaries()
+    t = eng.step(10)
+    for s in range(10):
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+    eng.close()
+
+
 def test_rough_tables_built_on_device_equal_host_builders_and_goldens():
     """specularity, truly-specular mask, specular map and creation roulette of the T T R R P box, built on
     the device (nk_rough_begin / nk_rough_pairs / nk_rough_finish), against the NumPy builders (which the reference's
