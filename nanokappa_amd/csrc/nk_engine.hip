@@ -131,14 +131,26 @@ static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
 // KERNEL bound to the one that matches.  Rough facets draw random numbers per particle, so they imply ids.  The last
 // parameter says where the mode records are read from (LDS copies of the segment's share, or the table in HBM).
 #define NK_SWEEP_CASE(G, R, B, P, S, lrec, STMT) { if (lrec) { auto KERNEL = k_sweep<G, R, B, P, S, true>; STMT; } else { auto KERNEL = k_sweep<G, R, B, P, S, false>; STMT; } }
+// the plain sweep of small meshes also exists with the commonest switches compiled in (nk_sweep_fast)
+#define NK_SWEEP_CASE_FAST(lrec, fast, STMT)                                                                                   \
+    { if (lrec) { if ((fast) == 1) { auto KERNEL = k_sweep<1, false, false, false, false, true, 1>; STMT; } else { auto KERNEL = k_sweep<1, false, false, false, false, true, 2>; STMT; } } \
+      else { if ((fast) == 1) { auto KERNEL = k_sweep<1, false, false, false, false, false, 1>; STMT; } else { auto KERNEL = k_sweep<1, false, false, false, false, false, 2>; STMT; } } }
 #define NK_SWEEP_CASE_S(G, R, B, P, split, lrec, STMT) { if (split) NK_SWEEP_CASE(G, R, B, P, true, lrec, STMT) else NK_SWEEP_CASE(G, R, B, P, false, lrec, STMT) }
 #define NK_SWEEP_CASE_RP(G, B, rough, pid, split, lrec, STMT)                                         \
     { if (rough) NK_SWEEP_CASE_S(G, true, B, true, split, lrec, STMT) else if (pid) NK_SWEEP_CASE_S(G, false, B, true, split, lrec, STMT) else NK_SWEEP_CASE_S(G, false, B, false, split, lrec, STMT) }
 #define NK_SWEEP_DISPATCH(gm, rough, rbf, pid, split, lrec, STMT)                                     \
     do {                                                                                               \
+        const int fast_ = ((gm) == 1 && !(rough) && !(rbf) && !(pid) && !(split)) ? nk_sweep_fast(ctx) : 0;   \
+        if (fast_) { NK_SWEEP_CASE_FAST(lrec, fast_, STMT) break; }                                    \
         if ((gm) == 1) { if (rbf) NK_SWEEP_CASE_RP(1, true, rough, pid, split, lrec, STMT) else NK_SWEEP_CASE_RP(1, false, rough, pid, split, lrec, STMT) }   \
         else { if (rbf) NK_SWEEP_CASE_RP(2, true, rough, pid, split, lrec, STMT) else NK_SWEEP_CASE_RP(2, false, rough, pid, split, lrec, STMT) }             \
     } while (0)
+// 1 / 2: slice subvolumes, 'nearest' / 'linear' particle temperatures and the local reference temperature (k_sweep's FAST)
+static inline int nk_sweep_fast(const nk_ctx *ctx) {
+    const NkDev &d = ctx->d;
+    if (getenv("NK_NO_FAST")) return 0;              // developer probe
+    return (d.sv_kind == 0 && d.T_ref_local && (d.sv_interp == 0 || d.sv_interp == 1)) ? 1 + d.sv_interp : 0;
+}
 // the sweep keeps its segments' mode records in LDS when the modes are partitioned over the segments and a segment's share fits
 static inline bool nk_want_lrec(const nk_ctx *ctx) { return ctx->d.part && ctx->d.nlmax <= NK_LREC; }
 // k_events, the same way
@@ -1027,7 +1039,7 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     const int gm_ = nk_geom_mode(ctx);
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx), split_ = nk_want_split(ctx);
     const bool lrec_ = nk_want_lrec(ctx);
-    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4) | (split_ << 5) | (lrec_ << 6);
+    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4) | (split_ << 5) | (lrec_ << 6) | (nk_sweep_fast(ctx) << 7);
     if (ctx->g_sweep == 0 || ctx->g_sweep_key != key) {
         const size_t lds_w = nk_lds(ctx, true, pid_ ? 3 : 2);
         int per_cu = 0;
@@ -1390,7 +1402,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         if (d.mig_buf) k_deliver<<<g_emit, NK_WG, 0, ctx->stream>>>(d);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
         pending = true;
-        if ((s & 63) == 63) NK_HIP(hipGetLastError());
+        if ((s & 63) == 0) NK_HIP(hipGetLastError());   // a bad launch configuration shows at the first step of a batch (every step launches the same)
     }
     NK_HIP(hipEventRecord(t1, ctx->stream));
     NK_HIP(hipGetLastError());
