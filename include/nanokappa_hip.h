@@ -185,9 +185,9 @@ int nk_init_boundaries(nk_ctx *ctx);
 /* Population.initialise_all_particles on the device (Population.py:186-321), instead of nk_reserve + nk_upload_particles, for
  * the common case: modes tiled over the particle ids (initialise_modes, :127-144: particle p has mode unique_modes[p %
  * n_unique], flat indices q * J + j of the active modes), ids pid_lo .. pid_lo + N - 1, positions uniform in the solid
- * (Mesh.sample_volume, Mesh.py:890-904; sv_first NULL = 'random_domain') or uniform in the subvolume the particle's index
- * belongs to (sv_first[S + 1] ascending from 0: index i in [sv_first[s], sv_first[s + 1]) lies in subvolume s =
- * 'random_subvol', :222-246), occupations Bose-Einstein at the subvolume's temperature (:280).  Needs nk_set_material,
+ * (Mesh.sample_volume, Mesh.py:890-904; sv_first NULL = 'random_domain') or uniform in the subvolume the particle's id
+ * belongs to (sv_first[S + 1] ascending from 0: id p in [sv_first[s], sv_first[s + 1]) lies in subvolume s =
+ * 'random_subvol', :222-246; ids, not local indices, so that the shards of several ranks make up the single-rank ensemble), occupations Bose-Einstein at the subvolume's temperature (:280).  Needs nk_set_material,
  * nk_set_mesh (with the volume tables), nk_set_subvolumes and the boundary-condition tables; nk_init_boundaries follows. */
 int nk_init_particles(nk_ctx *ctx, int64_t N, int64_t capacity, uint64_t pid_lo, const int32_t *unique_modes, int64_t n_unique,
                       const int64_t *sv_first);

@@ -1234,9 +1234,10 @@ __device__ __forceinline__ uint64_t nk_state_key(int mode, double x, double y, d
 }
 
 // Population.initialise_all_particles on the device (Population.py:186-321) for the common case: modes tiled over the
-// particle index (:127-144, at least one particle per mode and subvolume), positions 'random_domain' (one draw of
-// Mesh.sample_volume, Mesh.py:890-904) or 'random_subvol' (the particle index fixes the subvolume -- sv_first[s] is the first
-// index of subvolume s's share, :222-246 -- and draws are repeated until one falls into it), occupation = Bose-Einstein
+// particle id (:127-144, at least one particle per mode and subvolume), positions 'random_domain' (one draw of
+// Mesh.sample_volume, Mesh.py:890-904) or 'random_subvol' (the particle's id fixes the subvolume -- sv_first[s] is the first
+// id of subvolume s's share of the WHOLE ensemble, :222-246, so a rank's shard is a part of the single-rank ensemble --
+// and draws are repeated until one falls into it), occupation = Bose-Einstein
 // at the temperature of the subvolume the particle is in (:280).  A particle takes the next free slot of the segment that
 // owns its mode (cursor = seg_count, zeroed before the launch).
 __global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, uint64_t pid_lo, const int32_t *umodes, int32_t nu,
@@ -1250,7 +1251,7 @@ __global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, ui
         const int mode = umodes[pid % (uint64_t)nu];
         const int seg = mode % d.nseg, idx = mode / d.nseg;
         int want = -1;                                // random_subvol: the subvolume this index belongs to
-        if (sv_first) { int lo = 0, hi = d.S; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sv_first[mid] <= i) lo = mid; else hi = mid; } want = lo; }
+        if (sv_first) { int lo = 0, hi = d.S; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sv_first[mid] <= (int64_t)pid) lo = mid; else hi = mid; } want = lo; }
         double x = 0.0, y = 0.0, z = 0.0;
         int s = 0;
         for (uint32_t t = 0; t < 4096u; ++t) {         // (a subvolume holds at least 1 / 4096 of the volume, or keeps the last draw)

@@ -306,14 +306,14 @@ class Population(Constants):
         return getattr(geometry.mesh, 'n_of_simplices', 0) > 0 and hasattr(geometry.mesh, 'simplices_points')
 
     def _subvol_shares(self, geometry):
-        """'random_subvol' (Population.py:222-246): the first particle index of every subvolume's share, ceil(N vol_i / vol)
-        particles each, cut off at N; None for 'random_domain'."""
+        """'random_subvol' (Population.py:222-246): the first particle id of every subvolume's share of the whole ensemble,
+        ceil(N vol_i / vol) particles each, cut off at N (a rank creates the ids of its shard); None for 'random_domain'."""
         if self.args.part_dist[0] != 'random_subvol':
             return None
         vol = np.asarray(geometry.subvol_volume, dtype=float)
-        n = np.ceil(self.N_local * vol / (vol.sum() - vol[self.empty_subvols].sum())).astype(np.int64)
+        n = np.ceil(self.N_total * vol / (vol.sum() - vol[self.empty_subvols].sum())).astype(np.int64)
         n[self.empty_subvols] = 0
-        return np.minimum(np.concatenate(([0], np.cumsum(n))), self.N_local).astype(np.int64)
+        return np.minimum(np.concatenate(([0], np.cumsum(n))), self.N_total).astype(np.int64)
 
     def initialise_modes(self, phonon):
         """Population.py:127-144: tiled unique modes when there is at least one particle per mode and subvolume."""
@@ -535,8 +535,13 @@ class Population(Constants):
         self.N_p = int(self.subvol_N_p.sum())
         ref = phonon.crystal_energy_function(self.subvol_temperature) if self.T_reference == 'local' else self.ref_en_density
         self.total_energy = float(E_raw.sum()) * w
-        self.subvol_energy = self._normalise_energy(phonon, E_raw * w, self.subvol_N_p) + ref
-        self.subvol_heat_flux = self._normalise_flux(phonon, flux_raw * w, self.subvol_N_p)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            self.subvol_energy = self._normalise_energy(phonon, E_raw * w, self.subvol_N_p) + ref
+            self.subvol_heat_flux = self._normalise_flux(phonon, flux_raw * w, self.subvol_N_p)
+        # a rank's shard (consecutive ids) need not reach every subvolume: its t = 0 row has nothing to say about those
+        empty = self.subvol_N_p == 0
+        self.subvol_energy = np.where(empty, ref, self.subvol_energy)
+        self.subvol_heat_flux = np.where(empty[:, None], 0.0, self.subvol_heat_flux)
         self.calculate_kappa(geometry)
 
     # ----------------------------------------------------------------------------- normalisation
