@@ -94,3 +94,32 @@ def test_full_size_properties(cfg, total, monkeypatch):
         census = census + tr['N_sv']
         pr.engine.close()
     assert np.array_equal(em, t['N_emitted']) and np.array_equal(census, t['N_sv'])
+
+
+def test_config4_full_size_balance():
+    """BASELINE config 4 at full size (STL-imported 5000-triangle wire, 1250 rough facets, 5e7 particles): the split sweep
+    with k_events drawing from all queues -- particle balance and census every step, temperatures between the caps',
+    and the same integer tallies from a second engine (rough reflections draw from the particles' ids: deterministic)."""
+    import bench
+    from nanokappa_amd import synthetic
+    from nanokappa_amd.phonon import Phonon
+    from nanokappa_amd.population import Population
+    total, nsteps = 50000000, 8
+    runs = []
+    for _ in range(2):
+        args, geo = bench.wire_geometry(total)
+        args.seed, args.device = [2025], [0]
+        ph = Phonon(args, 0, material=synthetic.make_material(31, 'Si', temperatures=np.arange(200.0, 401.0, 10.0)))
+        pop = bench.quiet(Population, args, geo, ph, None, None)
+        n0 = int(pop.N_p)
+        t = pop.engine.step(nsteps)
+        live = int(pop.engine.timing()['live'])
+        pop.engine.close()
+        N = t['N_sv'].sum(axis=1)
+        assert np.array_equal(N - np.concatenate(([n0], N[:-1])), t['N_emitted'] - t['N_leaving'].sum(axis=1)), 'particle balance'
+        assert int(N[-1]) == live and n0 == total
+        assert np.all(np.isfinite(t['T_sv'])) and t['T_sv'].min() > 290.0 and t['T_sv'].max() < 310.0
+        runs.append(t)
+        del pop, geo, ph
+    for k in ('N_sv', 'N_emitted', 'N_leaving'):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
