@@ -826,7 +826,8 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
 
 // The events of a split sweep (Population.py:1546-1683), at four waves per SIMD: the tree walks are chains of dependent loads.
 #ifndef NK_EVENTS_OCC
-#define NK_EVENTS_OCC 4          // measured on the 5000-triangle wire (ms per step): 2 -> 7.7, 3 -> 7.2, 4 -> 5.9-6.2, 5 -> 6.4, 6 -> 7.1, 8 -> 11.3
+#define NK_EVENTS_OCC 4          // waves per SIMD; the 5000-triangle wire, ms per step, batch form of the kernel: 2 -> 7.7, 3 -> 7.2, 4 -> 5.9-6.2,
+                                 // 5 -> 6.4, 6 -> 7.1, 8 -> 11.3; the state-machine form below: 3 -> 7.7, 4 -> 6.0 (before its other changes)
 #endif
 // (Tried on the 5000-triangle wire and dropped: one workgroup of 1024 threads per CU that stages the face tree's boxes in LDS
 // -- 6.00 against 6.03 ms per step; the walk's box reads are not what the events wait for.)
