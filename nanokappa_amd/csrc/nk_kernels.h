@@ -589,6 +589,9 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 // (coalesced, one extra round trip for those particles) and k_events runs the events, whose tree walks are chains of
 // dependent loads, at twice the residency; the fused form keeps the events in registers (boxes: a third of the particles
 // have one every step, a second trip through HBM would cost more than the residency gains).
+#ifndef NK_SWEEP_OCC_BIG
+#define NK_SWEEP_OCC_BIG 2      // the variants with rough facets, RBF temperatures or large meshes (more than 168 VGPRs)
+#endif
 #ifndef NK_SWEEP_OCC_SPLIT
 #define NK_SWEEP_OCC_SPLIT 4
 #endif
@@ -596,7 +599,7 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 // particle temperatures, local reference temperature: the run-time switches become constants of a copy of the parameter
 // block (worth 2-3 % of the sweep: fewer instructions in every classification, interpolation and tally).
 template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC, int FAST = 0>
-__global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || ROUGH || RBF) ? 2 : NK_SWEEP_OCC)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
+__global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || ROUGH || RBF) ? NK_SWEEP_OCC_BIG : NK_SWEEP_OCC)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
     if (FAST) { d.sv_kind = 0; d.sv_interp = FAST - 1; d.T_ref_local = 1; }
