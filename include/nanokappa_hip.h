@@ -161,6 +161,12 @@ typedef struct {
 
 /* lifetime: `Population.__init__` / end of run */
 int nk_device_count(void);                            /* HIP devices this process sees (0 if none) */
+/* Set-up helper of the host geometry (no context): for every ray o + t d, t > 0 the number of triangles (v0, e1 = v1 - v0,
+ * e2 = v2 - v0; arrays [n*3]) it crosses, crossings at the same distance (to 1e-8) counted once; skip_self: ray i ignores
+ * triangle i.  The inside tests of nanokappa_amd.mesh (role of trimesh's ray queries in the reference's Mesh.py) run this on
+ * large meshes; counts[i] = -1 where a ray has more than 24 distinct crossings (the caller counts that ray itself). */
+int nk_mesh_crossings(int device, int64_t n_rays, const double *origins, const double *dirs, int64_t n_faces, const double *v0,
+                      const double *e1, const double *e2, int skip_self, int32_t *counts);
 int nk_create(nk_ctx **out, int device_id, uint64_t seed);
 void nk_destroy(nk_ctx *ctx);
 const char *nk_last_error(const nk_ctx *ctx);        /* ctx may be NULL: error of a failed nk_create */

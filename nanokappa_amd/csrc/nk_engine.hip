@@ -1309,6 +1309,31 @@ static int nk_check_ready(nk_ctx *ctx) {
     return NK_OK;
 }
 
+// Mesh._count_crossings of the host geometry on a device (no context needed): see k_mesh_crossings.
+int nk_mesh_crossings(int device, int64_t n_rays, const double *origins, const double *dirs, int64_t n_faces, const double *v0,
+                      const double *e1, const double *e2, int skip_self, int32_t *counts) {
+    if (n_rays <= 0 || n_faces <= 0 || !origins || !dirs || !v0 || !e1 || !e2 || !counts) return NK_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return NK_ERR_HIP;
+    double *buf = nullptr;
+    int32_t *dc = nullptr;
+    const size_t nr = (size_t)n_rays * 3, nf = (size_t)n_faces * 3;
+    if (hipMalloc((void **)&buf, (2 * nr + 3 * nf) * sizeof(double)) != hipSuccess) return NK_ERR_HIP;
+    if (hipMalloc((void **)&dc, (size_t)n_rays * sizeof(int32_t)) != hipSuccess) { hipFree(buf); return NK_ERR_HIP; }
+    double *po = buf, *pd = po + nr, *p0 = pd + nr, *p1 = p0 + nf, *p2 = p1 + nf;
+    hipError_t e = hipMemcpy(po, origins, nr * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(pd, dirs, nr * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p0, v0, nf * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p1, e1, nf * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(p2, e2, nf * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        k_mesh_crossings<<<(int)((n_rays + NK_WG - 1) / NK_WG), NK_WG>>>(n_rays, po, pd, n_faces, p0, p1, p2, skip_self, dc);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(counts, dc, (size_t)n_rays * sizeof(int32_t), hipMemcpyDeviceToHost);
+    hipFree(buf); hipFree(dc);
+    return e == hipSuccess ? NK_OK : NK_ERR_HIP;
+}
+
 int nk_init_boundaries(nk_ctx *ctx) {
     NK_ARG(ctx, "nk_init_boundaries: NULL context");
     int rc = nk_check_ready(ctx);

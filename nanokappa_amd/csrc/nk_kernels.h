@@ -1237,6 +1237,56 @@ __device__ __forceinline__ uint64_t nk_state_key(int mode, double x, double y, d
     return k;
 }
 
+// Set-up helper of the host geometry (nanokappa_amd/mesh.py, Mesh._count_crossings: inside tests by ray parity for the
+// outward orientation of the faces, the tetrahedra of the volume sampler and the Monte-Carlo subvolume volumes; the role of
+// trimesh's ray queries in the reference's Mesh.py): triangles crossed by the open rays o + t d, t > 0, all pairs,
+// Moller-Trumbore written out by components in the host's order of operations (no fused multiply-add), crossings at the
+// same distance (rounded to 1e-8: a ray through a shared edge or vertex) counted once.  One thread per ray, the triangles
+// pass through LDS in tiles.  A ray with more than NK_XMAX distinct crossings gets -1 (the host counts that one itself).
+#define NK_XMAX 24
+__global__ __launch_bounds__(NK_WG) void k_mesh_crossings(int64_t n, const double *orig, const double *dir, int64_t F, const double *v0,
+                                                          const double *e1, const double *e2, int skip_self, int32_t *counts) {
+#pragma clang fp contract(off)
+    __shared__ double tile[NK_WG * 9];
+    const int64_t r = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
+    const bool act = r < n;
+    double ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 1;
+    if (act) { ox = orig[3 * r]; oy = orig[3 * r + 1]; oz = orig[3 * r + 2]; dx = dir[3 * r]; dy = dir[3 * r + 1]; dz = dir[3 * r + 2]; }
+    double seen[NK_XMAX];
+    int ns = 0;
+    bool over = false;
+    const double eps = 1e-9;
+    for (int64_t f0 = 0; f0 < F; f0 += NK_WG) {
+        __syncthreads();
+        const int64_t tf = f0 + threadIdx.x;
+        if (tf < F)
+            for (int c = 0; c < 3; ++c) { tile[9 * threadIdx.x + c] = v0[3 * tf + c]; tile[9 * threadIdx.x + 3 + c] = e1[3 * tf + c]; tile[9 * threadIdx.x + 6 + c] = e2[3 * tf + c]; }
+        __syncthreads();
+        const int nt = F - f0 < NK_WG ? (int)(F - f0) : NK_WG;
+        if (!act) continue;
+        for (int i = 0; i < nt; ++i) {
+            const double *q = tile + 9 * i;
+            const double e1x = q[3], e1y = q[4], e1z = q[5], e2x = q[6], e2y = q[7], e2z = q[8];
+            const double px = dy * e2z - dz * e2y, py = dz * e2x - dx * e2z, pz = dx * e2y - dy * e2x;      // p = d x e2
+            const double det = e1x * px + e1y * py + e1z * pz;
+            const double tx = ox - q[0], ty = oy - q[1], tz = oz - q[2];
+            const double inv = 1.0 / det;
+            const double u = (tx * px + ty * py + tz * pz) * inv;
+            const double qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;      // q = tv x e1
+            const double w = (dx * qx + dy * qy + dz * qz) * inv;
+            const double t = (e2x * qx + e2y * qy + e2z * qz) * inv;
+            const bool ok = (fabs(det) > 1e-14) && (u >= -eps) && (w >= -eps) && (u + w <= 1 + eps) && (t > 1e-9);
+            if (!ok || (skip_self && f0 + i == r)) continue;
+            const double tr = rint(t * 1e8) / 1e8;                                       // np.round(t, 8)
+            bool dup = false;
+            for (int k = 0; k < ns; ++k) dup |= seen[k] == tr;
+            if (dup) continue;
+            if (ns < NK_XMAX) seen[ns++] = tr; else over = true;
+        }
+    }
+    if (act) counts[r] = over ? -1 : ns;
+}
+
 // Population.initialise_all_particles on the device (Population.py:186-321) for the common case: modes tiled over the
 // particle id (:127-144, at least one particle per mode and subvolume), positions 'random_domain' (one draw of
 // Mesh.sample_volume, Mesh.py:890-904) or 'random_subvol' (the particle's id fixes the subvolume -- sv_first[s] is the first

@@ -79,7 +79,7 @@ EXPORTS = ['nk_device_count', 'nk_create', 'nk_destroy', 'nk_last_error', 'nk_se
            'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2', 'nk_calibrate_stream',
            'nk_specular_begin', 'nk_specular_pairs', 'nk_specular_end', 'nk_rough_begin', 'nk_rough_pairs', 'nk_rough_finish',
            'nk_rough_download', 'nk_build_enter_prob', 'nk_init_particles', 'nk_tally_state', 'nk_kspec_begin', 'nk_kspec_pairs',
-           'nk_rough_finish_k']
+           'nk_rough_finish_k', 'nk_mesh_crossings']
 
 _lib = None
 
@@ -107,6 +107,7 @@ def load_library():
     L.nk_init_boundaries.argtypes = [C.c_void_p]
     L.nk_init_particles.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_uint64, c_ip, C.c_int64, C.POINTER(C.c_int64)]
     L.nk_tally_state.argtypes = [C.c_void_p, c_dp, c_dp, c_dp]
+    L.nk_mesh_crossings.argtypes = [C.c_int, C.c_int64, c_dp, c_dp, C.c_int64, c_dp, c_dp, c_dp, C.c_int, c_ip]
     L.nk_step.argtypes = [C.c_void_p, C.c_int32, C.POINTER(nk_tally)]
     L.nk_download_particles.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_ip, c_dp, c_dp, c_ip, c_u64p,
                                         C.POINTER(C.c_int64)]
@@ -160,6 +161,18 @@ def bc_codes(bound_cond):
 def device_count():
     """HIP devices this process sees."""
     return int(load_library().nk_device_count())
+
+
+def mesh_crossings(origins, dirs, v0, e1, e2, skip_self=False, device=0):
+    """Triangles crossed by every open ray (nk_mesh_crossings; -1 where a ray has too many distinct crossings)."""
+    L = load_library()
+    o, d = _d(origins), _d(dirs)
+    a, b, c = _d(v0), _d(e1), _d(e2)
+    out = np.zeros(o.shape[0], dtype=np.int32)
+    rc = L.nk_mesh_crossings(int(device), o.shape[0], _p(o), _p(d), a.shape[0], _p(a), _p(b), _p(c), int(bool(skip_self)), _p(out, c_ip))
+    if rc != 0:
+        raise RuntimeError('nk_mesh_crossings failed (%d)' % rc)
+    return out
 
 
 def comm_unique_id():

@@ -8,6 +8,25 @@ triangulation filtered by an inside test.
 import numpy as np
 
 
+_DEVICE_HELPER = None
+
+
+def _device_helper():
+    """Is there a GPU (and the library) for the set-up helper nk_mesh_crossings?  NK_HOST_MESH=1 keeps everything in NumPy."""
+    global _DEVICE_HELPER
+    if _DEVICE_HELPER is None:
+        import os
+        ok = False
+        if not os.environ.get('NK_HOST_MESH'):
+            try:
+                from . import engine
+                ok = engine.device_count() > 0
+            except Exception:
+                ok = False
+        _DEVICE_HELPER = ok
+    return _DEVICE_HELPER
+
+
 class Mesh(object):
     def __init__(self, vertices, faces, tol=1e-10):
         vertices = np.asarray(vertices, dtype=float)
@@ -54,8 +73,23 @@ class Mesh(object):
         by components: (rays, faces) planes instead of (rays, faces, 3) temporaries)."""
         v = self.vertices[self.faces]
         v0, e1, e2 = v[:, 0], v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+        own = np.arange(origins.shape[0]) if skip_self else None            # ray i ignores face i
+        if origins.shape[0] * v.shape[0] >= 4e6 and _device_helper():
+            # large meshes: the same all-pairs test as a kernel (nk_mesh_crossings, same order of operations); the few rays
+            # it gives up on (more distinct crossings than it keeps) take the NumPy form
+            from .engine import mesh_crossings
+            counts = mesh_crossings(origins, dirs, v0, e1, e2, skip_self).astype(int)
+            redo = np.nonzero(counts < 0)[0]
+            if redo.size:
+                counts[redo] = self._count_crossings_host(origins[redo], dirs[redo], v0, e1, e2, None if own is None else own[redo])
+            return counts
+        return self._count_crossings_host(origins, dirs, v0, e1, e2, own)
+
+    @staticmethod
+    def _count_crossings_host(origins, dirs, v0, e1, e2, own=None):
+        """The NumPy form; own[i]: the face ray i ignores (None: none)."""
         counts = np.zeros(origins.shape[0], dtype=int)
-        step = max(1, int(2e6 // max(1, v.shape[0])))
+        step = max(1, int(2e6 // max(1, v0.shape[0])))
         e1x, e1y, e1z = e1[:, 0][None], e1[:, 1][None], e1[:, 2][None]
         e2x, e2y, e2z = e2[:, 0][None], e2[:, 1][None], e2[:, 2][None]
         for s in range(0, origins.shape[0], step):
@@ -74,8 +108,8 @@ class Mesh(object):
             eps = 1e-9
             with np.errstate(invalid='ignore'):
                 ok = (np.abs(det) > 1e-14) & (u >= -eps) & (w >= -eps) & (u + w <= 1 + eps) & (t > 1e-9)
-            if skip_self:
-                idx = np.arange(s, min(s + step, origins.shape[0]))
+            if own is not None:
+                idx = own[s:s + step]
                 ok[np.arange(idx.shape[0]), idx] = False
             # a ray through a shared edge/vertex would be counted once per triangle: merge equal distances
             rows, cols = np.nonzero(ok)

@@ -156,3 +156,45 @@ def test_stl_wire_5000_faces_vs_oracle():
     eng = make_engine(ct, pos, mode, occ, counter, seed=99)
     steps_agree(eng, sim, 10)
     compare_by_pid(eng.download(), sim)
+
+
+def test_mesh_crossings_on_the_device_equal_the_host_count(monkeypatch):
+    """Set-up helper nk_mesh_crossings (ray-parity inside tests of nanokappa_amd.mesh on large meshes) against the NumPy
+    all-pairs count it replaces: random rays through the 5000-triangle wire, rays along mesh edges and vertices (equal
+    distances counted once), and the faces' own centroid rays of the orientation pass (ray i ignores face i); then the
+    whole geometry built both ways has the same orientation, tetrahedra and volume."""
+    import nanokappa_amd.mesh as M
+    from nanokappa_amd.mesh import Mesh
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+
+    def wire_mesh():
+        a = initialise_parser().parse_args(['--geometry', 'cylinder', '--dimensions', '2000', '200', '1250', '--subvolumes', 'slice', '20', '2',
+                                            '--bound_pos', 'relative', '0.5', '0.5', '0', '0.5', '0.5', '1', '--bound_cond', 'T', 'T', 'R',
+                                            '--bound_values', '302', '298', '5', '--poscar_file', 'POSCAR', '--hdf_file', 'synthetic',
+                                            '--particles', 'total', '1000'])
+        a.results_folder = ''
+        return Geometry(a).mesh
+
+    monkeypatch.setattr(M, '_DEVICE_HELPER', None)
+    mesh = wire_mesh()
+    assert M._device_helper() and mesh.faces.shape[0] == 5000
+    v = mesh.vertices[mesh.faces]
+    v0, e1, e2 = v[:, 0], v[:, 1] - v[:, 0], v[:, 2] - v[:, 0]
+    rng = np.random.default_rng(4)
+    lo, hi = mesh.bounds[0], mesh.bounds[1]
+    o = lo + (hi - lo) * (rng.random((3000, 3)) * 1.4 - 0.2)
+    d = rng.normal(size=(3000, 3))
+    # some rays aimed exactly at vertices and edge midpoints of the mesh
+    tgt = np.vstack((mesh.vertices[rng.integers(0, mesh.vertices.shape[0], 300)], (v[:300, 0] + v[:300, 1]) / 2))
+    d[:600] = tgt - o[:600]
+    host = Mesh._count_crossings_host(o, d, v0, e1, e2)
+    dev = mesh._count_crossings(o, d)
+    assert np.array_equal(host, dev) and host.max() >= 2
+    cen, nrm = v.mean(axis=1), mesh.face_normals
+    own = np.arange(cen.shape[0])
+    assert np.array_equal(Mesh._count_crossings_host(cen, nrm, v0, e1, e2, own), mesh._count_crossings(cen, nrm, skip_self=True))
+    # the geometry as a whole, built with and without the helper
+    monkeypatch.setattr(M, '_DEVICE_HELPER', False)
+    ref = wire_mesh()
+    assert np.array_equal(ref.faces, mesh.faces) and np.array_equal(ref.simplices, mesh.simplices) and ref.volume == mesh.volume
