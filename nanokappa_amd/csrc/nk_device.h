@@ -151,6 +151,8 @@ struct NkDev {
     int32_t part;                     // 1: idx is the local index of a mode of the owning segment; 0: the global mode index
     int32_t lb;                       // bits of idx in w0
     int32_t nlmax;                    // modes per segment, rounded up: ceil(M / nseg)
+    int32_t nlrec;                    // mode records a sweep wave keeps in LDS (= nlmax when the sweep reads its segments' records
+                                      // from LDS, else 0)
     // ---- bookkeeping words in device memory
     int32_t *ticket;                  // arrival counter of k_reduce's workgroups (the last one runs the update)
     int32_t *overflow;                // set when a particle had to be dropped for lack of capacity

@@ -40,6 +40,7 @@ struct nk_ctx {
     std::vector<int32_t> h_seg_count;
     std::vector<hipEvent_t> evpool;
     int g_sweep_key = -1;              // which k_sweep instantiation g_sweep was sized for
+    size_t g_sweep_lds = 0;            //   and with how much LDS per workgroup
     int layout_key = -1;               // how the particle store was laid out: 1 modes partitioned | 2 ids tracked
     std::vector<double> h_enter_prob;  // host copy of enter_prob (sizes the segments' head room)
     // set-up table builder state (nk_specular_*)
@@ -116,10 +117,11 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 // 1 = ray-casting tables fit LDS, 2 = they stay in global memory
 static inline int nk_geom_mode(const nk_ctx *ctx) { return (ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES) ? 1 : 2; }
 // kind: 0 plain, 1 k_emit (emission scratch), 2 / 3 k_sweep (mode records, output ring without / with ids)
+static inline bool nk_want_split(const nk_ctx *ctx);
 static inline size_t nk_lds(const nk_ctx *ctx, bool geom, int kind = 0) {
     const NkDev &d = ctx->d;
     const int gm = geom ? nk_geom_mode(ctx) : 0;
-    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, kind, (gm == 1 && d.res_lds) ? d.res_nf : 0, d.rbf_P);
+    return nk_lds_bytes(d.S, d.R, d.F, d.NP, d.Fc, gm, kind, (gm == 1 && d.res_lds) ? d.res_nf : 0, d.rbf_P, d.nlrec, nk_want_split(ctx) ? 0 : 1);
 }
 #define NK_GEOM_LAUNCH(kernel, grid, lds, ...)                                                        \
     do {                                                                                               \
@@ -1040,8 +1042,8 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx), split_ = nk_want_split(ctx);
     const bool lrec_ = nk_want_lrec(ctx);
     const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4) | (split_ << 5) | (lrec_ << 6) | (nk_sweep_fast(ctx) << 7);
-    if (ctx->g_sweep == 0 || ctx->g_sweep_key != key) {
-        const size_t lds_w = nk_lds(ctx, true, pid_ ? 3 : 2);
+    const size_t lds_w = nk_lds(ctx, true, pid_ ? 3 : 2);
+    if (ctx->g_sweep == 0 || ctx->g_sweep_key != key || ctx->g_sweep_lds != lds_w) {
         int per_cu = 0;
         hipError_t e_ = hipSuccess;
         NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, lrec_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
@@ -1050,6 +1052,7 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
         if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
         ctx->g_sweep = ctx->num_cu * per_cu;
         ctx->g_sweep_key = key;
+        ctx->g_sweep_lds = lds_w;
         if (getenv("NK_VERBOSE")) fprintf(stderr, "[nanokappa_hip] sweep: %d workgroups per CU (occupancy query rc %d), %zu B LDS each\n", per_cu, (int)e_, lds_w);
     }
     return ctx->g_sweep;
@@ -1086,14 +1089,24 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     // a whole number per wave keeps the waves level).  Small ensembles: more, shorter segments, down to 128 slots, until
     // every resident wave has one -- a wave's serial chain (tiles, event passes, entering particles) is what a small
     // sweep waits for.
-    int64_t nseg = capacity / 128;
-    const int64_t waves = (int64_t)nk_sweep_blocks(ctx) * (NK_WG / 64);
-    if (const char *e = getenv("NK_SEGMENTS")) nseg = atoi(e) > 0 ? atoi(e) : nseg;          // developer probe
-    else if (nseg >= waves) nseg = waves;
-    nseg = nseg < 64 ? 64 : (nseg > NK_MAX_SEGMENTS ? NK_MAX_SEGMENTS : nseg);
     d.part = nk_want_part(ctx) ? 1 : 0;
-    d.nseg = (int32_t)nseg;
-    d.nlmax = d.M > 0 ? (int32_t)((d.M + nseg - 1) / nseg) : 1;
+    d.nlrec = 0;
+    int64_t nseg = 0;
+    // the sweep's LDS (hence its residency, hence the segment count) depends on the record area, which depends on the segment
+    // count: settle in a few rounds
+    for (int round = 0; round < 4; ++round) {
+        const int64_t waves = (int64_t)nk_sweep_blocks(ctx) * (NK_WG / 64);
+        int64_t ns = capacity / 128;
+        if (const char *e = getenv("NK_SEGMENTS")) ns = atoi(e) > 0 ? atoi(e) : ns;          // developer probe
+        else if (ns >= waves) ns = waves;
+        ns = ns < 64 ? 64 : (ns > NK_MAX_SEGMENTS ? NK_MAX_SEGMENTS : ns);
+        const bool same = ns == nseg;
+        nseg = ns;
+        d.nseg = (int32_t)nseg;
+        d.nlmax = d.M > 0 ? (int32_t)((d.M + nseg - 1) / nseg) : 1;
+        d.nlrec = nk_want_lrec(ctx) ? d.nlmax : 0;
+        if (same) break;
+    }
     NK_ARG(d.nlmax < (1 << 14), "too many modes per segment for k_emit's packed entry word: use more particles (segments) or fewer modes");
     {   // bits of the stored mode index; the rest of the 32-bit word holds facet + 1
         const int64_t maxidx = d.part ? d.nlmax - 1 : (d.M > 0 ? d.M - 1 : 0);

@@ -73,8 +73,10 @@ struct NkLds {
     // emission scratch of k_emit, one slice of NK_EMIT_CHUNK entries per wave
     unsigned int *sp_pref, *sp_cnt, *sp_rm;
     double *sp_cv, *sp_pr;
-    // mode records of the sweep's segments, NK_LREC per wave (16-byte aligned)
+    // mode records of the sweep's segments, d.nlrec per wave (16-byte aligned)
     double *lrec;
+    // the sweep's carry: up to 64 parked particles per wave (NkCarryLds)
+    double *carry;
     // output ring of the sweep, NK_ORING particles per wave: x y z occ nts [pid] (doubles), then w0
     double *oring;
     unsigned int *oring_w;
@@ -82,7 +84,7 @@ struct NkLds {
 
 // geom: 0 = no ray-casting tables, 1 = planes/faces/facets staged in LDS, 2 = read from global memory (large meshes)
 // nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged); kind: 0 plain, 1 + k_emit's scratch,
-// 2 + the sweep's mode records and output ring, 3 the same with particle ids
+// 2 + the sweep's mode records (nlrec per wave), carry (unless the sweep is split) and output ring, 3 the same with particle ids
 #ifndef NK_LREC_STRIDE
 #define NK_LREC_STRIDE 5     // 16-byte units between the LDS copies of two mode records: 4 = packed (64 B), 5 spreads the banks
 #endif
@@ -90,14 +92,16 @@ struct NkLds {
 #define NK_OUT_RING 0        // 1: finished particles go through an LDS ring and leave in whole aligned tiles (NkOut below)
 #endif
 #define NK_ORING (NK_OUT_RING ? 128 : 0)
-__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, int kind, int nrf, int rbfP) {
+// doubles of one wave's carry: x y z occ nts cts (64 each), w0 + evc (64 words each); with ids: + pid (64), gm (64 words)
+#define NK_CARRY_DOUBLES(kind) ((kind) == 3 ? 544 : 448)
+__host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, int kind, int nrf, int rbfP, int nlrec = 0, int carry = 0) {
     const bool emit = kind == 1;
     int Fl = geom == 1 ? F : 0;
     int Pl = Fl ? NP : 0;
     int Fcl = geom == 1 ? Fc : 0;
     size_t nd = (size_t)S + (size_t)((rbfP + 1) & ~1) + 3 * S + ((3 * S) & 1) + 4 * (size_t)S + NK_NREP * S + NK_NREP * 3 * S + 4 * R +
                 (size_t)Fl * NK_FACE_DOUBLES + (size_t)Pl * NK_PLANE_DOUBLES + 2 * (size_t)R + 10 * (size_t)nrf +
-                (emit ? 2 * (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (size_t)(NK_WG / 64) * (NK_LREC * 2 * NK_LREC_STRIDE + NK_ORING * (kind == 3 ? 6 : 5)) : 0) + 4;
+                (emit ? 2 * (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (size_t)(NK_WG / 64) * ((size_t)nlrec * 2 * NK_LREC_STRIDE + (carry ? NK_CARRY_DOUBLES(kind) : 0) + NK_ORING * (kind == 3 ? 6 : 5)) : 0) + 4;
     size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) +
                    (size_t)(NK_NREP * S + R + 1 + (R + 1) + (emit ? 3 * (NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (NK_WG / 64) * NK_ORING : 0)) * 4 + 32;
     return (bytes + 15) & ~(size_t)15;
@@ -130,9 +134,10 @@ __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem
     if (EMIT) { L.sp_cv = p; p += (NK_WG / 64) * NK_EMIT_CHUNK; L.sp_pr = p; p += (NK_WG / 64) * NK_EMIT_CHUNK; } else L.sp_cv = L.sp_pr = nullptr;
     p += ((size_t)(p - (double *)smem) & 1);           // keep the records and the facet table 16-byte aligned
     if (KIND >= 2) {
-        L.lrec = p; p += (NK_WG / 64) * NK_LREC * 2 * NK_LREC_STRIDE;
+        L.lrec = p; p += (NK_WG / 64) * (size_t)d.nlrec * 2 * NK_LREC_STRIDE;
+        L.carry = p; p += d.qx ? 0 : (NK_WG / 64) * NK_CARRY_DOUBLES(KIND);
         L.oring = p; p += (NK_WG / 64) * NK_ORING * (KIND == 3 ? 6 : 5);
-    } else { L.lrec = nullptr; L.oring = nullptr; }
+    } else { L.lrec = nullptr; L.carry = nullptr; L.oring = nullptr; }
     NkFacet *facets = (NkFacet *)p;
     unsigned int *u = (unsigned int *)(facets + Fcl);
     L.bins.N = u; u += NK_NREP * S;
@@ -610,7 +615,11 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
     const int rep = lane & (NK_NREP - 1);
     const unsigned long long lower = (1ull << lane) - 1ull;
     const uint32_t lbmask = (1u << d.lb) - 1u;
-    double2 *lrec = reinterpret_cast<double2 *>(L.lrec) + wave * NK_LREC * NK_LREC_STRIDE;
+    double2 *lrec = reinterpret_cast<double2 *>(L.lrec) + wave * d.nlrec * NK_LREC_STRIDE;
+    // the wave's carry in LDS: x y z occ nts cts [64] each, then (ids) pid [64], then the words w0, evc and (ids) gm [64] each
+    double *const cX = L.carry ? L.carry + wave * NK_CARRY_DOUBLES(PID ? 3 : 2) : nullptr;
+    double *const cP = cX + 6 * 64;
+    uint32_t *const cW = reinterpret_cast<uint32_t *>(cX + (PID ? 7 : 6) * 64);
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
@@ -633,8 +642,6 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
         O.init(L, wave);
         int qn = 0;                                   // SPLIT: entries in the segment's event queue
         int cn = 0;                                   // particles in the carry (lanes [0, cn))
-        NkCarry<PID, ROUGH> C;
-        C.x = C.y = C.z = C.occ = C.nts = C.cts = 0.0; C.w0 = 0u; C.evc = 0u; C.gm = 0u; C.pid = 0ull;
 #ifdef NK_STAMPS
         unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
@@ -708,50 +715,44 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 qn += __popcll(mE);
                 continue;
             }
-            // the tile's event particles, packed into lanes [po, po + pn) of P
-            int pn = __popcll(mE), po = 0;
-            NkCarry<PID, ROUGH> P;
-            P.x = x; P.y = y; P.z = z; P.occ = occ; P.nts = nts; P.cts = 0.0; P.w0 = w0; P.evc = 0u; P.pid = pid;
-            P.gm = (uint32_t)((int)(w0 & lbmask) * sm.mstride + sm.moff);
-            if (pn > 0) P = P.push(ev ? __popcll(mE & lower) : pn + __popcll(~mE & lower));
-            // ---- drain (Population.py:1546-1683): fill the carry; whenever it is full (or on the last, empty tile) one
-            // boundary event per particle; finished particles are tallied and appended, absorbed ones vanish, the few that
-            // meet another wall stay
-            while (pn > 0 || (flush && cn > 0)) {
-                if (pn > 0) {
-                    const int k = pn < 64 - cn ? pn : 64 - cn;
-                    const NkCarry<PID, ROUGH> Q = P.pull((po + lane - cn) & 63);
-                    if (lane >= cn && lane < cn + k) C = Q;
-                    cn += k; po += k; pn -= k;
+            // ---- drain (Population.py:1546-1683): the tile's event particles are parked in the wave's carry (LDS); whenever it
+            // holds 64 (or on the last, empty tile) the whole wave runs one boundary event per particle; finished particles
+            // are tallied and appended, absorbed ones vanish, the few that meet another wall go back into the carry
+            const int pn = __popcll(mE), erank = __popcll(mE & lower);
+            int taken = 0;                            // event particles of this tile already parked
+            while (taken < pn || (flush && cn > 0)) {
+                if (taken < pn) {
+                    const int k = pn - taken < 64 - cn ? pn - taken : 64 - cn;
+                    if (ev && erank >= taken && erank < taken + k) {
+                        const int sl = cn + erank - taken;
+                        cX[sl] = x; cX[64 + sl] = y; cX[128 + sl] = z; cX[192 + sl] = occ; cX[256 + sl] = nts; cX[320 + sl] = 0.0;
+                        cW[sl] = w0; cW[64 + sl] = 0u;
+                        if (PID) { cP[sl] = __longlong_as_double((long long)pid); cW[128 + sl] = (uint32_t)((int)(w0 & lbmask) * sm.mstride + sm.moff); }
+                    }
+                    cn += k; taken += k;
                 }
-                if (cn < 64 && !(flush && pn == 0)) break;
+                if (cn < 64 && !(flush && taken == pn)) break;
                 NK_STAMP(3);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 const bool eact = lane < cn;
                 NkParticle p;
-                double cts = C.cts;
-                uint32_t evc = C.evc;
+                double cts = 0.0;
+                uint32_t evc = 0u, cw0 = 0u, cgm = 0u;
+                unsigned long long cpid = 0ull;
                 int st = NK_EV_DEAD;
-                p.x = C.x; p.y = C.y; p.z = C.z; p.occ = C.occ; p.nts = C.nts;
-                const int idx0 = eact ? (int)(C.w0 & lbmask) : 0;
+                p.x = p.y = p.z = p.occ = p.nts = 0.0;
+                if (eact) {
+                    p.x = cX[lane]; p.y = cX[64 + lane]; p.z = cX[128 + lane]; p.occ = cX[192 + lane]; p.nts = cX[256 + lane]; cts = cX[320 + lane];
+                    cw0 = cW[lane]; evc = cW[64 + lane];
+                    if (PID) { cpid = (unsigned long long)__double_as_longlong(cP[lane]); cgm = cW[128 + lane]; }
+                }
+                const int idx0 = eact ? (int)(cw0 & lbmask) : 0;
                 if (ROUGH) {                              // the carried particle may be in a mode another segment owns
-                    p.mode = eact ? (int)C.gm : sm.moff;
-                    const uint32_t q = (uint32_t)p.mode / (uint32_t)sm.mstride;
-#ifndef NK_PASS_LDS_REC          // (records from LDS for the lanes whose mode is ours: measured SLOWER, 0.69 against 0.54 ms on the rough box)
-                    if (false) {
-#else
-                    if (use_lrec && (int)((uint32_t)p.mode - q * (uint32_t)sm.mstride) == sm.moff) {
-#endif
-                        const NkLdsRec lq = nk_lds_rec(lrec + q * NK_LREC_STRIDE);
-                        const nk_v2d l0 = lq[0], l1 = lq[1];
-                        const double4 ra = make_double4(l0.x, l0.y, l1.x, l1.y);
-                        p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
-                        p.E0 = lq[2].x;
-                    } else {
-                        const NkMode *rec = d.modetab + p.mode;
-                        const double4 ra = *reinterpret_cast<const double4 *>(rec);
-                        p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
-                        p.E0 = rec->E0;
-                    }
+                    p.mode = eact ? (int)cgm : sm.moff;
+                    const NkMode *rec = d.modetab + p.mode;
+                    const double4 ra = *reinterpret_cast<const double4 *>(rec);
+                    p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
+                    p.E0 = rec->E0;
                 } else {
                     if (use_lrec) {
                         const NkLdsRec lq = nk_lds_rec(lrec + idx0 * NK_LREC_STRIDE);
@@ -766,8 +767,8 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                     }
                     p.mode = idx0 * sm.mstride + sm.moff;
                 }
-                p.facet = (int)(C.w0 >> d.lb) - 1;
-                if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, C.pid, step);
+                p.facet = (int)(cw0 >> d.lb) - 1;
+                if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, cpid, step);
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
 #ifdef NK_STAMPS
                 { const double fence_ = p.x + p.nts; asm volatile("" ::"v"(fence_)); }
@@ -784,23 +785,25 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
                 const bool home = alive && stay, away = alive && !stay;
                 const unsigned long long mA = __ballot(home), mM = __ballot(more);
-                O.push(d, base, lane, home, __popcll(mA & lower), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0e, C.pid);
+                O.push(d, base, lane, home, __popcll(mA & lower), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0e, cpid);
                 if (ROUGH && away) {                       // one 64-byte record into the inbox of the segment that owns the new mode
                     const int dst = (int)((uint32_t)p.mode - idxe * (uint32_t)d.nseg);
                     const int at = atomicAdd(d.mig_n + dst, 1);
                     if (at < d.mig_cap) {
                         double2 *r = d.mig_buf + ((int64_t)dst * d.mig_cap + at) * 4;
                         r[0] = make_double2(p.x, p.y); r[1] = make_double2(p.z, p.occ);
-                        r[2] = make_double2(p.nts, __longlong_as_double((long long)C.pid));
+                        r[2] = make_double2(p.nts, __longlong_as_double((long long)cpid));
                         r[3] = make_double2(__longlong_as_double((long long)w0e), 0.0);
                     } else atomicOr(d.overflow, 32);      // inbox full: the particle is lost (k_deliver asks for larger inboxes long before)
                 }
                 cn = __popcll(mM);
-                if (cn > 0) {
-                    C.x = p.x; C.y = p.y; C.z = p.z; C.occ = p.occ; C.nts = p.nts; C.cts = cts; C.w0 = w0e; C.evc = evc;
-                    C.gm = (uint32_t)p.mode;
-                    C = C.push(more ? __popcll(mM & lower) : cn + __popcll(~mM & lower));
+                if (more) {                               // back into the carry, packed (every entry was read above: slots <= lane)
+                    const int sl = __popcll(mM & lower);
+                    cX[sl] = p.x; cX[64 + sl] = p.y; cX[128 + sl] = p.z; cX[192 + sl] = p.occ; cX[256 + sl] = p.nts; cX[320 + sl] = cts;
+                    cW[sl] = w0e; cW[64 + sl] = evc;
+                    if (PID) { cP[sl] = __longlong_as_double((long long)cpid); cW[128 + sl] = (uint32_t)p.mode; }
                 }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 NK_STAMP(5);
             }
             NK_STAMP(3);
