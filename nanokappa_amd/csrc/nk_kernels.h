@@ -22,10 +22,11 @@
 //
 // The sweep (history: DESIGN.md):
 //   * a WAVE owns a segment and walks it tile by tile (64 particles, coalesced loads, next tile prefetched);
-//   * particles that meet a boundary inside the step (a third of them in a 20 nm box) are moved, with cross-lane
-//     permutes, into a second set of REGISTERS (the carry: up to 63 parked particles, packed in the low lanes); whenever
-//     64 are there the whole wave runs one boundary event per particle with all lanes busy; the few that meet another
-//     wall stay in the carry.  No LDS buffer, no second trip through HBM, no divergence against the streaming lanes;
+//   * particles that meet a boundary inside the step (a third of them in a 20 nm box) are parked in the wave's carry, 64
+//     slots in LDS; whenever 64 are there the whole wave runs one boundary event per particle with all lanes busy; the few
+//     that meet another wall go back into the carry.  No second trip through HBM, no divergence against the streaming
+//     lanes.  (The carry was a second set of registers filled by cross-lane permutes first: 26-40 permutes per tile and
+//     15 registers live across the tile loop; in LDS it is 8 writes per tile and 8 reads per pass.)
 //   * survivors are written back compacted IN PLACE (write cursor <= read cursor), absorbed particles simply vanish;
 //   * the modes a segment owns (nk_device.h) enter through the reservoirs in the same loop: the wave evaluates its
 //     (reservoir, mode) entries, keeps their counts in LDS and builds the entering particles in whole tiles.
@@ -75,7 +76,7 @@ struct NkLds {
     double *sp_cv, *sp_pr;
     // mode records of the sweep's segments, d.nlrec per wave (16-byte aligned)
     double *lrec;
-    // the sweep's carry: up to 64 parked particles per wave (NkCarryLds)
+    // the sweep's carry: up to 64 parked particles per wave
     double *carry;
     // output ring of the sweep, NK_ORING particles per wave: x y z occ nts [pid] (doubles), then w0
     double *oring;
@@ -321,48 +322,6 @@ __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t ste
         else atomicOr(d.overflow, 8);                                           // inbox full
     }
 }
-
-// ---- cross-lane moves of a parked particle (the carry)
-__device__ __forceinline__ double nk_pull_d(int src, double v) {      // every lane reads lane `src`
-    const int lo = __builtin_amdgcn_ds_bpermute(src << 2, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(src << 2, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double nk_push_d(int dst, double v) {      // every lane writes lane `dst` (a permutation)
-    const int lo = __builtin_amdgcn_ds_permute(dst << 2, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_permute(dst << 2, __double2hiint(v));
-    return __hiloint2double(hi, lo);
-}
-template <bool PID, bool GM = false>
-struct NkCarry {
-    double x, y, z, occ, nts, cts;     // cts: fraction of the step already consumed by earlier events
-    uint32_t w0, evc;                  // evc: events so far in this step (numbers the RNG draws)
-    uint32_t gm;                       // GM (rough facets): the particle's GLOBAL mode -- a reflection may have moved it to a
-                                       // mode another segment owns, which the local index in w0 cannot express
-    unsigned long long pid;
-    __device__ __forceinline__ NkCarry pull(int src) const {
-        NkCarry o;
-        o.x = nk_pull_d(src, x); o.y = nk_pull_d(src, y); o.z = nk_pull_d(src, z); o.occ = nk_pull_d(src, occ);
-        o.nts = nk_pull_d(src, nts); o.cts = nk_pull_d(src, cts);
-        o.w0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)w0);
-        o.evc = (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)evc);
-        o.gm = GM ? (uint32_t)__builtin_amdgcn_ds_bpermute(src << 2, (int)gm) : 0u;
-        o.pid = 0;
-        if (PID) o.pid = (unsigned long long)__double_as_longlong(nk_pull_d(src, __longlong_as_double((long long)pid)));
-        return o;
-    }
-    __device__ __forceinline__ NkCarry push(int dst) const {
-        NkCarry o;
-        o.x = nk_push_d(dst, x); o.y = nk_push_d(dst, y); o.z = nk_push_d(dst, z); o.occ = nk_push_d(dst, occ);
-        o.nts = nk_push_d(dst, nts); o.cts = nk_push_d(dst, cts);
-        o.w0 = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)w0);
-        o.evc = (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)evc);
-        o.gm = GM ? (uint32_t)__builtin_amdgcn_ds_permute(dst << 2, (int)gm) : 0u;
-        o.pid = 0;
-        if (PID) o.pid = (unsigned long long)__double_as_longlong(nk_push_d(dst, __longlong_as_double((long long)pid)));
-        return o;
-    }
-};
 
 // Reservoir emission as its own (small) kernel: fill_reservoirs + add_reservoir_particles for the modes a segment owns.
 // A wave evaluates its segment's (reservoir, mode) entries 128 at a time ('one_to_one': reads the segment's inbox), builds
