@@ -28,7 +28,7 @@
 #define NK_TAU_ROWS 3        // lifetime rows packed into each mode record (two intervals of the temperature grid)
 #define NK_MAX_SEGMENTS 16384 // upper bound of nseg
 #define NK_EMIT_CHUNK 128    // (reservoir, mode) entries a wave evaluates at a time (two per lane)
-#define NK_LREC 64           // mode records a wave of the sweep stages in LDS (segments that own more read them from L2)
+#define NK_LREC 128          // most mode records a wave of the sweep stages in LDS (segments that own more read them from L2)
 #define NK_NEWBORN 0x80000000u
 
 // RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")

@@ -154,7 +154,7 @@ static inline int nk_sweep_fast(const nk_ctx *ctx) {
     return (d.sv_kind == 0 && d.T_ref_local && (d.sv_interp == 0 || d.sv_interp == 1)) ? 1 + d.sv_interp : 0;
 }
 // the sweep keeps its segments' mode records in LDS when the modes are partitioned over the segments and a segment's share fits
-static inline bool nk_want_lrec(const nk_ctx *ctx) { return ctx->d.part && ctx->d.nlmax <= NK_LREC; }
+static inline bool nk_want_lrec(const nk_ctx *ctx) { return ctx->d.nlrec > 0; }      // decided with the segmentation (nk_alloc_particles)
 // k_events, the same way
 #define NK_EVENTS_CASE(G, R, B, P, STMT) { auto KERNEL = k_events<G, R, B, P>; STMT; }
 #define NK_EVENTS_CASE_RP(G, B, rough, pid, STMT)                                                     \
@@ -1104,7 +1104,13 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         nseg = ns;
         d.nseg = (int32_t)nseg;
         d.nlmax = d.M > 0 ? (int32_t)((d.M + nseg - 1) / nseg) : 1;
-        d.nlrec = nk_want_lrec(ctx) ? d.nlmax : 0;
+        // the segments' mode records in LDS where a segment's share fits and the LDS they take costs no resident workgroup
+        d.nlrec = 0;
+        if (d.part && d.nlmax <= NK_LREC) {
+            const int without = nk_sweep_blocks(ctx);
+            d.nlrec = d.nlmax;
+            if (nk_sweep_blocks(ctx) < without) d.nlrec = 0;
+        }
         if (same) break;
     }
     NK_ARG(d.nlmax < (1 << 14), "too many modes per segment for k_emit's packed entry word: use more particles (segments) or fewer modes");

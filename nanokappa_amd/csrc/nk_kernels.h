@@ -588,10 +588,10 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
         const NkSegModes sm = nk_seg_modes(d, seg);
         constexpr bool use_lrec = LREC;             // host: the modes are partitioned and every segment's share fits (nk_want_lrec)
         if (use_lrec) {
-            if (lane < sm.nl) {
-                const double4 *g = reinterpret_cast<const double4 *>(sm.rec + lane);
+            for (int r0 = lane; r0 < sm.nl; r0 += 64) {
+                const double4 *g = reinterpret_cast<const double4 *>(sm.rec + r0);
                 const double4 a = g[0], b = g[1];
-                double2 *q = lrec + lane * NK_LREC_STRIDE;
+                double2 *q = lrec + r0 * NK_LREC_STRIDE;
                 q[0] = make_double2(a.x, a.y); q[1] = make_double2(a.z, a.w); q[2] = make_double2(b.x, b.y); q[3] = make_double2(b.z, b.w);
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
