@@ -553,6 +553,9 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 // (coalesced, one extra round trip for those particles) and k_events runs the events, whose tree walks are chains of
 // dependent loads, at twice the residency; the fused form keeps the events in registers (boxes: a third of the particles
 // have one every step, a second trip through HBM would cost more than the residency gains).
+#ifndef NK_PREFETCH2
+#define NK_PREFETCH2 0
+#endif
 #ifndef NK_SWEEP_OCC_BIG
 #define NK_SWEEP_OCC_BIG 2      // the variants with rough facets, RBF temperatures or large meshes (more than 168 VGPRs)
 #endif
@@ -614,6 +617,17 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
             w0N = NK_LD(d.w0 + i); xN = NK_LD(d.x + i); yN = NK_LD(d.y + i); zN = NK_LD(d.z + i); occN = NK_LD(d.occ + i); ntsN = NK_LD(d.nts + i);
             if (PID) pidN = NK_LD(d.pid + i);
         }
+#if NK_PREFETCH2
+        // a second tile on its way (more bytes in flight per wave: the memory system's latency at this load is about one tile's time)
+        uint32_t w0M = 0u;
+        double xM = 0, yM = 0, zM = 0, occM = 0, ntsM = 0;
+        unsigned long long pidM = 0;
+        if (NK_TILE + lane < count) {
+            const int64_t i = base + NK_TILE + lane;
+            w0M = NK_LD(d.w0 + i); xM = NK_LD(d.x + i); yM = NK_LD(d.y + i); zM = NK_LD(d.z + i); occM = NK_LD(d.occ + i); ntsM = NK_LD(d.nts + i);
+            if (PID) pidM = NK_LD(d.pid + i);
+        }
+#endif
         for (int t = 0; t <= nA; ++t) {
             const bool flush = t == nA;               // one empty tile: drains the carry
             bool act = false;
@@ -625,11 +639,20 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 const int r = t * NK_TILE;
                 act = r + lane < count;
                 w0 = w0N; x = xN; y = yN; z = zN; occ = occN; nts = ntsN; pid = pidN;
+#if NK_PREFETCH2
+                w0N = w0M; xN = xM; yN = yM; zN = zM; occN = occM; ntsN = ntsM; pidN = pidM;
+                if (r + 2 * NK_TILE + lane < count) {
+                    const int64_t i = base + r + 2 * NK_TILE + lane;
+                    w0M = NK_LD(d.w0 + i); xM = NK_LD(d.x + i); yM = NK_LD(d.y + i); zM = NK_LD(d.z + i); occM = NK_LD(d.occ + i); ntsM = NK_LD(d.nts + i);
+                    if (PID) pidM = NK_LD(d.pid + i);
+                }
+#else
                 if (r + NK_TILE + lane < count) {
                     const int64_t i = base + r + NK_TILE + lane;
                     w0N = NK_LD(d.w0 + i); xN = NK_LD(d.x + i); yN = NK_LD(d.y + i); zN = NK_LD(d.z + i); occN = NK_LD(d.occ + i); ntsN = NK_LD(d.nts + i);
                     if (PID) pidN = NK_LD(d.pid + i);
                 }
+#endif
                 const bool newborn = (w0 & NK_NEWBORN) != 0u;
                 w0 &= ~NK_NEWBORN;
                 const int idx = act ? (int)(w0 & lbmask) : 0;
