@@ -62,6 +62,11 @@
 #define NK_STAMP(k) do { } while (0)
 #endif
 
+// lanes below this one whose bit is set in `m` (a ballot): v_mbcnt_lo / v_mbcnt_hi, no mask of the lower lanes to keep
+__device__ __forceinline__ int nk_rank(unsigned long long m) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned int)m, 0u));
+}
+
 // =================================================================================== LDS carve-up
 struct NkLds {
     NkSvTab tb;                          // centres, temperatures (+ RBF coefficients), per-subvolume records
@@ -575,7 +580,6 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
     const bool do_flux = (flags & 1) != 0;          // flags: 1 = heat-flux step
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rep = lane & (NK_NREP - 1);
-    const unsigned long long lower = (1ull << lane) - 1ull;
     const uint32_t lbmask = (1u << d.lb) - 1u;
     double2 *lrec = reinterpret_cast<double2 *>(L.lrec) + wave * d.nlrec * NK_LREC_STRIDE;
     // the wave's carry in LDS: x y z occ nts cts [64] each, then (ids) pid [64], then the words w0, evc and (ids) gm [64] each
@@ -683,11 +687,11 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
             const bool done = act && !ev;
             const unsigned long long mD = __ballot(done), mE = __ballot(ev);
             if (done) nk_tally_one(d, L.tb, L.bins, x, y, z, occ, omega, E0, vx, vy, vz, do_flux, rep);
-            O.push(d, base, lane, done, __popcll(mD & lower), __popcll(mD), x, y, z, occ, nts, w0, pid);
+            O.push(d, base, lane, done, nk_rank(mD), __popcll(mD), x, y, z, occ, nts, w0, pid);
             NK_STAMP(2);
             if (SPLIT) {                               // the tile's event particles leave for the queue; k_events takes over
                 if (ev) {
-                    const int o = qn + __popcll(mE & lower);
+                    const int o = qn + nk_rank(mE);
                     if (o < d.segcap) {
                         const int64_t i = base + o;
                         d.qx[i] = x; d.qy[i] = y; d.qz[i] = z; d.qocc[i] = occ; d.qnts[i] = nts; d.qw0[i] = w0;
@@ -700,7 +704,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
             // ---- drain (Population.py:1546-1683): the tile's event particles are parked in the wave's carry (LDS); whenever it
             // holds 64 (or on the last, empty tile) the whole wave runs one boundary event per particle; finished particles
             // are tallied and appended, absorbed ones vanish, the few that meet another wall go back into the carry
-            const int pn = __popcll(mE), erank = __popcll(mE & lower);
+            const int pn = __popcll(mE), erank = nk_rank(mE);
             int taken = 0;                            // event particles of this tile already parked
             while (taken < pn || (flush && cn > 0)) {
                 if (taken < pn) {
@@ -767,7 +771,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
                 const bool home = alive && stay, away = alive && !stay;
                 const unsigned long long mA = __ballot(home), mM = __ballot(more);
-                O.push(d, base, lane, home, __popcll(mA & lower), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0e, cpid);
+                O.push(d, base, lane, home, nk_rank(mA), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0e, cpid);
                 if (ROUGH && away) {                       // one 64-byte record into the inbox of the segment that owns the new mode
                     const int dst = (int)((uint32_t)p.mode - idxe * (uint32_t)d.nseg);
                     const int at = atomicAdd(d.mig_n + dst, 1);
@@ -780,7 +784,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 }
                 cn = __popcll(mM);
                 if (more) {                               // back into the carry, packed (every entry was read above: slots <= lane)
-                    const int sl = __popcll(mM & lower);
+                    const int sl = nk_rank(mM);
                     cX[sl] = p.x; cX[64 + sl] = p.y; cX[128 + sl] = p.z; cX[192 + sl] = p.occ; cX[256 + sl] = p.nts; cX[320 + sl] = cts;
                     cW[sl] = w0e; cW[64 + sl] = evc;
                     if (PID) { cP[sl] = __longlong_as_double((long long)cpid); cW[128 + sl] = (uint32_t)p.mode; }
@@ -878,7 +882,6 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
     const bool do_flux = (flags & 1) != 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int rep = lane & (NK_NREP - 1);
-    const unsigned long long lower = (1ull << lane) - 1ull;
     const uint32_t lbmask = (1u << d.lb) - 1u;
     const bool tree = GEOM == 2 && d.NG > 0;
     const int32_t *pf = d.seg_evq + d.nseg;           // exclusive prefix sums of the queue lengths
@@ -907,7 +910,7 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                 if (lane == 0) g0 = atomicAdd(d.ev_ticket, n);
                 g0 = __builtin_amdgcn_readfirstlane(g0);
                 if (g0 + n >= total) more = false;
-                const int g = g0 + __popcll(mN & lower);
+                const int g = g0 + nk_rank(mN);
                 if (phase == NK_PH_NEED && g < total) {
                     int lo = 0, hi = d.nseg;              // the segment whose queue holds entry g: the last one with pf[s] <= g
                     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pf[mid] <= g) lo = mid; else hi = mid; }
