@@ -61,9 +61,10 @@ def quiet(fn, *a, **k):
         sys.stdout = old
 
 
-def _oracle_run(geo, ph, n, seed, seconds_target, max_steps, start=None):
+def _oracle_run(geo, ph, n, seed, seconds_target, max_steps, start=None, rough=None):
     """n particles of the bench workload through the CPU oracle (oracle/nk_oracle.c, a scalar C port of the reference
-    loop): same box / BCs / material.  Returns (phonon-steps, seconds, steps)."""
+    loop): same geometry / BCs / material.  `rough` = (facets, specularity, true_specular, spec_map, roulette) of the
+    rough facets, as the Population built them.  Returns (phonon-steps, seconds, steps)."""
     sys.path.insert(0, os.path.join(ROOT, 'oracle'))
     import nk_oracle as O
     from nanokappa_amd import setup_tables as ST
@@ -77,8 +78,11 @@ def _oracle_run(geo, ph, n, seed, seconds_target, max_steps, start=None):
     ep = ST.enter_probability(geo, ph, geo.res_facets, density, 1.0).reshape(-1, Q * J)
     rng = np.random.default_rng(seed)
     res = O.make_reservoirs(geo.res_facets, geo.res_values, ep, rng.random(ep.shape))
-    z = np.zeros(0)
-    rough = O.make_rough(np.zeros(0, dtype=np.int32), z, np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32), z)
+    if rough is None:
+        z = np.zeros(0)
+        rgh = O.make_rough(np.zeros(0, dtype=np.int32), z, np.zeros(0, dtype=np.uint8), np.zeros(0, dtype=np.int32), z)
+    else:
+        rgh = O.make_rough(*rough)
     par = O.make_params(dt=1.0, particle_density=density, seed=seed)
     pos = geo.mesh.sample_volume(n, rng)
     active = np.nonzero(~ph.inactive_modes_mask.ravel())[0]
@@ -86,27 +90,26 @@ def _oracle_run(geo, ph, n, seed, seconds_target, max_steps, start=None):
     occ = ph.calculate_occupation(298.0, ph.omega.ravel()[mode])
     store = O.ParticleStore(int(1.3 * n) + 4096)
     store.load(pos, mode, occ)
-    sim = O.OracleSim(mat, mesh, sv, res, rough, par, store, np.full(geo.n_of_subvols, 298.0))
+    sim = O.OracleSim(mat, mesh, sv, res, rgh, par, store, np.full(geo.n_of_subvols, 298.0))
     sim.init_boundaries()
     sim.run_timestep()                       # warm-up step
     if start is not None:
         start.wait()                         # all workers set up: measure while all of them run
     t0 = time.time()
     steps, psteps = 0, 0
-    while time.time() - t0 < seconds_target and steps < max_steps:
+    while steps < 1 or (time.time() - t0 < seconds_target and steps < max_steps):
         sim.run_timestep()
         psteps += int(sim.N_sv.sum())
         steps += 1
     return psteps, time.time() - t0, steps
 
 
-def cpu_baseline(geo, ph, mesh_n, seconds_target=15.0):
-    """The CPU oracle timed on this host on a bounded sample of the same workload: 1e6 particles, one thread."""
-    n = 1000000
-    psteps, dt, steps = _oracle_run(geo, ph, n, 1, seconds_target, 200)
+def cpu_baseline(geo, ph, mesh_n, desc, n=1000000, seconds_target=15.0, rough=None):
+    """The CPU oracle timed on this host on a bounded sample of the same workload (default 1e6 particles), one thread."""
+    psteps, dt, steps = _oracle_run(geo, ph, n, 1, seconds_target, 200, rough=rough)
     return dict(value=psteps / dt, unit='phonon-steps/s', cores=1, kind='port',
-                sample='%d particles x %d steps of the same workload (box 200 A, T T P, %d^3 x 6 modes), oracle/nk_oracle.c, 1 thread'
-                       % (n, steps, mesh_n))
+                sample='%d particles x %d steps of the same workload (%s, %d^3 x 6 modes), oracle/nk_oracle.c, 1 thread'
+                       % (n, steps, desc, mesh_n))
 
 
 def _all_cores_worker(geo, ph, n, seed, seconds_target, start, out):
@@ -120,7 +123,7 @@ def _all_cores_worker(geo, ph, n, seed, seconds_target, start, out):
         out.put(('error', repr(e), 0))
 
 
-def cpu_baseline_all_cores(geo, ph, mesh_n, seconds_target=8.0):
+def cpu_baseline_all_cores(geo, ph, mesh_n, desc, seconds_target=8.0):
     """The same oracle on every core this process may use: one worker process per core (forked BEFORE anything touches
     the GPU), each with its own share of 1e6 particles -- the particle shards of the multi-rank scheme, without the
     exchange of tallies.  Sum of the workers' rates while all of them run.  None if it cannot be measured."""
@@ -153,8 +156,8 @@ def cpu_baseline_all_cores(geo, ph, mesh_n, seconds_target=8.0):
         return None
     rate = sum(r[0] / r[1] for r in res)
     return dict(value=rate, unit='phonon-steps/s', cores=cores, kind='port',
-                sample='%d worker processes x %d particles x %d-%d steps of the same workload, oracle/nk_oracle.c, one thread each, '
-                       'tallies not exchanged' % (cores, n, min(r[2] for r in res), max(r[2] for r in res)))
+                sample='%d worker processes x %d particles x %d-%d steps of the same workload (%s), oracle/nk_oracle.c, one thread each, '
+                       'tallies not exchanged' % (cores, n, min(r[2] for r in res), max(r[2] for r in res), desc))
 
 
 CONFIGS = ('c2', 'c1b', 'c3', 'c4', 'c5')
@@ -208,42 +211,76 @@ def wire_geometry(total):
     return args, quiet(Geometry, args)
 
 
-def launch_ranks(n):
+def launch_ranks(n, deadline_s=None):
     """`bench.py --gpus N` without a launcher: start the N rank processes (one per GPU) BEFORE anything touches a GPU,
-    relay rank 0's JSON line, fail if any rank fails."""
+    relay rank 0's JSON line.  The children are watched together: the first one that exits non-zero, or the overall
+    deadline (NK_BENCH_DEADLINE seconds, default 1500), ends the others -- a rank that died after ncclCommInitRank would
+    otherwise leave its peers in the all-reduce for ever -- and the parent exits non-zero naming the rank."""
     import socket
     import subprocess
+    import tempfile
+    if deadline_s is None:
+        deadline_s = float(os.environ.get('NK_BENCH_DEADLINE', '1500'))
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
     port = s.getsockname()[1]
     s.close()
-    procs = []
+    procs, outs = [], []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), NK_RDV_KEY='%d_%d' % (os.getpid(), port))
         env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        out = tempfile.TemporaryFile() if r == 0 else None     # a file, not a pipe: nobody has to drain it while we poll
+        outs.append(out)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=(subprocess.PIPE if r == 0 else subprocess.DEVNULL)))
-    out, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out.decode())
+                                      stdout=(out if r == 0 else subprocess.DEVNULL)))
+    t0, failed = time.time(), None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = 'rank(s) failed: %s' % ', '.join('rank %d rc %d' % b for b in bad)
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.time() - t0 > deadline_s:
+            failed = 'deadline of %.0f s passed with rank(s) %s still running' % (deadline_s, [r for r, rc in enumerate(rcs) if rc is None])
+            break
+        time.sleep(0.2)
+    if failed:
+        for p in procs:                      # exactly the children started above, nothing by pattern
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.time()
+        while any(p.poll() is None for p in procs) and time.time() - t1 < 10:
+            time.sleep(0.1)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    outs[0].seek(0)
+    sys.stdout.write(outs[0].read().decode())
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        raise SystemExit('bench.py: rank(s) failed: %s' % ', '.join('rank %d rc %d' % b for b in bad))
+    if failed:
+        raise SystemExit('bench.py: ' + failed + ' (the other ranks were stopped)')
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=50)
-    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=50)
     ap.add_argument('--repeats', type=int, default=5, help='timed regions of --steps steps each; the median is reported')
     ap.add_argument('--config', default='c2', choices=CONFIGS)
     ap.add_argument('--particles', type=float, default=None, help='particles per GPU (default: the config\'s own)')
     ap.add_argument('--mesh-n', type=int, default=31, help='q-mesh of the synthetic material (31 -> 29791 q-points)')
     ap.add_argument('--box', type=float, default=200.0)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--sustained', type=int, default=None,
+                    help='steps of the `sustained` leg (BASELINE config 2 is quoted on 10000 iterations); default 10000 for '
+                         'the default line (c2, one GPU), 0 otherwise')
+    ap.add_argument('--per-call', type=int, default=None,
+                    help='Population.run_timestep calls of the `per_call` leg (the reference driver\'s granularity); '
+                         'default 500 for the default line, 0 otherwise')
     ap.add_argument('--calibrate', action='store_true',
                     help='after the timed region run 3 known-traffic sweeps (k_cal_stream) for PMC calibration')
     a = ap.parse_args()
@@ -257,6 +294,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
     if world != a.gpus:
         raise SystemExit('--gpus %d does not match WORLD_SIZE %d' % (a.gpus, world))
+    hook = os.environ.get('NK_BENCH_TEST_HOOK')          # tests/test_launcher.py: what launch_ranks does about dead / hung ranks
+    if hook == 'rank1_dies_rank0_hangs' and world > 1:
+        if rank == 1:
+            raise SystemExit(3)
+        time.sleep(600)
+    if hook == 'all_hang' and world > 1:
+        time.sleep(600)
     from nanokappa_amd.sharding import NodeRendezvous
     rdv = NodeRendezvous(rank, world, os.environ.get('NK_RDV_KEY', os.environ.get('MASTER_PORT', 'solo')))
 
@@ -269,6 +313,7 @@ def main():
 
     per_gpu = a.particles if a.particles is not None else {'c4': 5e7, 'c5': 1.25e7}.get(a.config, 1e7)
     total = int(per_gpu) * world
+    os.environ.setdefault('NK_MESH_DEVICE', str(local_rank))     # the host geometry's inside tests run on this rank's GPU too
     if a.config == 'c4':
         args, geo = wire_geometry(total)
         species, desc = 'Si', 'STL-imported wire, 5000 triangles, L 2000 A, R 200 A, caps T, rough side (eta 5 A), slice 20 subvols'
@@ -280,10 +325,18 @@ def main():
         geo = quiet(Geometry, args)
     ph = Phonon(args, 0, material=synthetic.make_material(a.mesh_n, species, temperatures=np.arange(200.0, 401.0, 10.0)))
 
-    cpu_legs = world == 1 and not a.no_cpu_baseline and a.config == 'c2'
+    default_line = world == 1 and a.config == 'c2' and a.particles is None
+    n_sustained = a.sustained if a.sustained is not None else (10000 if default_line else 0)
+    n_per_call = a.per_call if a.per_call is not None else (500 if default_line else 0)
+    cpu_legs = world == 1 and not a.no_cpu_baseline
+    rough_cfg = a.config in ('c1b', 'c4')
     all_cores = None
-    if cpu_legs:
-        all_cores = cpu_baseline_all_cores(geo, ph, a.mesh_n)      # forks: must come before the GPU is touched
+    if cpu_legs and not rough_cfg:
+        # forks: must come before the GPU is touched -- the box geometries stay below the size at which the host mesh
+        # code would use the GPU (nk_mesh_crossings), and the engine library is not loaded yet
+        assert 'nanokappa_amd.engine' not in sys.modules or sys.modules['nanokappa_amd.engine']._lib is None, \
+            'cpu_baseline_all_cores must fork before the HIP library is loaded'
+        all_cores = cpu_baseline_all_cores(geo, ph, a.mesh_n, desc)
     comm = None
     if world > 1:
         uid = rdv.broadcast(comm_unique_id() if rank == 0 else b'')
@@ -294,18 +347,27 @@ def main():
         args.device = [local_rank % nd]
     pop = quiet(Population, args, geo, ph, None, comm)
     eng = pop.engine
+    # what RCCL itself says about the communicator (not WORLD_SIZE): every rank reports, rank 0 prints
+    ci = eng.comm_info()
+
+    def housekeeping(tm0, tm1):
+        return {k: tm1[k] - tm0[k] for k in ('regrows', 'halts', 'tau_rebuilds', 'batches')}
 
     if a.warmup > 0:
         eng.step(a.warmup)                 # nk_step returns after the stream has drained (hipStreamSynchronize)
+    # one untimed region with the timed regions' own call pattern (same --steps): first-use costs of that pattern (history
+    # buffer, event pool, clocks) land here, not in the first timed region
+    eng.step(a.steps)
     runs = []
     for _ in range(a.repeats):
+        tm0 = eng.timing()
         rdv.barrier()
         t0 = time.perf_counter()
         t = eng.step(a.steps)              # enqueues the steps, drains the stream, copies the tallies back
         rdv.barrier()
         elapsed = rdv.max(time.perf_counter() - t0)
         tm = eng.timing()
-        runs.append(dict(elapsed=elapsed, psteps=float(t['N_sv'].sum()), tm=tm))   # N_sv: all ranks (all-reduced)
+        runs.append(dict(elapsed=elapsed, psteps=float(t['N_sv'].sum()), tm=tm, hk=housekeeping(tm0, tm)))   # N_sv: all ranks (all-reduced)
     if a.calibrate:
         cal = eng.calibrate_stream(3)
         if rank == 0:
@@ -314,6 +376,41 @@ def main():
     med = runs[order[len(order) // 2]]
     elapsed, psteps, tm = med['elapsed'], med['psteps'], med['tm']
     value = psteps / elapsed
+    per_rank = rdv.allgather(json.dumps(dict(rank=rank, comm_rank=ci['comm_rank'], comm_nranks=ci['comm_nranks'],
+                                              selftest_sum=ci['selftest_sum'], device=ci['device'], pci_bus_id=ci['pci_bus_id'],
+                                              live=tm['live'], sweep_ms=tm['step_kernel_ms'])).encode())
+
+    # ---- the reference driver's own granularity: one Population.run_timestep per step (nanokappa.py:91-98)
+    per_call = None
+    if n_per_call > 0:
+        n0 = pop.current_timestep
+        t0 = time.perf_counter()
+        ps = 0.0
+        for _ in range(n_per_call):
+            quiet(pop.run_timestep, geo, ph)
+            ps += pop.N_p
+        dt_pc = time.perf_counter() - t0
+        per_call = dict(calls=n_per_call, seconds=dt_pc, ms_per_call=1e3 * dt_pc / n_per_call, value=ps / dt_pc, unit='phonon-steps/s',
+                        what='%d x Population.run_timestep (one nk_step(1) each: launches + stream drain + tally copy + host '
+                             'bookkeeping), steps %d..%d' % (n_per_call, n0, pop.current_timestep))
+    # ---- BASELINE's own run length in one go (config 2: 10 000 iterations), through Population.run
+    sustained = None
+    if n_sustained > 0:
+        tm0 = eng.timing()
+        n0 = pop.current_timestep
+        t0 = time.perf_counter()
+        quiet(pop.run, n_sustained, geo, ph)
+        dt_s = time.perf_counter() - t0
+        rows = [r for r in pop.conv_rows if r['step'] > n0 + n_sustained // 2]
+        kap = np.array([r['kappa'] for r in rows], dtype=float)
+        npart = np.array([r['N_p'] for r in pop.conv_rows if r['step'] > n0], dtype=float)
+        sustained = dict(steps=n_sustained, seconds=dt_s, ms_per_step=1e3 * dt_s / n_sustained,
+                         value=float(npart.mean()) * n_sustained / dt_s, unit='phonon-steps/s',
+                         kappa_mean=float(np.nanmean(kap)), kappa_std=float(np.nanstd(kap)), kappa_samples=int(kap.size),
+                         kappa_unit='W/m/K (synthetic material)', N_p_mean=float(npart.mean()),
+                         housekeeping=housekeeping(tm0, eng.timing()),
+                         what='Population.run(%d) in one go (100-step library calls, every tenth step a convergence row); kappa over '
+                              'the rows of the second half' % n_sustained)
 
     if rank == 0:
         live_rank = tm['live'] / world if world > 1 else tm['live']
@@ -330,16 +427,24 @@ def main():
             except Exception:
                 traffic = None
         ms = [1e3 * r['elapsed'] / a.steps for r in runs]
+        ranks = [json.loads(b.decode()) for b in per_rank]
         out = {
             'metric': 'phonon-steps/sec (whole node)', 'value': value, 'unit': 'phonon-steps/s',
             'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': 1e3 * elapsed / a.steps,
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
             'repeats': a.repeats, 'ms_per_step_min': min(ms), 'ms_per_step_max': max(ms),
-            'timing': 'median of %d timed regions of %d steps each (barrier + drained stream on both sides, max over ranks)'
-                      % (a.repeats, a.steps),
+            'ms_per_step_repeats': ms, 'sweep_ms_repeats': [r['tm']['step_kernel_ms'] for r in runs],
+            'housekeeping_repeats': [r['hk'] for r in runs],
+            'timing': 'median of %d timed regions of %d steps each (barrier + drained stream on both sides, max over ranks); %d warm-up '
+                      'steps and one untimed region of %d steps before them' % (a.repeats, a.steps, a.warmup, a.steps),
             'config': {'workload': '%s-like synthetic %d^3x6 modes, %s, dt 1 ps, %.3g particles per GPU (BASELINE config %s)'
                                    % (species, a.mesh_n, desc, per_gpu, a.config),
                        'particles_total': total, 'live_particles_end': tm['live'], 'parallelism': 'particle-shard x%d' % world},
+            # the communicator as RCCL reports it (ncclCommCount / ncclCommUserRank, and the all-reduce of ones at nk_comm_init);
+            # one GPU: no communicator (nranks 0)
+            'rccl': {'nranks': ranks[0]['comm_nranks'], 'selftest_sum': ranks[0]['selftest_sum'],
+                     'all_ranks_agree': all(r['comm_nranks'] == ranks[0]['comm_nranks'] for r in ranks),
+                     'distinct_devices': len(set(r['pci_bus_id'] for r in ranks)), 'ranks': ranks},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': 'k_sweep', 'kernel_ms': k_ms, 'emit_count_kernel_ms': tm['emit_kernel_ms'],
@@ -347,8 +452,19 @@ def main():
                          'frac_whole_step': BYTES_PER_PHONON_STEP * value / 1e9 / HBM_PEAK_GBS / max(world, 1),
                          'algorithmic_bytes_per_launch': BYTES_PER_PHONON_STEP * live_rank},
         }
+        if world > 1 and (ranks[0]['comm_nranks'] != world or not out['rccl']['all_ranks_agree']):
+            raise SystemExit('bench.py: RCCL reports %d ranks, the launcher %d' % (ranks[0]['comm_nranks'], world))
+        if per_call is not None:
+            out['per_call'] = per_call
+        if sustained is not None:
+            out['sustained'] = sustained
         if cpu_legs:
-            out['cpu_baseline'] = cpu_baseline(geo, ph, a.mesh_n)
+            rough = None
+            if rough_cfg:                    # the tables the Population built (on the device), handed to the oracle
+                sp, ts, sm, ro = pop.rough_tables()
+                rough = (np.asarray(pop.rough_facets, dtype=np.int32), sp, ts.astype(np.uint8), sm.astype(np.int32), ro)
+            n_cpu = {'c4': 20000, 'c1b': 300000}.get(a.config, 1000000)
+            out['cpu_baseline'] = cpu_baseline(geo, ph, a.mesh_n, desc, n=n_cpu, rough=rough)
             if all_cores is not None:
                 out['cpu_baseline_all_cores'] = all_cores
         out['cpu_reference_numpy'] = CPU_REFERENCE_NUMPY

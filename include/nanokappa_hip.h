@@ -157,6 +157,11 @@ typedef struct {
     double total_ms;         /* wall time of the whole call on the stream */
     int64_t slots;           /* particle capacity (nseg * segcap) */
     int64_t live;            /* live particles after the call (this rank) */
+    /* housekeeping that can land inside a timed region, counted since nk_create: a benchmark reads them per region */
+    int64_t regrows;         /* times the particle store was grown on the device after a halt request */
+    int64_t halts;           /* batches that ended early on a halt request (every rank at the same step) */
+    int64_t tau_rebuilds;    /* rebuilds of the packed mode records (lifetime window / E0 reference moved, or new segmentation) */
+    int64_t batches;         /* nk_step_batch calls = stream drains + history copies */
 } nk_timing;
 
 /* lifetime: `Population.__init__` / end of run */
@@ -214,7 +219,23 @@ int nk_get_timing(nk_ctx *ctx, nk_timing *t);
 
 /* multi-GPU: one context per rank; tallies are all-reduced (sum, f64) over RCCL every step */
 int nk_comm_unique_id(void *id128 /* 128 bytes out */);
+/* Joins the communicator and PROVES it before returning: the rank count and this rank's index are read back from RCCL
+ * (ncclCommCount / ncclCommUserRank) and a vector {1, rank + 1} is all-reduced on the context's stream; NK_ERR_COMM unless
+ * the sums are nranks and nranks (nranks + 1) / 2, i.e. unless exactly the expected ranks took part. */
 int nk_comm_init(nk_ctx *ctx, const void *id128, int rank, int nranks);
+/* What the communicator itself says (not what the caller passed): for logs and the bench line. */
+typedef struct {
+    int32_t rank, nranks;            /* as given to nk_comm_init (1 rank before it is called) */
+    int32_t comm_rank, comm_nranks;  /* ncclCommUserRank / ncclCommCount; -1 / 0 when there is no communicator (one rank, dry run) */
+    int32_t device;                  /* HIP device of this context */
+    int32_t selftest_ok;             /* 1: the all-reduce of ones at nk_comm_init returned nranks */
+    double selftest_sum;             /* what that all-reduce returned (0 without communicator) */
+    char pci_bus_id[32];             /* hipDeviceGetPCIBusId of that device */
+} nk_comm_report;
+int nk_comm_info(nk_ctx *ctx, nk_comm_report *out);
+/* Sum of a small host vector over the ranks of the communicator (in place; unchanged when there is none): the t = 0 tallies
+ * of the shards (Population.py:282, :318-321 on an ensemble that is spread over the ranks). */
+int nk_comm_allreduce(nk_ctx *ctx, double *inout, int64_t n);
 
 /* device versions of the reference's primitives, for parity tests (tests/ -m gpu) */
 int nk_find_boundary(nk_ctx *ctx, int64_t n, const double *x /* [n*3] */, const double *v /* [n*3] */,

@@ -22,6 +22,8 @@ struct NkRccl {      // symbols resolved lazily with dlopen: a single-GPU run ne
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+    ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
 };
 
 static thread_local std::string g_create_error;
@@ -70,13 +72,15 @@ struct nk_ctx {
     void *mig_buf = nullptr, *mig_n = nullptr;   // migration inboxes (rough facets; sized with nseg and segcap)
     double *ep_p = nullptr, *rc_p = nullptr;     // (reservoir, mode) tables in the segments' order (sized with nseg)
     int rm_nseg = 0;                             // segmentation rc_p was built for (0: the counters live in res_counter)
-    double *acc = nullptr;         // [NB + 1]
+    double *acc = nullptr;         // [NB + 2]: tally columns, then the two halt requests that travel with them
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
     nk_params params;
     nk_timing timing;
     NkRccl rccl;
     ncclComm_t comm = nullptr;
+    int comm_rank = -1, comm_nranks = 0;   // as RCCL reports them (nk_comm_info)
+    double comm_selftest = 0.0;
     int num_cu = 256;
     std::vector<int32_t> h_ffo, h_ffi;   // host copies of the mesh's facet -> faces CSR, its area cdf and the vertices
     std::vector<double> h_fcdf, h_verts;
@@ -205,6 +209,7 @@ static int nk_update_tau_window(nk_ctx *ctx, bool force) {
                                                                   d.nseg > 0 ? d.nseg : 1, d.nlmax, (NkMode *)d.modetab, tp);
     NK_HIP(hipGetLastError());
     d.tau_row0 = row0;
+    ctx->timing.tau_rebuilds += 1;
     for (int k = 0; k < NK_TAU_ROWS; ++k) d.tau_g[k] = (row0 + k < d.NT) ? g[row0 + k] : INFINITY;
     for (int k = 0; k + 1 < NK_TAU_ROWS; ++k) d.tau_ig[k] = 1.0 / (d.tau_g[k + 1] - d.tau_g[k]);
     if (d.NT < NK_TAU_ROWS) d.tau_g[0] = INFINITY;     // no packed window: every lookup takes the full-table path
@@ -716,8 +721,8 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     if (ctx->acc) { hipFree(ctx->acc); ctx->acc = nullptr; }
     if (ctx->hist) { hipFree(ctx->hist); ctx->hist = nullptr; }      // the history rows follow NB
     ctx->hist_cap = 0;
-    NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)(d.NB + 1) * sizeof(double)));
-    NK_HIP(hipMemset(ctx->acc, 0, (size_t)(d.NB + 1) * sizeof(double)));
+    NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)(d.NB + 2) * sizeof(double)));
+    NK_HIP(hipMemset(ctx->acc, 0, (size_t)(d.NB + 2) * sizeof(double)));
     const double *p;
     NK_UP((const double *)nullptr, (size_t)(ctx->num_cu * 16) * d.NB, &p);     // >= the sweep's and k_events' persistent grids
     d.partials = (double *)p;
@@ -1238,6 +1243,7 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
         d = old;
         return rc;
     }
+    ctx->timing.regrows += 1;
     k_regrow<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(old, d);
     NK_HIP(hipGetLastError());
     NK_HIP(hipStreamSynchronize(ctx->stream));
@@ -1386,6 +1392,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)rows_alloc * HROW * sizeof(double)));
         ctx->hist_cap = rows_alloc;
     }
+    ctx->timing.batches += 1;
     NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));   // row_valid = 0
     const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, d.pid ? 3 : 2), lds_e = nk_lds(ctx, true, 1);
     const int gm_ = nk_geom_mode(ctx);
@@ -1437,7 +1444,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         double *hrow = ctx->hist + (size_t)s * HROW;
         if (ctx->comm) {
             k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 0);
-            ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB + 1, ncclDouble, ncclSum, ctx->comm, ctx->stream);
+            ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB + 2, ncclDouble, ncclSum, ctx->comm, ctx->stream);
             if (nrc != ncclSuccess) { ctx->err = "ncclAllReduce failed"; return NK_ERR_COMM; }
             k_update<<<1, NK_WG, 0, ctx->stream>>>(d, ctx->acc, hrow, do_flux);
         } else {
@@ -1556,6 +1563,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         if (s_out < nsteps || hw[0] || hw[2] || hw[3]) {
             // halted: a segment could overflow at the next step (or could not take its migrants, which then wait in its
             // inbox).  Grow every segment by half (on the device, state intact), deliver, and carry on.
+            ctx->timing.halts += 1;
             if (++grown > 40) { ctx->err = "nk_step: the particle store keeps filling up"; return NK_ERR_CAPACITY; }
             const bool only_inbox = hw[3] && !hw[0] && !hw[2] && s_out == nsteps;
             if (!only_inbox) {
@@ -1568,10 +1576,8 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
             }
             int32_t zero4[4] = {0, 0, 0, 0};
             NK_HIP(hipMemcpy(d.halt, zero4, 16, hipMemcpyHostToDevice));
-            if (hw[2] && d.nranks > 1) {
-                ctx->err = "nk_step: a segment could not take its migrating particles on this rank (the ranks would no longer halt together); reserve more capacity";
-                return NK_ERR_CAPACITY;
-            }
+            // (hw[2] comes out of the all-reduced vector: with several ranks every one of them is here at the same step, has
+            // grown its segments by the same amount, and delivers whatever waits in its own inboxes)
             if (hw[2]) {                                 // migrants that did not fit: they do now
                 k_deliver<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(d);
                 NK_HIP(hipGetLastError());
@@ -1661,7 +1667,9 @@ static int nk_load_rccl(NkRccl &r, std::string &err) {
     r.CommInitRank = (decltype(r.CommInitRank))dlsym(r.lib, "ncclCommInitRank");
     r.AllReduce = (decltype(r.AllReduce))dlsym(r.lib, "ncclAllReduce");
     r.CommDestroy = (decltype(r.CommDestroy))dlsym(r.lib, "ncclCommDestroy");
-    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy) { err = "librccl lacks expected symbols"; return NK_ERR_COMM; }
+    r.CommCount = (decltype(r.CommCount))dlsym(r.lib, "ncclCommCount");
+    r.CommUserRank = (decltype(r.CommUserRank))dlsym(r.lib, "ncclCommUserRank");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.CommCount || !r.CommUserRank) { err = "librccl lacks expected symbols"; return NK_ERR_COMM; }
     return NK_OK;
 }
 int nk_comm_unique_id(void *id128) {
@@ -1688,6 +1696,58 @@ int nk_comm_init(nk_ctx *ctx, const void *id128, int rank, int nranks) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
     memcpy(&id, id128, 128);
     if (ctx->rccl.CommInitRank(&ctx->comm, nranks, id, rank) != ncclSuccess) { ctx->err = "ncclCommInitRank failed"; ctx->comm = nullptr; return NK_ERR_COMM; }
+    // The communicator proves itself before anything relies on it: RCCL's own view of the rank count, then an all-reduce of
+    // {1, rank + 1} on the engine's stream -- every expected rank took part exactly once iff the sums are nranks and
+    // nranks (nranks + 1) / 2.
+    int cn = 0, cr = -1;
+    if (ctx->rccl.CommCount(ctx->comm, &cn) != ncclSuccess || ctx->rccl.CommUserRank(ctx->comm, &cr) != ncclSuccess) {
+        ctx->err = "ncclCommCount / ncclCommUserRank failed"; return NK_ERR_COMM;
+    }
+    ctx->comm_nranks = cn; ctx->comm_rank = cr;
+    if (cn != nranks || cr != rank) {
+        ctx->err = "RCCL reports rank " + std::to_string(cr) + " of " + std::to_string(cn) + ", expected rank " + std::to_string(rank) + " of " + std::to_string(nranks);
+        return NK_ERR_COMM;
+    }
+    double *probe = nullptr, hp[2] = {1.0, (double)(rank + 1)};
+    NK_HIP(hipMalloc((void **)&probe, 16));
+    hipError_t he = hipMemcpyAsync(probe, hp, 16, hipMemcpyHostToDevice, ctx->stream);
+    ncclResult_t nrc = he == hipSuccess ? ctx->rccl.AllReduce(probe, probe, 2, ncclDouble, ncclSum, ctx->comm, ctx->stream) : ncclSystemError;
+    if (he == hipSuccess && nrc == ncclSuccess) he = hipMemcpyAsync(hp, probe, 16, hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess && nrc == ncclSuccess) he = hipStreamSynchronize(ctx->stream);
+    hipFree(probe);
+    if (he != hipSuccess || nrc != ncclSuccess) { ctx->err = "self-test all-reduce of the new communicator failed"; return NK_ERR_COMM; }
+    ctx->comm_selftest = hp[0];
+    if (hp[0] != (double)nranks || hp[1] != 0.5 * (double)nranks * (double)(nranks + 1)) {
+        ctx->err = "self-test all-reduce returned " + std::to_string(hp[0]) + " / " + std::to_string(hp[1]) + " instead of " +
+                   std::to_string(nranks) + " / " + std::to_string(nranks * (nranks + 1) / 2) + ": not every rank took part";
+        return NK_ERR_COMM;
+    }
+    return NK_OK;
+}
+int nk_comm_allreduce(nk_ctx *ctx, double *inout, int64_t n) {
+    NK_ARG(ctx && inout && n >= 0, "nk_comm_allreduce: bad arguments");
+    if (!ctx->comm || n == 0) return NK_OK;
+    NK_HIP(hipSetDevice(ctx->device));
+    double *buf = nullptr;
+    NK_HIP(hipMalloc((void **)&buf, (size_t)n * 8));
+    hipError_t he = hipMemcpyAsync(buf, inout, (size_t)n * 8, hipMemcpyHostToDevice, ctx->stream);
+    ncclResult_t nrc = he == hipSuccess ? ctx->rccl.AllReduce(buf, buf, (size_t)n, ncclDouble, ncclSum, ctx->comm, ctx->stream) : ncclSystemError;
+    if (he == hipSuccess && nrc == ncclSuccess) he = hipMemcpyAsync(inout, buf, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (he == hipSuccess && nrc == ncclSuccess) he = hipStreamSynchronize(ctx->stream);
+    hipFree(buf);
+    if (he != hipSuccess || nrc != ncclSuccess) { ctx->err = "nk_comm_allreduce failed"; return NK_ERR_COMM; }
+    return NK_OK;
+}
+int nk_comm_info(nk_ctx *ctx, nk_comm_report *out) {
+    NK_ARG(ctx && out, "nk_comm_info: NULL argument");
+    memset(out, 0, sizeof(*out));
+    out->rank = ctx->d.rank; out->nranks = ctx->d.nranks;
+    out->comm_rank = ctx->comm ? ctx->comm_rank : -1;
+    out->comm_nranks = ctx->comm ? ctx->comm_nranks : 0;
+    out->device = ctx->device;
+    out->selftest_sum = ctx->comm ? ctx->comm_selftest : 0.0;
+    out->selftest_ok = (ctx->comm && ctx->comm_selftest == (double)ctx->d.nranks) ? 1 : 0;
+    if (hipDeviceGetPCIBusId(out->pci_bus_id, (int)sizeof(out->pci_bus_id), ctx->device) != hipSuccess) out->pci_bus_id[0] = 0;
     return NK_OK;
 }
 
@@ -1753,7 +1813,7 @@ int nk_tally_state(nk_ctx *ctx, double *E_raw, double *N_sv, double *flux_raw) {
         ctx->pending_relax = false;
     }
     const int g = nk_sweep_grid(ctx);
-    NK_BUF(double, acc, nullptr, d.NB + 1);
+    NK_BUF(double, acc, nullptr, d.NB + 2);
     k_tally_state<<<g, NK_WG, nk_lds(ctx, false), ctx->stream>>>(d);
     k_reduce<<<d.NB, NK_WG, 0, ctx->stream>>>(d, g, acc.p, nullptr, 1, 0);
     NK_HIP(hipGetLastError());

@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
     if (d.halt[0]) return;
     NkLds L;
     nk_lds_setup<GEOM, 1>(d, smem, L);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: segment bookkeeping lives in scalar registers
     unsigned int *sp_pref = L.sp_pref + wave * NK_EMIT_CHUNK, *sp_cnt = L.sp_cnt + wave * NK_EMIT_CHUNK,
                  *sp_rm = L.sp_rm + wave * NK_EMIT_CHUNK;
     double *sp_cv = L.sp_cv + wave * NK_EMIT_CHUNK, *sp_pr = L.sp_pr + wave * NK_EMIT_CHUNK;
@@ -489,6 +489,18 @@ struct NkOut {
         w0 = L.oring_w + wave * NK_ORING;
         on = ob = wout = 0;
     }
+    // the same in two halves (plain cursor only): the slots are taken now, the stores are issued later (the sweep's tile commit)
+    __device__ __forceinline__ int reserve(int rank, int n) { const int o = wout + rank; wout += n; return o; }
+    __device__ __forceinline__ void store(const NkDev &d, int64_t base, bool put, int o, double px, double py, double pz, double pocc,
+                                          double pnts, uint32_t pw0, unsigned long long ppid) {
+        if (put) {
+            if (o < d.segcap) {
+                const int64_t i = base + o;
+                NK_ST(d.x + i, px); NK_ST(d.y + i, py); NK_ST(d.z + i, pz); NK_ST(d.occ + i, pocc); NK_ST(d.nts + i, pnts); NK_ST(d.w0 + i, pw0);
+                if (PID) NK_ST(d.pid + i, ppid);
+            } else atomicOr(d.overflow, 2);     // segment full
+        }
+    }
     // lanes with `put` append their particle (rank = position among them, n = how many); a full tile leaves at once
     __device__ __forceinline__ void push(const NkDev &d, int64_t base, int lane, bool put, int rank, int n, double px, double py,
                                          double pz, double pocc, double pnts, uint32_t pw0, unsigned long long ppid) {
@@ -561,6 +573,9 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 #ifndef NK_PREFETCH2
 #define NK_PREFETCH2 0
 #endif
+#ifndef NK_DEFER_STORE
+#define NK_DEFER_STORE 0      // measured: no gain (profiles/r03_notes.txt); the switch stays in the source
+#endif
 #ifndef NK_SWEEP_OCC_BIG
 #define NK_SWEEP_OCC_BIG 2      // the variants with rough facets, RBF temperatures or large meshes (more than 168 VGPRs)
 #endif
@@ -578,7 +593,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
     NkLds L;
     nk_lds_setup<GEOM, PID ? 3 : 2>(d, smem, L);
     const bool do_flux = (flags & 1) != 0;          // flags: 1 = heat-flux step
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: segment bookkeeping lives in scalar registers
     const int rep = lane & (NK_NREP - 1);
     const uint32_t lbmask = (1u << d.lb) - 1u;
     double2 *lrec = reinterpret_cast<double2 *>(L.lrec) + wave * d.nlrec * NK_LREC_STRIDE;
@@ -632,6 +647,16 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
             if (PID) pidM = NK_LD(d.pid + i);
         }
 #endif
+        // The finished particles of a tile are STORED at the top of the next iteration, between the wait for that iteration's
+        // tile and the next prefetch (NK_DEFER_STORE): a wave's memory counter retires in order, so the wait for a tile also
+        // waits for every store issued after its loads -- stores issued at the end of the previous iteration are the youngest
+        // operations in the queue and their acknowledgement is a full memory round trip; issued an iteration earlier they
+        // have long retired.  Their slots are taken at once (reserve), so the event pass appends behind them as before.
+        bool sdone = false;
+        int so = 0;
+        double sx = 0, sy = 0, sz = 0, socc = 0, snts = 0;
+        uint32_t sw0 = 0u;
+        unsigned long long spid = 0;
         for (int t = 0; t <= nA; ++t) {
             const bool flush = t == nA;               // one empty tile: drains the carry
             bool act = false;
@@ -643,6 +668,14 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 const int r = t * NK_TILE;
                 act = r + lane < count;
                 w0 = w0N; x = xN; y = yN; z = zN; occ = occN; nts = ntsN; pid = pidN;
+            }
+            if (NK_DEFER_STORE && !NK_OUT_RING) {       // the previous tile's finished particles leave now
+                asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(occ), "+v"(nts), "+v"(w0));   // behind the wait for this tile
+                O.store(d, base, sdone, so, sx, sy, sz, socc, snts, sw0, spid);
+                sdone = false;
+            }
+            if (!flush) {
+                const int r = t * NK_TILE;
 #if NK_PREFETCH2
                 w0N = w0M; xN = xM; yN = yM; zN = zM; occN = occM; ntsN = ntsM; pidN = pidM;
                 if (r + 2 * NK_TILE + lane < count) {
@@ -687,7 +720,10 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
             const bool done = act && !ev;
             const unsigned long long mD = __ballot(done), mE = __ballot(ev);
             if (done) nk_tally_one(d, L.tb, L.bins, x, y, z, occ, omega, E0, vx, vy, vz, do_flux, rep);
-            O.push(d, base, lane, done, nk_rank(mD), __popcll(mD), x, y, z, occ, nts, w0, pid);
+            if (NK_DEFER_STORE && !NK_OUT_RING) {
+                so = O.reserve(nk_rank(mD), __popcll(mD));
+                sdone = done; sx = x; sy = y; sz = z; socc = occ; snts = nts; sw0 = w0; spid = pid;
+            } else O.push(d, base, lane, done, nk_rank(mD), __popcll(mD), x, y, z, occ, nts, w0, pid);
             NK_STAMP(2);
             if (SPLIT) {                               // the tile's event particles leave for the queue; k_events takes over
                 if (ev) {
@@ -1035,13 +1071,16 @@ __global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkDev n) {
 // the step's update they are appended to the segment (one wave per segment, coalesced stores).  A segment that cannot
 // take its migrants keeps them in the inbox and raises the halt word: the host grows the store and delivers again.
 __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         int n = d.mig_n[seg];
         if (n <= 0) continue;
         if (n > d.mig_cap) n = d.mig_cap;
         const int count = d.seg_count[seg];
+        // no room: the migrants stay in the inbox.  k_reduce saw that before the tallies were summed over the ranks, so halt[0]
+        // and halt[2] are already up on EVERY rank (nk_update_body) and all of them stop after this step; the atomics here only
+        // cover a k_deliver that the host launches on its own
         if (count + n > d.segcap) { if (lane == 0) { atomicOr(d.halt + 2, 1); atomicOr(d.halt, 1); } continue; }
         const int64_t base = (int64_t)seg * d.segcap + count;
         for (int j = lane; j < n; j += 64) {
@@ -1066,7 +1105,8 @@ __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
 // Normalise, invert E(T), publish the new subvolume temperatures, history row: calculate_energy (Population.py:719-728)
 // + refresh_temperatures (:692), run by ONE workgroup.
 // History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, row_valid, halt, overflow
-// acc[NB] (summed over the ranks like the tallies) > 0: some segment could overflow at the next step -> raise the halt word,
+// acc[NB] / acc[NB + 1] (summed over the ranks like the tallies) > 0: some segment could overflow at the next step / cannot
+// take its migrants -> raise the halt word,
 // on every rank at the same step.
 __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc, double *hist_row, int do_flux) {
     // One workgroup, so everything here is a chain of memory latencies: the E(T) / T(E) tables are read as one 4-point
@@ -1128,10 +1168,12 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
     if (tid == 0) {
         hist_row[NB + 2 * S + 0] = (double)do_flux;
         hist_row[NB + 2 * S + 1] = 1.0;              // this step ran
-        const bool hreq = acc[NB] > 0.0;
+        const bool hdel = acc[NB + 1] > 0.0;         // on some rank a segment cannot take the migrants waiting in its inbox
+        const bool hreq = acc[NB] > 0.0 || hdel;
         hist_row[NB + 2 * S + 2] = hreq ? 1.0 : 0.0;
         hist_row[NB + 2 * S + 3] = (double)*d.overflow;
         if (hreq) d.halt[0] = 1;
+        if (hdel) d.halt[2] = 1;
     }
 }
 
@@ -1153,7 +1195,15 @@ __global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc
         __syncthreads();
     }
     if (threadIdx.x == 0) acc[b] = sh[0];
-    if (threadIdx.x == 0 && b == 0) acc[NB] = (double)d.halt[1];
+    if (b == 0) {
+        // the two halt requests that travel with the tally vector (summed over the ranks, so that every rank stops at the same
+        // step): the sweep's "a segment could overflow at the next step", and -- rough facets -- "a segment cannot take the
+        // migrants that wait in its inbox" (what k_deliver will find after this step's update, checked here, before the sum)
+        int stuck = 0;
+        if (d.mig_n) for (int sg = threadIdx.x; sg < d.nseg; sg += NK_WG) { const int n = d.mig_n[sg]; stuck |= (n > 0 && d.seg_count[sg] + (n < d.mig_cap ? n : d.mig_cap) > d.segcap) ? 1 : 0; }
+        stuck = __syncthreads_or(stuck);
+        if (threadIdx.x == 0) { acc[NB] = (double)d.halt[1]; acc[NB + 1] = (double)stuck; }
+    }
     if (!fuse) return;
     if (threadIdx.x == 0) {
         __threadfence();
@@ -1466,9 +1516,12 @@ __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
         const int count = d.seg_count[seg];
         for (int k = threadIdx.x; k < count; k += NK_WG) {
             const int64_t i = base + k;
-            const uint32_t w0 = d.w0[i];
+            uint32_t w0 = d.w0[i];
             double x = d.x[i], y = d.y[i], z = d.z[i], occ = d.occ[i], nts = d.nts[i];
-            if (w0 == 0xFFFFFFFEu) { x += occ; }                  // keeps the occ load alive; never true
+            // every one of the six loads must really be issued: a load whose only use sits behind a never-taken branch is sunk
+            // into that branch by the compiler (round 2's version lost its occ load that way: 36 B read, not the 44 B the
+            // calibration assumed -- its "read factor" 2.44 was 2.0 x 44 / 36)
+            asm volatile("" : "+v"(w0), "+v"(occ));
             d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts;
         }
     }
@@ -1478,7 +1531,7 @@ __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
 // (two particles per lane) accesses.
 template <int W>
 __global__ __launch_bounds__(NK_WG, 3) void k_probe_copy(NkDev d) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NK_WG / 64);
     constexpr int PPL = W / 8;                         // particles per lane
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {

@@ -69,7 +69,13 @@ class nk_tally(C.Structure):
 class nk_timing(C.Structure):
     _fields_ = [('step_kernel_ms', C.c_double), ('emit_kernel_ms', C.c_double), ('events_kernel_ms', C.c_double),
                 ('total_ms', C.c_double),
-                ('slots', C.c_int64), ('live', C.c_int64)]
+                ('slots', C.c_int64), ('live', C.c_int64),
+                ('regrows', C.c_int64), ('halts', C.c_int64), ('tau_rebuilds', C.c_int64), ('batches', C.c_int64)]
+
+
+class nk_comm_report(C.Structure):
+    _fields_ = [('rank', C.c_int32), ('nranks', C.c_int32), ('comm_rank', C.c_int32), ('comm_nranks', C.c_int32),
+                ('device', C.c_int32), ('selftest_ok', C.c_int32), ('selftest_sum', C.c_double), ('pci_bus_id', C.c_char * 32)]
 
 
 EXPORTS = ['nk_device_count', 'nk_create', 'nk_destroy', 'nk_last_error', 'nk_set_material', 'nk_set_mesh', 'nk_set_subvolumes',
@@ -79,7 +85,7 @@ EXPORTS = ['nk_device_count', 'nk_create', 'nk_destroy', 'nk_last_error', 'nk_se
            'nk_find_boundary', 'nk_classify', 'nk_eval', 'nk_reflect', 'nk_uniform2', 'nk_calibrate_stream',
            'nk_specular_begin', 'nk_specular_pairs', 'nk_specular_end', 'nk_rough_begin', 'nk_rough_pairs', 'nk_rough_finish',
            'nk_rough_download', 'nk_build_enter_prob', 'nk_init_particles', 'nk_tally_state', 'nk_kspec_begin', 'nk_kspec_pairs',
-           'nk_rough_finish_k', 'nk_mesh_crossings']
+           'nk_rough_finish_k', 'nk_mesh_crossings', 'nk_comm_info', 'nk_comm_allreduce']
 
 _lib = None
 
@@ -117,6 +123,8 @@ def load_library():
     L.nk_get_timing.argtypes = [C.c_void_p, C.POINTER(nk_timing)]
     L.nk_comm_unique_id.argtypes = [C.c_void_p]
     L.nk_comm_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.nk_comm_info.argtypes = [C.c_void_p, C.POINTER(nk_comm_report)]
+    L.nk_comm_allreduce.argtypes = [C.c_void_p, c_dp, C.c_int64]
     L.nk_find_boundary.argtypes = [C.c_void_p, C.c_int64, c_dp, c_dp, c_dp, c_dp, c_ip]
     L.nk_classify.argtypes = [C.c_void_p, C.c_int64, c_dp, c_ip]
     L.nk_eval.argtypes = [C.c_void_p, C.c_int32, C.c_int64, c_dp, c_ip, c_dp]
@@ -163,9 +171,15 @@ def device_count():
     return int(load_library().nk_device_count())
 
 
-def mesh_crossings(origins, dirs, v0, e1, e2, skip_self=False, device=0):
-    """Triangles crossed by every open ray (nk_mesh_crossings; -1 where a ray has too many distinct crossings)."""
+def mesh_crossings(origins, dirs, v0, e1, e2, skip_self=False, device=None):
+    """Triangles crossed by every open ray (nk_mesh_crossings; -1 where a ray has too many distinct crossings).
+    device: HIP device index; default NK_MESH_DEVICE, else this process's LOCAL_RANK (a rank's geometry set-up stays on the
+    rank's own GPU), modulo the devices this process sees."""
     L = load_library()
+    if device is None:
+        device = int(os.environ.get('NK_MESH_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        nd = L.nk_device_count()
+        device = device % nd if nd > 0 else 0
     o, d = _d(origins), _d(dirs)
     a, b, c = _d(v0), _d(e1), _d(e2)
     out = np.zeros(o.shape[0], dtype=np.int32)
@@ -392,7 +406,8 @@ class Engine(object):
         self._ck(self.L.nk_get_timing(self.h, C.byref(t)), 'nk_get_timing')
         return dict(step_kernel_ms=t.step_kernel_ms, emit_kernel_ms=t.emit_kernel_ms, events_kernel_ms=t.events_kernel_ms,
                     total_ms=t.total_ms,
-                    slots=int(t.slots), live=int(t.live))
+                    slots=int(t.slots), live=int(t.live), regrows=int(t.regrows), halts=int(t.halts),
+                    tau_rebuilds=int(t.tau_rebuilds), batches=int(t.batches))
 
     # ---- set-up table builder (find_specular_correspondences 'velocity', Population.py:1241-1454)
     def specular_begin(self, group_vel, omega, delta_omega):
@@ -480,6 +495,26 @@ class Engine(object):
     def comm_init(self, unique_id, rank, nranks):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._ck(self.L.nk_comm_init(self.h, buf, int(rank), int(nranks)), 'nk_comm_init')
+
+    def comm_allreduce(self, *arrays):
+        """Sum of small host arrays over the ranks of the communicator; returns them unchanged when there is none."""
+        flat = _d(np.concatenate([np.ravel(np.asarray(a, dtype=float)) for a in arrays]))
+        self._ck(self.L.nk_comm_allreduce(self.h, _p(flat), flat.shape[0]), 'nk_comm_allreduce')
+        out, off = [], 0
+        for a in arrays:
+            a = np.asarray(a)
+            out.append(flat[off:off + a.size].reshape(a.shape).copy())
+            off += a.size
+        return out
+
+    def comm_info(self):
+        """What RCCL itself reports about this context's communicator (rank count, own rank, the self-test all-reduce of
+        nk_comm_init), the HIP device and its PCI bus id."""
+        r = nk_comm_report()
+        self._ck(self.L.nk_comm_info(self.h, C.byref(r)), 'nk_comm_info')
+        return dict(rank=int(r.rank), nranks=int(r.nranks), comm_rank=int(r.comm_rank), comm_nranks=int(r.comm_nranks),
+                    device=int(r.device), selftest_ok=bool(r.selftest_ok), selftest_sum=float(r.selftest_sum),
+                    pci_bus_id=r.pci_bus_id.decode(errors='replace'))
 
     # -------------------------------------------------------------------- taps
     def find_boundary(self, x, v):

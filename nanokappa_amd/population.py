@@ -381,11 +381,7 @@ class Population(Constants):
         else:
             # resume file, Population.py:284-306; a run on several ranks leaves one file per rank beside it
             # (write_final_state), and every rank reads them all before taking its share
-            files = [key] if os.path.exists(key) else []
-            stem, ext = os.path.splitext(key)
-            files += sorted(glob.glob(stem + '.rank*of*' + ext))
-            if not files:
-                raise Exception('Wrong particle data file. Change the keyword or check whether the file exists.')
+            files = resume_files(key)
             data = np.vstack([np.loadtxt(f, delimiter=',', comments='#', dtype=float, ndmin=2) for f in files])
             modes = data[:, [0, 1]].astype(int)
             pos = data[:, [2, 3, 4]].copy()
@@ -508,29 +504,31 @@ class Population(Constants):
     def _initial_tallies(self, geometry, phonon, pos, modes, occ):
         """calculate_energy / calculate_heat_flux / calculate_kappa on the initial state (Population.py:282, :318-321)."""
         S = self.n_of_subvols
-        w = self.nranks            # with several ranks the t = 0 row is extrapolated from this rank's share
-        self.subvol_N_p = np.bincount(self.subvol_id, minlength=S).astype(np.int64) * w
-        self.N_p = int(self.subvol_N_p.sum())
         om = phonon.omega[modes[:, 0], modes[:, 1]]
         if self.T_reference == 'local':
             dn = occ - phonon.calculate_occupation(self.subvol_temperature[self.subvol_id], om)
-            ref = phonon.crystal_energy_function(self.subvol_temperature)
         else:
             dn = occ - self.reference_occupation[modes[:, 0], modes[:, 1]]
-            ref = self.ref_en_density
         e = self.hbar * om * dn
-        self.total_energy = float(e.sum()) * w
-        E_raw = np.bincount(self.subvol_id, weights=e, minlength=S) * w
+        E_raw = np.bincount(self.subvol_id, weights=e, minlength=S)
         v = phonon.group_vel[modes[:, 0], modes[:, 1], :]
-        flux_raw = np.stack([np.bincount(self.subvol_id, weights=v[:, d] * e, minlength=S) for d in range(3)], axis=1) * w
-        self.subvol_energy = self._normalise_energy(phonon, E_raw, self.subvol_N_p) + ref
-        self.subvol_heat_flux = self._normalise_flux(phonon, flux_raw, self.subvol_N_p)
-        self.calculate_kappa(geometry)
+        flux_raw = np.stack([np.bincount(self.subvol_id, weights=v[:, d] * e, minlength=S) for d in range(3)], axis=1)
+        N_sv = np.bincount(self.subvol_id, minlength=S).astype(float)
         del self.subvol_id
+        self._finish_initial_tallies(geometry, phonon, E_raw, N_sv, flux_raw)
 
     def _finish_initial_tallies(self, geometry, phonon, E_raw, N_sv, flux_raw):
-        """The same from the engine's tally of the particles it created (nk_tally_state: this rank's sums)."""
-        w = self.nranks
+        """The t = 0 row from this rank's sums (the host's, or the engine's tally of the particles it created, nk_tally_state).
+        With several ranks the sums are all-reduced over the communicator -- a rank's shard is a run of consecutive ids, which
+        under 'random_subvol' covers only some of the subvolumes; only a run without communicator (NK_COMM_DRYRUN, a test
+        hook) extrapolates from its own share."""
+        w = 1
+        if self.nranks > 1:
+            info = self.engine.comm_info() if hasattr(self.engine, 'comm_info') else {'comm_nranks': 0}
+            if info['comm_nranks'] == self.nranks:
+                E_raw, N_sv, flux_raw = self.engine.comm_allreduce(E_raw, N_sv, flux_raw)
+            else:
+                w = self.nranks
         self.subvol_N_p = np.rint(N_sv).astype(np.int64) * w
         self.N_p = int(self.subvol_N_p.sum())
         ref = phonon.crystal_energy_function(self.subvol_temperature) if self.T_reference == 'local' else self.ref_en_density
@@ -538,7 +536,7 @@ class Population(Constants):
         with np.errstate(invalid='ignore', divide='ignore'):
             self.subvol_energy = self._normalise_energy(phonon, E_raw * w, self.subvol_N_p) + ref
             self.subvol_heat_flux = self._normalise_flux(phonon, flux_raw * w, self.subvol_N_p)
-        # a rank's shard (consecutive ids) need not reach every subvolume: its t = 0 row has nothing to say about those
+        # subvolumes without particles (empty_subvols; a dry-run shard that does not reach them): nothing to say about those
         empty = self.subvol_N_p == 0
         self.subvol_energy = np.where(empty, ref, self.subvol_energy)
         self.subvol_heat_flux = np.where(empty[:, None], 0.0, self.subvol_heat_flux)
@@ -787,13 +785,19 @@ class Population(Constants):
         """particle_data.txt and subvolumes.txt, formats of Population.py:2071-2151."""
         time = datetime.now().strftime('%Y-%m-%dT%H:%M:%S.%f')
         p = self.particles()
+        # the reference's header (Population.py:2071-2086); the per-rank files of a run on several ranks (this package's own
+        # extension) carry one more line, the timestep and which shard this is: a resume checks that they belong together
         header = ('Particles final state data \n' + 'Date and time: {}\n'.format(time) +
                   'hdf file = {}, POSCAR file = {}\n'.format(self.args.hdf_file, self.args.poscar_file) +
+                  ('timestep = {}, rank = {} of {}\n'.format(int(self.current_timestep), self.rank, self.nranks) if self.nranks > 1 else '') +
                   'q-point, branch, pos x [angs], pos y [angs], pos z [angs], occupation')
         data = np.hstack((p['modes'], p['positions'], p['occupation'].reshape(-1, 1)))
         name = 'particle_data.txt' if self.nranks == 1 else 'particle_data.rank%dof%d.txt' % (self.rank, self.nranks)
-        np.savetxt(os.path.join(self.results_folder_name, name), data, '%d, %d, %.3f, %.3f, %.3f, %.6e',
-                   delimiter=',', header=header)
+        # written under a temporary name and renamed: a crash never leaves half a checkpoint under the real name
+        final = os.path.join(self.results_folder_name, name)
+        tmp = final + '.tmp%d' % os.getpid()
+        np.savetxt(tmp, data, '%d, %d, %.3f, %.3f, %.3f, %.6e', delimiter=',', header=header)
+        os.replace(tmp, final)
         if self.rank != 0:
             return
         if self.current_timestep > 0 and geometry.subvol_type == 'slice' and hasattr(self.view, 'mean_T'):
@@ -836,6 +840,51 @@ class Population(Constants):
     def save_plot_real_time(self):
         """Called by the reference driver (nanokappa.py:105) but defined nowhere there; a no-op here."""
         return None
+
+
+def resume_files(key):
+    """The particle files a resume (--part_dist <file>, Population.py:284-306) reads: EITHER the single file `key` OR the
+    complete family `<stem>.rank<r>of<N><ext>` of ONE N that a run on N ranks left beside it -- never a mixture (a folder
+    that holds both, rank files of two different N, a missing rank, or rank files written at different timesteps is an
+    error: stacking them would duplicate or lose particles silently)."""
+    import re
+    stem, ext = os.path.splitext(key)
+    fam = {}
+    for f in glob.glob(glob.escape(stem) + '.rank*of*' + glob.escape(ext)):
+        m = re.match(re.escape(stem) + r'\.rank(\d+)of(\d+)' + re.escape(ext) + '$', f)
+        if m:
+            fam.setdefault(int(m.group(2)), {})[int(m.group(1))] = f
+    single = os.path.exists(key)
+    if single and fam:
+        raise Exception('Ambiguous particle data: %s exists beside per-rank files %s; keep one checkpoint only.'
+                        % (key, sorted(f for d in fam.values() for f in d.values())))
+    if single:
+        return [key]
+    if not fam:
+        raise Exception('Wrong particle data file. Change the keyword or check whether the file exists.')
+    if len(fam) > 1:
+        raise Exception('Ambiguous particle data: per-rank files of runs with different rank counts (%s) beside %s.'
+                        % (sorted(fam), key))
+    (n, files), = fam.items()
+    missing = [r for r in range(n) if r not in files]
+    if missing:
+        raise Exception('Incomplete particle data: rank file(s) %s of %d missing beside %s.' % (missing, n, key))
+    steps = set()
+    for r in range(n):
+        with open(files[r]) as fh:
+            head = [next(fh, '') for _ in range(6)]
+        ts = [re.search(r'timestep = (\d+), rank = (\d+) of (\d+)', h) for h in head]
+        ts = [t for t in ts if t]
+        if ts:
+            if (int(ts[0].group(2)), int(ts[0].group(3))) != (r, n):
+                raise Exception('%s says it is rank %s of %s.' % (files[r], ts[0].group(2), ts[0].group(3)))
+            steps.add(int(ts[0].group(1)))
+        else:
+            steps.add(None)                  # file of an older version: no timestep line
+    if len(steps) > 1:
+        raise Exception('Inconsistent particle data: the rank files beside %s were written at different timesteps (%s).'
+                        % (key, sorted(str(t) for t in steps)))
+    return [files[r] for r in range(n)]
 
 
 def _phonon_tables(ph):

@@ -19,6 +19,8 @@ def test_cpu_baselines_run():
     ph = Phonon(args, 0, material=synthetic.make_material(5, 'Si', temperatures=np.arange(200.0, 401.0, 50.0)))
     psteps, dt, steps = bench._oracle_run(geo, ph, 20000, 3, 0.5, 5)
     assert steps >= 1 and psteps > 10000 and dt > 0
-    r = bench.cpu_baseline_all_cores(geo, ph, 5, seconds_target=0.5)
+    r = bench.cpu_baseline_all_cores(geo, ph, 5, 'box 200 A, T T P', seconds_target=0.5)
     if r is not None:                      # a single-core host has no such leg
         assert r['cores'] >= 2 and r['value'] > 0 and r['kind'] == 'port' and 'worker processes' in r['sample']
+    one = bench.cpu_baseline(geo, ph, 5, 'box 200 A, T T P', n=20000, seconds_target=0.5)
+    assert one['cores'] == 1 and one['value'] > 0 and '20000 particles' in one['sample']

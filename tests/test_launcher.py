@@ -53,5 +53,29 @@ def test_self_launch_starts_n_ranks_and_reports_failure():
                        timeout=300)
     from nanokappa_amd.engine import device_count
     if device_count() == 0:
-        assert p.returncode != 0 and 'rank 0' in p.stderr and 'rank 1' in p.stderr
+        assert p.returncode != 0 and ('rank 0 rc' in p.stderr or 'rank 1 rc' in p.stderr)
         assert '"n_gpus"' not in p.stdout
+
+
+def test_self_launch_stops_the_survivors_when_a_rank_dies():
+    """A rank that dies while its peer waits (in a collective, on real hardware) must not leave the parent waiting: the
+    parent stops the survivor, exits non-zero and names the dead rank.  NK_BENCH_TEST_HOOK makes rank 1 exit with code 3 at
+    once and rank 0 sleep for ten minutes."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    env['NK_BENCH_TEST_HOOK'] = 'rank1_dies_rank0_hangs'
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and 'rank 1 rc 3' in p.stderr and 'stopped' in p.stderr
+    assert time.time() - t0 < 60
+
+
+def test_self_launch_deadline():
+    """Every rank hanging: the overall deadline ends the run."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE')}
+    env['NK_BENCH_TEST_HOOK'] = 'all_hang'
+    env['NK_BENCH_DEADLINE'] = '3'
+    p = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1'], env=env,
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode != 0 and 'deadline' in p.stderr

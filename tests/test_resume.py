@@ -52,3 +52,42 @@ def test_resume_from_particle_data_file(tmp_path):
     assert np.abs(pop2.subvol_temperature - 298.0).max() > 0.5              # not the 'cold' start of --temp_dist
     pop2.run(20, geo2, ph2)
     assert abs(pop2.N_p - N_run) < 0.02 * N_run
+
+
+def test_resume_files_are_one_consistent_set(tmp_path):
+    """A resume reads EITHER the single file OR the complete rank family of one run -- never a mixture (files of
+    different rank counts, or a single file beside rank files, were stacked into one ensemble with duplicated particles)."""
+    import pytest
+    from nanokappa_amd.population import resume_files
+    d = str(tmp_path)
+    key = os.path.join(d, 'particle_data.txt')
+
+    def rank_file(r, n, step):
+        f = os.path.join(d, 'particle_data.rank%dof%d.txt' % (r, n))
+        with open(f, 'w') as fh:
+            fh.write('# Particles final state data \n# Date and time: x\n# hdf file = a, POSCAR file = b\n'
+                     '# timestep = %d, rank = %d of %d\n# q-point, branch, ...\n0, 0, 1.000, 1.000, 1.000, 1.0e+00\n' % (step, r, n))
+        return f
+
+    with pytest.raises(Exception, match='Wrong particle data file'):
+        resume_files(key)
+    a, b = rank_file(0, 2, 300), rank_file(1, 2, 300)
+    assert resume_files(key) == [a, b]
+    rank_file(1, 2, 400)                                   # a crash between the ranks' writes
+    with pytest.raises(Exception, match='different timesteps'):
+        resume_files(key)
+    rank_file(1, 2, 300)
+    c = rank_file(0, 4, 300)                               # left over from another run
+    with pytest.raises(Exception, match='different rank counts'):
+        resume_files(key)
+    os.remove(c)
+    os.remove(b)
+    with pytest.raises(Exception, match='missing'):
+        resume_files(key)
+    rank_file(1, 2, 300)
+    open(key, 'w').write('# single\n0, 0, 1.0, 1.0, 1.0, 1.0\n')
+    with pytest.raises(Exception, match='Ambiguous'):
+        resume_files(key)
+    os.remove(a)
+    os.remove(os.path.join(d, 'particle_data.rank1of2.txt'))
+    assert resume_files(key) == [key]
