@@ -5,8 +5,12 @@
 // or the caller asks for it -- a 64-bit particle id that keys the counter-based RNG: 44 or 52 bytes per particle.
 // The store is split into `nseg` equal segments; a segment holds its live particles contiguously from its start and is
 // owned by one wave at a time.
-// Modes are PARTITIONED over the segments: mode m belongs to segment m % nseg and is stored as the local index m / nseg
-// (a few bits).  A segment therefore only ever touches its own few dozen 64-byte mode records (they sit contiguously in a
+// Modes are PARTITIONED over the segments: every mode has a slot = local index * nseg + segment (NkDev::m2s / s2m) and is
+// stored as its local index (a few bits).  The slots are dealt on the host (nk_build_mode_map) in the order of the modes'
+// boundary-event rate, back and forth over the segments, so that every segment gets the same number of modes AND the same
+// share of fast and slow ones: a wave owns a segment for a whole sweep, and with "segment = m % nseg" a segment count that
+// is a multiple of the branch count gave every segment ONE branch -- events per segment between 4 and 22 per step around a
+// mean of 8.6 in the 200 A box, the slowest wave 1.45 x the mean (profiles/r03_notes.txt).  A segment therefore only ever touches its own few dozen 64-byte mode records (they sit contiguously in a
 // permuted copy of the mode table and stay in L1/L2), and it emits the reservoir particles of its own modes itself: no
 // spawn list, no global atomics, no gathers across an 11 MB table.  (With rough facets a reflection changes the mode: such a
 // particle finishes its step where it is and then migrates to the owning segment through that segment's inbox, k_deliver.)
@@ -60,7 +64,9 @@ struct NkDev {
     // ---- material
     int32_t Q, J, NT, M;              // M = Q*J
     const NkMode *modetab;            // [M] by mode index
-    const NkMode *modetab_p;          // [nseg * nlmax] permuted copy: record of mode m at (m % nseg) * nlmax + m / nseg
+    const NkMode *modetab_p;          // [nseg * nlmax] permuted copy: record of the mode with slot l * nseg + s at s * nlmax + l
+    const int32_t *m2s;               // [M] slot of a mode (slot % nseg = its segment, slot / nseg = its local index there)
+    const int32_t *s2m;               // [nseg * nlmax] mode of (segment s, local index l) at s * nlmax + l; -1 where there is none
     int32_t tau_row0;                 // first T_grid row held in NkMode::tau
     double tau_g[NK_TAU_ROWS];        // T_grid[tau_row0 .. tau_row0+2] by value (scalar registers, no loads)
     double tau_ig[NK_TAU_ROWS - 1];   // 1 / (g[k+1] - g[k]) of the two packed intervals
@@ -145,7 +151,7 @@ struct NkDev {
     int32_t *seg_new;                 // [nseg] particles k_emit appended behind them at this step (the sweep takes them in)
     int32_t *seg_bound;               // [nseg] upper bound of the particles that can enter the segment in one step
     double *x, *y, *z, *occ, *nts;
-    uint32_t *w0;                     // newborn << 31 | (facet + 1) << lb | idx;  idx = mode / nseg (part) or the mode itself;
+    uint32_t *w0;                     // newborn << 31 | (facet + 1) << lb | idx;  idx = the mode's local index in its segment (part) or the mode itself;
                                       // newborn: appended by k_emit at this step (no relaxation, no drift yet)
     uint64_t *pid;                    // null: particle ids are not tracked (no per-particle random draws in this configuration)
     int32_t part;                     // 1: idx is the local index of a mode of the owning segment; 0: the global mode index
@@ -331,7 +337,8 @@ __device__ __forceinline__ double nk_E_of_T(const NkDev &d, double T) {
 // lifetime_function = RegularGridInterpolator((T,q,j), tau) at integer (q,j): linear in tau along T (Phonon.py:336).
 // Out-of-table T gives NaN (the reference raises ValueError there).  ta, tb, tc are the three rows packed into the
 // particle's mode record (two grid intervals around the live temperature range); anything else reads the full table.
-__device__ __forceinline__ double nk_lifetime(const NkDev &d, double ta, double tb, double tc, double T, int mode) {
+template <class SegModes>
+__device__ __forceinline__ double nk_lifetime(const NkDev &d, double ta, double tb, double tc, double T, const SegModes &sm, int idx) {
     // Fast path: T inside the packed window (g0, g2].  searchsorted-left - 1 puts T in (g_k, g_k+1] at interval k; grid
     // values and reciprocal widths come from scalar registers, lifetimes from the mode record.
     if (T > d.tau_g[0] && T <= d.tau_g[2]) {
@@ -352,6 +359,7 @@ __device__ __forceinline__ double nk_lifetime(const NkDev &d, double ta, double 
     i -= 1;
     i = i < 0 ? 0 : (i > NT - 2 ? NT - 2 : i);
     const double y = (T - g[i]) / (g[i + 1] - g[i]);
+    const int mode = sm.mode(idx);                   // (the global mode index is only read here, outside the packed window)
     const double t0 = d.tau[(int64_t)i * d.M + mode];
     const double t1 = d.tau[(int64_t)(i + 1) * d.M + mode];
     return t0 * (1.0 - y) + t1 * y;
@@ -814,6 +822,8 @@ struct NkBins {
 struct NkParticle {
     double x, y, z, occ, nts, omega, E0, vx, vy, vz;
     int mode, facet;          // mode: the GLOBAL mode index
+    int slot;                 // rough facets, partitioned modes: the mode's slot (segment, local index); a reflection reads the
+                              // new one from m2s together with the new mode's record (no memory round trip of its own)
 };
 
 // Boundary events inside a timestep: Population.boundary_scattering (Population.py:1546-1683) restated per particle.
@@ -869,6 +879,7 @@ __device__ __forceinline__ int nk_event_pre(const NkDev &d, const NkFacet *facet
         nk_reflect<RBF>(d, tb, fc.rough, p.mode, cx, cy, cz, p.occ, p.omega, p.E0, r0, r1, r1, mo, no, oo, eo);
         p.mode = mo; p.occ = no; p.omega = oo; p.E0 = eo;
         const NkMode *rec = d.modetab + mo;
+        if (d.part) p.slot = d.m2s[mo];
         p.vx = rec->vx; p.vy = rec->vy; p.vz = rec->vz;
     }
     return NK_EV_MORE;

@@ -66,6 +66,10 @@ struct nk_ctx {
     std::vector<int32_t> rb_facet;
     int64_t o2o_first = 0;            // 'one_to_one': particles entering at the first step (sizes the spawn inboxes)
     bool stepped = false;             // a timestep has run (the emission ownership of a rank is fixed from then on)
+    std::vector<double> h_vg;         // host copy of the group velocities (the mode map deals the modes by their event rate)
+    std::vector<int32_t> h_m2s, h_s2m;  // host copies of the mode map (NkDev::m2s / s2m), built with the segmentation
+    int32_t *m2s_dev = nullptr, *s2m_dev = nullptr;
+    int map_nseg = 0;                 // segmentation the map was dealt for
     NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
     int64_t modetab_p_len = 0;
     void *inbox = nullptr, *inbox_n = nullptr;   // 'one_to_one' spawn inboxes (sized with nseg)
@@ -193,7 +197,7 @@ static int nk_update_tau_window(nk_ctx *ctx, bool force) {
     d.invT0 = 1.0 / d.T0;
     d.c_hk = d.hbar / d.kb;
     NkMode *tp = nullptr;
-    if (d.part && d.nseg > 0) {
+    if (d.part && d.nseg > 0 && d.m2s) {
         const int64_t need = (int64_t)d.nseg * d.nlmax;
         if (need > ctx->modetab_p_len) {
             if (ctx->modetab_p) hipFree(ctx->modetab_p);
@@ -206,7 +210,7 @@ static int nk_update_tau_window(nk_ctx *ctx, bool force) {
     }
     d.modetab_p = tp;
     k_build_modetab<<<(d.M + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_omega, ctx->d_vg, d.tau, d.M, d.NT, row0, d.c_hk, d.invT0,
-                                                                  d.nseg > 0 ? d.nseg : 1, d.nlmax, (NkMode *)d.modetab, tp);
+                                                                  d.nseg > 0 ? d.nseg : 1, d.nlmax, d.m2s, (NkMode *)d.modetab, tp);
     NK_HIP(hipGetLastError());
     d.tau_row0 = row0;
     ctx->timing.tau_rebuilds += 1;
@@ -300,6 +304,8 @@ void nk_destroy(nk_ctx *ctx) {
     if (ctx->acc) hipFree(ctx->acc);
     if (ctx->hist) hipFree(ctx->hist);
     if (ctx->modetab_p) hipFree(ctx->modetab_p);
+    if (ctx->m2s_dev) hipFree(ctx->m2s_dev);
+    if (ctx->s2m_dev) hipFree(ctx->s2m_dev);
     if (ctx->inbox) hipFree(ctx->inbox);
     if (ctx->inbox_n) hipFree(ctx->inbox_n);
     if (ctx->mig_buf) hipFree(ctx->mig_buf);
@@ -319,6 +325,7 @@ int nk_set_material(nk_ctx *ctx, const nk_material *m) {
     for (int i = 1; i < m->NT; ++i) NK_ARG(m->T_grid[i] > m->T_grid[i - 1], "nk_set_material: T_grid must ascend");
     NK_UP(m->omega, (size_t)d.M, &ctx->d_omega);
     NK_UP(m->group_vel, (size_t)d.M * 3, &ctx->d_vg);
+    ctx->h_vg.assign(m->group_vel, m->group_vel + (size_t)d.M * 3);
     NK_UP((const NkMode *)nullptr, (size_t)d.M, &d.modetab);
     NK_UP(m->lifetime, (size_t)d.NT * d.M, &d.tau);
     NK_UP(m->T_grid, (size_t)d.NT, &d.Tgrid);
@@ -686,7 +693,7 @@ static int nk_entry_tables_drop(nk_ctx *ctx, bool keep_counters) {
     if (ctx->rm_nseg > 0 && keep_counters && d.R > 0 && d.res_counter) {
         const int64_t n = (int64_t)d.R * d.M;
         k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(0, d.R, d.M, ctx->rm_nseg, (d.M + ctx->rm_nseg - 1) / ctx->rm_nseg,
-                                                                   d.res_counter, ctx->rc_p);
+                                                                   d.m2s, d.res_counter, ctx->rc_p);      // (the map the tables were built with)
         NK_HIP(hipGetLastError());
         NK_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -698,7 +705,7 @@ static int nk_entry_tables_drop(nk_ctx *ctx, bool keep_counters) {
 }
 static int nk_entry_tables_build(nk_ctx *ctx) {
     NkDev &d = ctx->d;
-    if (!(d.R > 0 && d.nseg > 0 && d.enter_prob && d.res_counter) || ctx->rm_nseg == d.nseg) return NK_OK;
+    if (!(d.R > 0 && d.nseg > 0 && d.m2s && d.enter_prob && d.res_counter) || ctx->rm_nseg == d.nseg) return NK_OK;
     int rc = nk_entry_tables_drop(ctx, true);
     if (rc) return rc;
     const size_t len = (size_t)d.nseg * d.R * d.nlmax;
@@ -707,8 +714,8 @@ static int nk_entry_tables_build(nk_ctx *ctx) {
     NK_HIP(hipMemsetAsync(ctx->ep_p, 0, len * 8, ctx->stream));
     NK_HIP(hipMemsetAsync(ctx->rc_p, 0, len * 8, ctx->stream));
     const int64_t n = (int64_t)d.R * d.M;
-    k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, (double *)d.enter_prob, ctx->ep_p);
-    k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, d.res_counter, ctx->rc_p);
+    k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, d.m2s, (double *)d.enter_prob, ctx->ep_p);
+    k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, d.m2s, d.res_counter, ctx->rc_p);
     NK_HIP(hipGetLastError());
     d.ep_p = ctx->ep_p; d.rc_p = ctx->rc_p;
     ctx->rm_nseg = d.nseg;
@@ -950,7 +957,7 @@ static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
     for (int sgm = 0; sgm < d.nseg; ++sgm)
         for (int j = 0; j < cnt[sgm]; ++j, ++k) {
             const uint32_t idx = w0[(size_t)k] & lbmask;
-            h.mode[(size_t)k] = d.part ? (int32_t)((int64_t)idx * d.nseg + sgm) : (int32_t)idx;
+            h.mode[(size_t)k] = d.part ? ctx->h_s2m[(size_t)sgm * d.nlmax + idx] : (int32_t)idx;
             h.facet[(size_t)k] = (int32_t)(w0[(size_t)k] >> d.lb) - 1;
         }
     return NK_OK;
@@ -966,11 +973,12 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
     std::vector<int64_t> order((size_t)N);
     std::vector<int64_t> start((size_t)d.nseg + 1, 0);
     if (d.part) {
-        for (int64_t i = 0; i < N; ++i) start[(size_t)(mode[i] % d.nseg) + 1] += 1;
+        const std::vector<int32_t> &m2s = ctx->h_m2s;
+        for (int64_t i = 0; i < N; ++i) start[(size_t)(m2s[(size_t)mode[i]] % d.nseg) + 1] += 1;
         for (int sgm = 0; sgm < d.nseg; ++sgm) start[(size_t)sgm + 1] += start[(size_t)sgm];
         // inside a segment: by local mode index (stable), so that a tile shares a few records
         std::vector<int64_t> key((size_t)N);
-        for (int64_t i = 0; i < N; ++i) { order[(size_t)i] = i; key[(size_t)i] = (int64_t)(mode[i] % d.nseg) * ((int64_t)d.nlmax + 1) + mode[i] / d.nseg; }
+        for (int64_t i = 0; i < N; ++i) { order[(size_t)i] = i; key[(size_t)i] = (int64_t)(m2s[(size_t)mode[i]] % d.nseg) * ((int64_t)d.nlmax + 1) + m2s[(size_t)mode[i]] / d.nseg; }
         std::stable_sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return key[(size_t)a] < key[(size_t)b]; });
     } else {
         std::vector<int64_t> mstart((size_t)M + 1, 0);               // counting sort by mode
@@ -1010,7 +1018,7 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
         for (int64_t i = 0; i < N; ++i) {
             const int32_t fc = facet ? facet[i] : -1;
             NK_ARG(fc >= -1 && fc < d.Fc, "nk_upload_particles: facet index out of range");
-            const uint32_t idx = d.part ? (uint32_t)(mode[i] / d.nseg) : (uint32_t)mode[i];
+            const uint32_t idx = d.part ? (uint32_t)(ctx->h_m2s[(size_t)mode[i]] / d.nseg) : (uint32_t)mode[i];
             w0[(size_t)i] = ((uint32_t)(fc + 1) << d.lb) | idx;
         }
         if ((rc = put(w0.data(), 4, d.w0))) return rc;
@@ -1063,6 +1071,50 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     return ctx->g_sweep;
 }
 
+// The segment that owns mode m (host copy of the mode map; before a map exists for this segmentation: the plain deal).
+static inline int nk_mode_seg(const nk_ctx *ctx, int m, int nseg) {
+    return (ctx->map_nseg == nseg && !ctx->h_m2s.empty()) ? ctx->h_m2s[(size_t)m] % nseg : m % nseg;
+}
+
+// Deal the modes over the segments (NkDev::m2s / s2m, nk_device.h): in the order of their boundary-event rate -- per step
+// sum_a |v_a| dt / extent_a of the mesh's bounding box --, round by round, forwards and backwards alternately, so that every
+// segment gets M / nseg modes (+1) and an equal share of fast and slow ones; modes that cannot move (never populated) last.
+static int nk_build_mode_map(nk_ctx *ctx) {
+    NkDev &d = ctx->d;
+    if (ctx->m2s_dev) { hipFree(ctx->m2s_dev); ctx->m2s_dev = nullptr; }
+    if (ctx->s2m_dev) { hipFree(ctx->s2m_dev); ctx->s2m_dev = nullptr; }
+    d.m2s = nullptr; d.s2m = nullptr;
+    ctx->h_m2s.clear(); ctx->h_s2m.clear(); ctx->map_nseg = 0;
+    if (d.M <= 0 || d.nseg <= 0) return NK_OK;
+    const int M = d.M, nseg = d.nseg, nlmax = d.nlmax;
+    std::vector<double> w((size_t)M, 0.0);
+    const bool plain = !d.part;          // developer probe without the partition: the modes' emission is dealt m % nseg, forwards
+    if (!plain && ctx->have_mesh && ctx->h_vg.size() == (size_t)M * 3) {
+        double inv[3];
+        for (int a = 0; a < 3; ++a) { const double e = d.bbox[3 + a] - d.bbox[a]; inv[a] = e > 0.0 ? 1.0 / e : 0.0; }
+        for (int m = 0; m < M; ++m)
+            w[(size_t)m] = fabs(ctx->h_vg[3 * (size_t)m]) * inv[0] + fabs(ctx->h_vg[3 * (size_t)m + 1]) * inv[1] + fabs(ctx->h_vg[3 * (size_t)m + 2]) * inv[2];
+    }
+    std::vector<int32_t> order((size_t)M);
+    for (int m = 0; m < M; ++m) order[(size_t)m] = m;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return w[(size_t)a] > w[(size_t)b]; });
+    ctx->h_m2s.assign((size_t)M, 0);
+    ctx->h_s2m.assign((size_t)nseg * nlmax, -1);
+    for (int k = 0; k < M; ++k) {
+        const int round = k / nseg, pos = k - round * nseg;
+        const int seg = (!plain && (round & 1)) ? nseg - 1 - pos : pos;
+        ctx->h_m2s[(size_t)order[(size_t)k]] = round * nseg + seg;
+        ctx->h_s2m[(size_t)seg * nlmax + round] = order[(size_t)k];
+    }
+    NK_HIP(hipMalloc((void **)&ctx->m2s_dev, (size_t)M * 4));
+    NK_HIP(hipMalloc((void **)&ctx->s2m_dev, (size_t)nseg * nlmax * 4));
+    NK_HIP(hipMemcpy(ctx->m2s_dev, ctx->h_m2s.data(), (size_t)M * 4, hipMemcpyHostToDevice));
+    NK_HIP(hipMemcpy(ctx->s2m_dev, ctx->h_s2m.data(), (size_t)nseg * nlmax * 4, hipMemcpyHostToDevice));
+    d.m2s = ctx->m2s_dev; d.s2m = ctx->s2m_dev;
+    ctx->map_nseg = nseg;
+    return NK_OK;
+}
+
 // Upper bound of the particles that can enter one segment in one step (the sweep's halt criterion uses the same sum).
 static int64_t nk_spawn_bound(const nk_ctx *ctx, int nseg) {
     const NkDev &d = ctx->d;
@@ -1070,7 +1122,7 @@ static int64_t nk_spawn_bound(const nk_ctx *ctx, int nseg) {
     if (d.res_gen == 2) return 4 * (ctx->o2o_first / std::max(nseg, 1) + 64);
     std::vector<int64_t> per((size_t)nseg, 0);
     for (int r = 0; r < d.R; ++r)
-        for (int m = 0; m < d.M; ++m) per[(size_t)(m % nseg)] += (int64_t)floor(ctx->h_enter_prob[(size_t)r * d.M + m]) + 1;
+        for (int m = 0; m < d.M; ++m) per[(size_t)(nk_mode_seg(ctx, m, nseg))] += (int64_t)floor(ctx->h_enter_prob[(size_t)r * d.M + m]) + 1;
     int64_t mx = 0;
     for (int64_t v : per) mx = std::max(mx, v);
     return (mx + d.nranks - 1) / d.nranks + d.R;
@@ -1119,6 +1171,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         if (same) break;
     }
     NK_ARG(d.nlmax < (1 << 14), "too many modes per segment for k_emit's packed entry word: use more particles (segments) or fewer modes");
+    { int rcm = nk_build_mode_map(ctx); if (rcm) return rcm; }
     {   // bits of the stored mode index; the rest of the 32-bit word holds facet + 1
         const int64_t maxidx = d.part ? d.nlmax - 1 : (d.M > 0 ? d.M - 1 : 0);
         int lb = 1;
@@ -1129,8 +1182,8 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     int64_t segcap = (capacity + nseg - 1) / nseg;
     if (d.part && (mode || umodes) && N > 0) {           // room for the fullest segment of this population + a step's arrivals
         std::vector<int64_t> per((size_t)nseg, 0);
-        if (mode) { for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0) per[(size_t)(mode[i] % nseg)] += 1; }
-        else for (int64_t u = 0; u < nu; ++u) per[(size_t)(umodes[u] % nseg)] += nk_tiled_count(u, nu, pid_lo, N);
+        if (mode) { for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0 && mode[i] < d.M) per[(size_t)nk_mode_seg(ctx, mode[i], (int)nseg)] += 1; }
+        else for (int64_t u = 0; u < nu; ++u) per[(size_t)nk_mode_seg(ctx, umodes[u], (int)nseg)] += nk_tiled_count(u, nu, pid_lo, N);
         int64_t mx = 0;
         for (int64_t v : per) mx = std::max(mx, v);
         segcap = std::max(segcap, mx + mx / 4 + 64);
@@ -1163,7 +1216,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         NK_PALLOC(int32_t, seg_evq, pi, 2 * (size_t)d.nseg + 1);
     }
 #ifdef NK_STAMPS
-    { const unsigned long long *ps; int rc_ = nk_upload<unsigned long long>(ctx, nullptr, (size_t)d.nseg * 8, &ps, true); if (rc_) return rc_; d.stamps = (unsigned long long *)ps; }
+    { const unsigned long long *ps; int rc_ = nk_upload<unsigned long long>(ctx, nullptr, (size_t)d.nseg * 16, &ps, true); if (rc_) return rc_; d.stamps = (unsigned long long *)ps; }
 #endif
 #undef NK_PALLOC
     ctx->layout_key = (d.part ? 1 : 0) | (d.pid ? 2 : 0) | (d.qx ? 4 : 0);
@@ -1289,7 +1342,7 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     bool fits = d.cap > 0 && ctx->layout_key == ((nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0) | (nk_want_split(ctx) ? 4 : 0)) && N + N / 5 + 1024 <= d.cap;
     if (fits && d.part) {                              // every segment must hold its modes' particles with head room
         std::vector<int64_t> per((size_t)d.nseg, 0);
-        for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0) per[(size_t)(mode[i] % d.nseg)] += 1;
+        for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0 && mode[i] < d.M) per[(size_t)nk_mode_seg(ctx, mode[i], d.nseg)] += 1;
         const int64_t room = (int64_t)d.segcap - nk_spawn_bound(ctx, d.nseg) - 2 * NK_TILE;
         for (int64_t v : per) fits = fits && v + v / 16 <= room;
     }
@@ -1462,11 +1515,40 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     NK_HIP(hipMemcpy(h.data(), ctx->hist, h.size() * sizeof(double), hipMemcpyDeviceToHost));
 #ifdef NK_STAMPS
     if (d.stamps) {                                     // developer build: section shares of the LAST sweep of the batch
-        std::vector<unsigned long long> st((size_t)d.nseg * 8);
+        std::vector<unsigned long long> st((size_t)d.nseg * 16);
         NK_HIP(hipMemcpy(st.data(), d.stamps, st.size() * 8, hipMemcpyDeviceToHost));
         double sum[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int sgm = 0; sgm < d.nseg; ++sgm) for (int k = 0; k < 7; ++k) sum[k] += (double)st[(size_t)sgm * 8 + k];
         double tot = 0; for (int k = 0; k < 6; ++k) tot += sum[k];
+        {   // in-kernel shader clock of the sweep (s_memtime against the 100 MHz s_memrealtime, per segment; median)
+            std::vector<unsigned long long> clk;
+            for (int sgm = 0; sgm < d.nseg; ++sgm) clk.push_back(st[(size_t)sgm * 8 + 7]);
+            std::sort(clk.begin(), clk.end());
+            // wall-clock marks (10 ns ticks of the 100 MHz counter): where the launch's time goes outside the tile loops
+            unsigned long long e0 = ~0ull, x1 = 0;
+            std::vector<double> pro, loop, epi, fin;
+            for (int sgm = 0; sgm < d.nseg; ++sgm) {
+                const unsigned long long *w = &st[((size_t)d.nseg + sgm) * 8];
+                if (!w[0] || !w[3]) continue;
+                e0 = std::min(e0, w[0]); x1 = std::max(x1, w[3]);
+            }
+            for (int sgm = 0; sgm < d.nseg; ++sgm) {
+                const unsigned long long *w = &st[((size_t)d.nseg + sgm) * 8];
+                if (!w[0] || !w[3]) continue;
+                pro.push_back((double)(w[1] - w[0]) * 0.01); loop.push_back((double)(w[2] - w[1]) * 0.01);
+                epi.push_back((double)(w[3] - w[2]) * 0.01); fin.push_back((double)(w[3] - e0) * 0.01);
+            }
+            auto q = [](std::vector<double> v, const char *nm) {
+                if (v.empty()) return;
+                std::sort(v.begin(), v.end());
+                double sm = 0; for (double x : v) sm += x;
+                fprintf(stderr, "[stamps] %s [us]: min %.1f  p10 %.1f  median %.1f  mean %.1f  p90 %.1f  max %.1f\n", nm, v.front(), v[v.size() / 10], v[v.size() / 2], sm / v.size(), v[v.size() * 9 / 10], v.back());
+            };
+            fprintf(stderr, "[stamps] first entry -> last exit: %.1f us over %zu waves\n", (double)(x1 - e0) * 0.01, pro.size());
+            q(pro, "entry -> tile loop (tables into LDS, records)"); q(loop, "tile loop"); q(epi, "tile loop end -> wave through (flush, workgroup barrier, tally row)");
+            q(fin, "wave through, after the first entry");
+            fprintf(stderr, "[stamps] shader clock inside k_sweep: median %.0f MHz (min %.0f, max %.0f)\n", clk[clk.size() / 2] / 10.0, clk.front() / 10.0, clk.back() / 10.0);
+        }
         fprintf(stderr, "[stamps] cycles per tile: arrive %.0f  relax+drift %.0f  tally+store %.0f  pack/merge %.0f  event %.0f  event tally/store/repack %.0f  | total %.0f (tiles %.0f)\n",
                 sum[0] / sum[6], sum[1] / sum[6], sum[2] / sum[6], sum[3] / sum[6], sum[4] / sum[6], sum[5] / sum[6], tot / sum[6], sum[6]);
         if (d.qx) {                                     // split sweep: k_events' per-segment clocks (words 3-5)

@@ -98,8 +98,8 @@ struct NkLds {
 #define NK_OUT_RING 0        // 1: finished particles go through an LDS ring and leave in whole aligned tiles (NkOut below)
 #endif
 #define NK_ORING (NK_OUT_RING ? 128 : 0)
-// doubles of one wave's carry: x y z occ nts cts (64 each), w0 + evc (64 words each); with ids: + pid (64), gm (64 words)
-#define NK_CARRY_DOUBLES(kind) ((kind) == 3 ? 544 : 448)
+// doubles of one wave's carry: x y z occ nts cts (64 each), w0 + evc (64 words each); with ids: + pid (64), gm and slot (64 words each)
+#define NK_CARRY_DOUBLES(kind) ((kind) == 3 ? 576 : 448)
 __host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, int kind, int nrf, int rbfP, int nlrec = 0, int carry = 0) {
     const bool emit = kind == 1;
     int Fl = geom == 1 ? F : 0;
@@ -226,14 +226,43 @@ __device__ __forceinline__ void nk_lds_flush(const NkDev &d, const NkLds &L, int
     }
 }
 
+// Particle <-> mode bookkeeping of a segment (nk_device.h: modes are partitioned over the segments).
+struct NkSegModes {
+    const NkMode *rec;      // record of stored index i at rec[i]
+    const int32_t *gm;      // global mode of stored index i at gm[i] (null: the stored index is the mode itself)
+    int nl;                 // modes this segment owns (whose reservoir particles it creates)
+    int estride, eoff;      // without the partition (developer probe): the l-th of those modes is l * estride + eoff
+    __device__ __forceinline__ int mode(int i) const { return gm ? gm[i] : i; }                         // of a stored index
+    __device__ __forceinline__ int entry_mode(int l) const { return gm ? gm[l] : l * estride + eoff; }     // of an emission entry
+};
+struct NkPlainModes { __device__ __forceinline__ int mode(int i) const { return i; } };   // the stored index is the mode
+// slot of a mode -> (segment, local index)
+__device__ __forceinline__ void nk_mode_home(const NkDev &d, int mode, int &seg, int &idx) {
+    const uint32_t slot = (uint32_t)d.m2s[mode], n = (uint32_t)d.nseg;
+    const uint32_t q = slot / n;
+    idx = (int)q;
+    seg = (int)(slot - q * n);
+}
+__device__ __forceinline__ NkSegModes nk_seg_modes(const NkDev &d, int seg) {
+    NkSegModes sm;
+    sm.rec = d.part ? d.modetab_p + (int64_t)seg * d.nlmax : d.modetab;
+    sm.gm = d.part ? d.s2m + (int64_t)seg * d.nlmax : nullptr;
+    // the slots are dealt round by round, forwards in the even rounds and backwards in the odd ones (nk_build_mode_map):
+    // every segment has M / nseg modes, the last, partial round gives one more to its first (even) or last (odd) M % nseg
+    const int full = d.M / d.nseg, rem = d.M - full * d.nseg;
+    sm.nl = d.part ? full + ((rem > 0 && ((full & 1) ? seg >= d.nseg - rem : seg < rem)) ? 1 : 0) : full + (seg < rem ? 1 : 0);
+    sm.estride = d.nseg; sm.eoff = seg;
+    return sm;
+}
+
 // Deferred lifetime_scattering (Population.py:1701-1710) for one particle.
 // The mode record is passed as two 32-byte halves {omega, vx, vy, vz} {E0, tau0..tau2} (two dwordx4 pairs, no struct copy).
 template <bool RBF = true>
 __device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const double4 &ra, const double4 &rb, double x,
-                                           double y, double z, double occ, int mode) {
+                                           double y, double z, double occ, const NkSegModes &sm, int idx) {
     double invT;
     const double T = nk_interp_T<RBF>(d, L.tb, x, y, z, invT);
-    const double tau = nk_lifetime(d, rb.y, rb.z, rb.w, T, mode);
+    const double tau = nk_lifetime(d, rb.y, rb.z, rb.w, T, sm, idx);
     const double n0 = (T > 0.0) ? nk_be(ra.x * d.c_hk, rb.x, invT, d.invT0) : 0.0;
     return (tau > 0.0) ? n0 + (occ - n0) * nk_exp(-d.dt * nk_rcp(tau)) : n0;
 }
@@ -259,21 +288,6 @@ __device__ __forceinline__ void nk_sample_res_face(const int *off, const double 
         if ((GEOM) == 2 && (d).NG > 0) nk_find_boundary_tree(d, skip, x, y, z, vx, vy, vz, tc, fc);                      \
         else nk_find_boundary((L).planes, (L).faces, (d).NP, (d).tol, x, y, z, vx, vy, vz, tc, fc);                   \
     } while (0)
-
-// Particle <-> mode bookkeeping of a segment (nk_device.h: modes are partitioned over the segments).
-struct NkSegModes {
-    const NkMode *rec;      // record of stored index i at rec[i]
-    int mstride, moff;      // global mode of stored index i = i * mstride + moff
-    int nl;                 // modes this segment owns
-};
-__device__ __forceinline__ NkSegModes nk_seg_modes(const NkDev &d, int seg) {
-    NkSegModes sm;
-    sm.rec = d.part ? d.modetab_p + (int64_t)seg * d.nlmax : d.modetab;
-    sm.mstride = d.part ? d.nseg : 1;
-    sm.moff = d.part ? seg : 0;
-    sm.nl = seg < d.M ? (d.M - seg + d.nseg - 1) / d.nseg : 0;
-    return sm;
-}
 
 // ========================================================================================= kernels
 // Which modes enter at each reservoir at `step`, and how many particles of each: fill_reservoirs 'constant'
@@ -321,7 +335,8 @@ __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t ste
         int m = nk_ss_left(d.res_roulette + (int64_t)r * d.M, d.M, um);
         m = m > d.M - 1 ? d.M - 1 : m;
         if (i >= (1ll << 24)) { atomicOr(d.overflow, 16); continue; }          // one_to_one index beyond 2^24
-        const int seg = m % d.nseg;
+        int seg, lidx;
+        if (d.part) nk_mode_home(d, m, seg, lidx); else seg = m % d.nseg;
         const int at = atomicAdd(d.sp_inbox_n + seg, 1);
         if (at < d.sp_icap) d.sp_inbox[(int64_t)seg * d.sp_icap + at] = ((uint64_t)i << 40) | ((uint64_t)((int64_t)r * d.M + m) << 12);
         else atomicOr(d.overflow, 8);                                           // inbox full
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                     if (e < nent) {
                         const int r = e / sm.nl, l = e - r * sm.nl;
                         rl = ((unsigned int)r << 12) | ((unsigned int)l << 18);      // c < 4096, R <= 64, l < 2^14
-                        const int64_t rm = (int64_t)r * d.M + ((int64_t)l * d.nseg + seg);
+                        const int64_t rm = (int64_t)r * d.M + sm.entry_mode(l);
                         const int64_t at = ((int64_t)seg * d.R + r) * d.nlmax + l;
                         prob = d.ep_p[at];
                         nk_emit_entry(d, step, rm, at, prob, c, cmine, cv);
@@ -403,7 +418,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                     o2o = recd >> 40;
                     r = (int)((uint32_t)rm / (uint32_t)d.M);                        // rm < 2^28
                     const int mode = (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
-                    idx = d.part ? (int)((uint32_t)mode / (uint32_t)d.nseg) : mode;
+                    idx = d.part ? (int)((uint32_t)d.m2s[mode] / (uint32_t)d.nseg) : mode;
                 } else {
                     // the entry this particle belongs to: the last one whose exclusive prefix is <= j
                     int lo = 0, hi = NK_EMIT_CHUNK;
@@ -588,6 +603,9 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC, int FAST = 0>
 __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || ROUGH || RBF) ? NK_SWEEP_OCC_BIG : NK_SWEEP_OCC)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef NK_STAMPS
+    const unsigned long long st_entry_r = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
+#endif
     if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
     if (FAST) { d.sv_kind = 0; d.sv_interp = FAST - 1; d.T_ref_local = 1; }
     NkLds L;
@@ -615,9 +633,15 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 const double4 a = g[0], b = g[1];
                 double2 *q = lrec + r0 * NK_LREC_STRIDE;
                 q[0] = make_double2(a.x, a.y); q[1] = make_double2(a.z, a.w); q[2] = make_double2(b.x, b.y); q[3] = make_double2(b.z, b.w);
+                if (NK_LREC_STRIDE > 4 && (ROUGH || PID)) *reinterpret_cast<int *>(q + 4) = sm.mode(r0);   // the mode itself, in the record's spare 16 bytes
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
         }
+        // global mode of a stored index: from the LDS copy of the record where there is one (no memory access in the tile loop)
+        auto mode_of = [&](int i) -> int {
+            if (use_lrec && NK_LREC_STRIDE > 4) return *(const __attribute__((address_space(3))) int *)(const void *)(lrec + i * NK_LREC_STRIDE + 4);
+            return sm.mode(i);
+        };
         const int nA = (count + NK_TILE - 1) / NK_TILE;
         NkOut<PID> O;                                 // finished particles on their way back to the segment
         O.init(L, wave);
@@ -626,6 +650,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
 #ifdef NK_STAMPS
         unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
+        const unsigned long long st_c0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();   // shader clock against the 100 MHz counter
 #endif
         // next tile is requested before the current tile's arithmetic
         uint32_t w0N = 0u;
@@ -706,7 +731,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
 #endif
                 NK_STAMP(0);
                 if (act && !newborn) {
-                    if (do_relax) occ = nk_relax<RBF>(d, L, ra, rb, x, y, z, occ, idx * sm.mstride + sm.moff);
+                    if (do_relax) occ = nk_relax<RBF>(d, L, ra, rb, x, y, z, occ, sm, idx);
                     x += vx * d.dt; y += vy * d.dt; z += vz * d.dt;                 // drift, Population.py:793
                     nts -= 1.0;                                                     // :795
                 }
@@ -749,7 +774,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                         const int sl = cn + erank - taken;
                         cX[sl] = x; cX[64 + sl] = y; cX[128 + sl] = z; cX[192 + sl] = occ; cX[256 + sl] = nts; cX[320 + sl] = 0.0;
                         cW[sl] = w0; cW[64 + sl] = 0u;
-                        if (PID) { cP[sl] = __longlong_as_double((long long)pid); cW[128 + sl] = (uint32_t)((int)(w0 & lbmask) * sm.mstride + sm.moff); }
+                        if (PID) { cP[sl] = __longlong_as_double((long long)pid); cW[128 + sl] = (uint32_t)mode_of((int)(w0 & lbmask)); cW[192 + sl] = (w0 & lbmask) * (uint32_t)d.nseg + (uint32_t)seg; }
                     }
                     cn += k; taken += k;
                 }
@@ -759,18 +784,19 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 const bool eact = lane < cn;
                 NkParticle p;
                 double cts = 0.0;
-                uint32_t evc = 0u, cw0 = 0u, cgm = 0u;
+                uint32_t evc = 0u, cw0 = 0u, cgm = 0u, cslot = (uint32_t)seg;
                 unsigned long long cpid = 0ull;
                 int st = NK_EV_DEAD;
                 p.x = p.y = p.z = p.occ = p.nts = 0.0;
                 if (eact) {
                     p.x = cX[lane]; p.y = cX[64 + lane]; p.z = cX[128 + lane]; p.occ = cX[192 + lane]; p.nts = cX[256 + lane]; cts = cX[320 + lane];
                     cw0 = cW[lane]; evc = cW[64 + lane];
-                    if (PID) { cpid = (unsigned long long)__double_as_longlong(cP[lane]); cgm = cW[128 + lane]; }
+                    if (PID) { cpid = (unsigned long long)__double_as_longlong(cP[lane]); cgm = cW[128 + lane]; cslot = cW[192 + lane]; }
                 }
                 const int idx0 = eact ? (int)(cw0 & lbmask) : 0;
                 if (ROUGH) {                              // the carried particle may be in a mode another segment owns
-                    p.mode = eact ? (int)cgm : sm.moff;
+                    p.mode = eact ? (int)cgm : mode_of(0);
+                    p.slot = (int)cslot;
                     const NkMode *rec = d.modetab + p.mode;
                     const double4 ra = *reinterpret_cast<const double4 *>(rec);
                     p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
@@ -787,7 +813,8 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                         p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                         p.E0 = sm.rec[idx0].E0;
                     }
-                    p.mode = idx0 * sm.mstride + sm.moff;
+                    p.mode = PID ? (int)cgm : idx0;                          // (nothing reads it without rough facets)
+                    p.slot = (int)cslot;
                 }
                 p.facet = (int)(cw0 >> d.lb) - 1;
                 if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, cpid, step);
@@ -800,8 +827,9 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 // the particle's segment after the event: a reflection may have handed it to another one
                 bool stay = true;
                 uint32_t idxe = (uint32_t)idx0;
+                int hseg = seg;                            // the segment that owns the particle's mode now
                 if (ROUGH) {
-                    if (d.part) { const uint32_t q = (uint32_t)p.mode / (uint32_t)d.nseg; stay = (int)((uint32_t)p.mode - q * (uint32_t)d.nseg) == seg; idxe = q; }
+                    if (d.part) { const uint32_t hi = (uint32_t)p.slot / (uint32_t)d.nseg; hseg = (int)((uint32_t)p.slot - hi * (uint32_t)d.nseg); stay = hseg == seg; idxe = hi; }
                     else idxe = (uint32_t)p.mode;
                 }
                 const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
@@ -809,7 +837,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                 const unsigned long long mA = __ballot(home), mM = __ballot(more);
                 O.push(d, base, lane, home, nk_rank(mA), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0e, cpid);
                 if (ROUGH && away) {                       // one 64-byte record into the inbox of the segment that owns the new mode
-                    const int dst = (int)((uint32_t)p.mode - idxe * (uint32_t)d.nseg);
+                    const int dst = hseg;
                     const int at = atomicAdd(d.mig_n + dst, 1);
                     if (at < d.mig_cap) {
                         double2 *r = d.mig_buf + ((int64_t)dst * d.mig_cap + at) * 4;
@@ -823,7 +851,7 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
                     const int sl = nk_rank(mM);
                     cX[sl] = p.x; cX[64 + sl] = p.y; cX[128 + sl] = p.z; cX[192 + sl] = p.occ; cX[256 + sl] = p.nts; cX[320 + sl] = cts;
                     cW[sl] = w0e; cW[64 + sl] = evc;
-                    if (PID) { cP[sl] = __longlong_as_double((long long)cpid); cW[128 + sl] = (uint32_t)p.mode; }
+                    if (PID) { cP[sl] = __longlong_as_double((long long)cpid); cW[128 + sl] = (uint32_t)p.mode; cW[192 + sl] = (uint32_t)p.slot; }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
                 NK_STAMP(5);
@@ -835,6 +863,14 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
             unsigned long long *o = d.stamps + (int64_t)seg * 8;
             for (int k = 0; k < 6; ++k) o[k] = st_acc[k];
             o[6] = (unsigned long long)nA;
+            // in-kernel clock: shader cycles per tick of the constant 100 MHz counter over this segment, x 1000 (MHz x 10)
+            unsigned long long c1_;
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(c1_)::"memory");
+            const unsigned long long r1_ = __builtin_amdgcn_s_memrealtime();
+            o[7] = r1_ > st_r0 ? ((c1_ - st_c0) * 1000ull) / (r1_ - st_r0) : 0ull;
+            // wall-clock marks of this wave (10 ns ticks): kernel entry, tile loop begin, tile loop end
+            unsigned long long *w = d.stamps + ((int64_t)d.nseg + seg) * 8;
+            w[0] = st_entry_r; w[1] = st_r0; w[2] = r1_;
         }
 #endif
         if (O.on > 0) O.flush(d, base, lane, O.on);
@@ -850,6 +886,12 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
         }
     }
     nk_lds_flush(d, L, blockIdx.x);
+#ifdef NK_STAMPS
+    if (d.stamps && lane == 0) {
+        const int seg0 = blockIdx.x * (NK_WG / 64) + wave;
+        if (seg0 < d.nseg) d.stamps[((int64_t)d.nseg + seg0) * 8 + 3] = __builtin_amdgcn_s_memrealtime();   // the wave is through
+    }
+#endif
 }
 
 // The events of a split sweep (Population.py:1546-1683), at four waves per SIMD: the tree walks are chains of dependent loads.
@@ -956,8 +998,11 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                     const uint32_t w0 = d.qw0[i];
                     if (PID) pid = d.qpid[i];
                     idx0 = (int)(w0 & lbmask);
-                    p.mode = d.part ? idx0 * d.nseg + seg : idx0;
-                    const NkMode *rec = d.modetab + p.mode;
+                    // record from the segments' copy of the table; the mode itself (rough reflections key their tables by it) is
+                    // fetched beside it, not in front of it
+                    p.mode = d.part ? d.s2m[(int64_t)seg * d.nlmax + idx0] : idx0;
+                    p.slot = idx0 * d.nseg + seg;
+                    const NkMode *rec = d.part ? d.modetab_p + (int64_t)seg * d.nlmax + idx0 : d.modetab + idx0;
                     const double4 ra = *reinterpret_cast<const double4 *>(rec);
                     p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                     p.E0 = rec->E0;
@@ -1013,8 +1058,9 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
             nk_tally_one(d, L.tb, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.E0, p.vx, p.vy, p.vz, do_flux, rep);
             bool stay = true;
             uint32_t idxe = (uint32_t)idx0;
+            int hseg = seg;                               // the segment that owns the particle's mode now
             if (ROUGH) {
-                if (d.part) { const uint32_t qq = (uint32_t)p.mode / (uint32_t)d.nseg; stay = (int)((uint32_t)p.mode - qq * (uint32_t)d.nseg) == seg; idxe = qq; }
+                if (d.part) { const uint32_t hi = (uint32_t)p.slot / (uint32_t)d.nseg; hseg = (int)((uint32_t)p.slot - hi * (uint32_t)d.nseg); stay = hseg == seg; idxe = hi; }
                 else idxe = (uint32_t)p.mode;
             }
             const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
@@ -1026,7 +1072,7 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                     if (PID) d.pid[i] = pid;
                 } else atomicOr(d.overflow, 4);
             } else {                                      // (ROUGH) one 64-byte record into the inbox of the segment that owns the new mode
-                const int dst = (int)((uint32_t)p.mode - idxe * (uint32_t)d.nseg);
+                const int dst = hseg;
                 const int at = atomicAdd(d.mig_n + dst, 1);
                 if (at < d.mig_cap) {
                     double2 *r = d.mig_buf + ((int64_t)dst * d.mig_cap + at) * 4;
@@ -1238,7 +1284,7 @@ __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d, int honor_halt) {
             const int idx = (int)(d.w0[i] & lbmask);
             const double4 *mrec = reinterpret_cast<const double4 *>(sm.rec + idx);
             const double4 ra = mrec[0], rb = mrec[1];
-            d.occ[i] = nk_relax(d, L, ra, rb, d.x[i], d.y[i], d.z[i], d.occ[i], idx * sm.mstride + sm.moff);
+            d.occ[i] = nk_relax(d, L, ra, rb, d.x[i], d.y[i], d.z[i], d.occ[i], sm, idx);
         }
     }
 }
@@ -1341,7 +1387,8 @@ __global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, ui
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint64_t pid = pid_lo + (uint64_t)i;
         const int mode = umodes[pid % (uint64_t)nu];
-        const int seg = mode % d.nseg, idx = mode / d.nseg;
+        int seg, idx;
+        nk_mode_home(d, mode, seg, idx);
         int want = -1;                                // random_subvol: the subvolume this index belongs to
         if (sv_first) { int lo = 0, hi = d.S; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sv_first[mid] <= (int64_t)pid) lo = mid; else hi = mid; } want = lo; }
         double x = 0.0, y = 0.0, z = 0.0;
@@ -1410,7 +1457,7 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
                        y > d.bbox[4] + 1e-10 || z > d.bbox[5] + 1e-10;
             if (!out) continue;
             const uint32_t idx = d.w0[i] & lbmask;
-            const uint64_t pid = d.pid ? d.pid[i] : nk_state_key((int)idx * sm.mstride + sm.moff, x, y, z);
+            const uint64_t pid = d.pid ? d.pid[i] : nk_state_key(sm.mode((int)idx), x, y, z);
             double u[6];
             nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 0, u[0], u[1]);
             nk_uniform2_dev(d.seed, pid, step, NK_TAG_RESAMP + 1, u[2], u[3]);
@@ -1432,17 +1479,18 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
 }
 
 // (reservoir, mode) tables between the caller's order [r * M + m] and the segments' order (nk_device.h ep_p / rc_p)
-__global__ void k_perm_rm(int to_seg_order, int R, int M, int nseg, int nlmax, double *canon, double *perm) {
+__global__ void k_perm_rm(int to_seg_order, int R, int M, int nseg, int nlmax, const int32_t *m2s, double *canon, double *perm) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)R * M) return;
     const int r = (int)(i / M), m = (int)(i - (int64_t)r * M);
-    const int64_t at = ((int64_t)(m % nseg) * R + r) * nlmax + m / nseg;
+    const int slot = m2s[m];
+    const int64_t at = ((int64_t)(slot % nseg) * R + r) * nlmax + slot / nseg;
     if (to_seg_order) perm[at] = canon[i]; else canon[i] = perm[at];
 }
 
 // {omega, v, E0, tau[row0..row0+2]} records, by mode index and (part) in the segments' order
 __global__ void k_build_modetab(const double *omega, const double *vg, const double *tau, int M, int NT, int row0, double c_hk,
-                                double invT0, int nseg, int nlmax, NkMode *out, NkMode *out_p) {
+                                double invT0, int nseg, int nlmax, const int32_t *m2s, NkMode *out, NkMode *out_p) {
     int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
     NkMode r;
@@ -1453,7 +1501,7 @@ __global__ void k_build_modetab(const double *omega, const double *vg, const dou
         r.tau[k] = (row >= 0 && row < NT) ? tau[(int64_t)row * M + m] : 0.0;
     }
     out[m] = r;
-    if (out_p) out_p[(int64_t)(m % nseg) * nlmax + m / nseg] = r;
+    if (out_p) { const int slot = m2s[m]; out_p[(int64_t)(slot % nseg) * nlmax + slot / nseg] = r; }
 }
 
 // ---- parity taps: the reference's primitives evaluated on the device
@@ -1486,7 +1534,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, int what, int64_t n
     if (i >= n) return;
     switch (what) {
         case 0: out[i] = nk_occupation(d, a[i], d.modetab[mode[i]].omega, d.modetab[mode[i]].E0); break;
-        case 1: { const NkMode *rec = d.modetab + mode[i]; out[i] = nk_lifetime(d, rec->tau[0], rec->tau[1], rec->tau[2], a[i], mode[i]); break; }
+        case 1: { const NkMode *rec = d.modetab + mode[i]; out[i] = nk_lifetime(d, rec->tau[0], rec->tau[1], rec->tau[2], a[i], NkPlainModes(), mode[i]); break; }
         case 2: out[i] = nk_T_of_E(d, a[i]); break;
         case 3: out[i] = nk_E_of_T(d, a[i]); break;
         case 5: out[i] = nk_exp(a[i]); break;

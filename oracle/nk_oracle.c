@@ -375,6 +375,7 @@ int64_t nko_emit(const nko_material *mat, const nko_mesh *mesh, nko_reservoirs *
             } else {                                               /* fixed_rate :410-417 */
                 double d0, d1;
                 nko_uniform2(p->seed, (uint64_t)rm | 0xFFFFFFFF00000000ull, (uint32_t)step, TAG_DICE, &d0, &d1);
+                if (res->dice) d0 = res->dice[rm];                 /* test tap: the reference's own dice */
                 mask = d0 <= (prob - fixed);
                 cnt = d0;
             }

@@ -89,6 +89,9 @@ typedef struct {
     int32_t *dbg_res;        /* [cap]   reservoir index */
     const int64_t *n_leaving;/* [R] one_to_one: particles to emit at this step = those that left through the facet at
                               * the previous step, all ranks together (Population.py:344, :466, :1585) */
+    const double *dice;      /* optional test tap (NULL = off): 'fixed_rate' takes its dice (Population.py:410) from here
+                              * instead of the counter-based generator, [R*Q*J] -- replays the uniforms the reference drew
+                              * (tests/golden/emission_fixed.npz) */
 } nko_reservoirs;
 
 typedef struct {

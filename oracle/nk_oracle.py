@@ -47,7 +47,7 @@ class Subvols(C.Structure):
 class Reservoirs(C.Structure):
     _fields_ = [('R', C.c_int32), ('facet', c_ip), ('T', c_dp), ('enter_prob', c_dp), ('counter', c_dp),
                 ('gen', C.c_int32), ('dbg_dt_in', c_dp), ('dbg_x0', c_dp), ('dbg_level', c_ip), ('dbg_res', c_ip),
-                ('n_leaving', c_lp)]
+                ('n_leaving', c_lp), ('dice', c_dp)]
 
 
 class Rough(C.Structure):
@@ -200,6 +200,14 @@ def make_reservoirs(facets, T, enter_prob, counter, gen=0, n_leaving=None):
     r.counter_array = cn
     r.n_leaving_array = nl
     return r
+
+
+def attach_dice(res, dice):
+    """'fixed_rate' test tap: the generator's dice (Population.py:410) come from `dice` [R, Q*J] instead of Philox."""
+    dc = _d(dice)
+    res.dice = _p(dc, c_dp)
+    _keep(res, dc)
+    return res
 
 
 def attach_emission_taps(res, cap):

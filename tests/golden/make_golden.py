@@ -489,6 +489,37 @@ def gen_emission():
     np.savez_compressed(os.path.join(HERE, 'emission.npz'), **out)
 
 
+def gen_emission_fixed():
+    """fill_reservoirs('fixed_rate') (Population.py:408-455) + add_reservoir_particles (:525-552) with the uniforms it drew:
+    the first np.random.rand call of the step is the dice array (R, Q, J) (:410) -- stored, so that the oracle's fixed_rate
+    branch can replay the reference's own decisions (tests/test_oracle_golden.py::test_emission_fixed_rate_replay)."""
+    out = {}
+    args, geo, ph, pop, mat = build_case('ttp', 20000, 2468)
+    pop.res_gen = 'fixed_rate'
+    for scale_name, scale in (('lo', 1.0), ('hi', 40.0)):
+        pop.enter_prob = pop.enter_probability(geo, ph) * scale
+        p = scale_name + '__'
+        out[p + 'enter_prob'] = pop.enter_prob.copy()
+        np.random.seed(47)
+        with RandLog() as log:
+            pop.fill_reservoirs(geo, ph)
+        dice = log.calls[0]
+        assert dice.shape == pop.enter_prob.shape
+        out[p + 'dice'] = dice
+        out[p + 'res_modes'] = pop.res_modes.copy()
+        out[p + 'res_dt_in'] = pop.res_dt_in.copy()
+        out[p + 'res_facet_id'] = pop.res_facet_id.copy()
+        out[p + 'res_positions'] = pop.res_positions.copy()
+        out[p + 'res_occupation'] = pop.res_occupation.copy()
+        n0 = pop.positions.shape[0]
+        pop.add_reservoir_particles(geo)
+        out[p + 'new_positions'] = pop.positions[n0:].copy()
+        out[p + 'new_n_timesteps'] = pop.n_timesteps[n0:].copy()
+        out[p + 'new_collision_facets'] = np.asarray(pop.collision_facets[n0:], dtype=np.int64)
+        print('fixed_rate', scale_name, 'emitted', pop.res_modes.shape[0], 'rand calls', len(log.calls))
+    np.savez_compressed(os.path.join(HERE, 'emission_fixed.npz'), **out)
+
+
 def build_case_argv(argv, seed):
     mat = material_small()
     args = H.make_args(ref, argv)

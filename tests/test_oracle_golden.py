@@ -293,3 +293,66 @@ def test_one_to_one_generator_counts_and_modes():
         exp = np.array([ep[r, b].sum() for b in bins]) / ep[r].sum() * obs.sum()
         ok = exp > 20
         assert np.all(np.abs(obs[ok] - exp[ok]) < 6 * np.sqrt(exp[ok]) + 0.12 * exp[ok])
+
+
+@pytest.mark.parametrize('scale', ['lo', 'hi'])
+def test_emission_fixed_rate_replay(scale):
+    """fill_reservoirs('fixed_rate') (Population.py:408-455) pinned deterministically: the oracle's fixed_rate branch, fed the
+    dice array the reference drew (tests/golden/emission_fixed.npz, the first rand call of the step, :410), must make the
+    reference's decisions -- which (reservoir, mode) entries emit and how many (:415-417), the level-1 entry time
+    dt (1 - dice / p) (:440) -- and hand the particles to add_reservoir_particles the same way (:525-552)."""
+    g = sub(golden('emission_fixed'), scale)
+    gm = sub(golden('mesh'), 'box200ttp')
+    ph = golden_phonon()
+    J = ph.number_of_branches
+    M = ph.number_of_qpoints * J
+    mat = O.make_material(ph.tables())
+    mesh = O.make_mesh(gm)
+    ep = g['enter_prob'].reshape(2, M)
+    res = O.make_reservoirs(gm['res_facets'], [302.0, 298.0], ep, np.zeros_like(ep), gen=1)
+    O.attach_dice(res, g['dice'].reshape(2, M))
+    cap = g['res_modes'].shape[0] + 64
+    O.attach_emission_taps(res, cap)
+    par = O.make_params(seed=99)
+    store = O.ParticleStore(cap)
+    n = O.lib().nko_emit(C.byref(mat), C.byref(mesh), C.byref(res), C.byref(par), C.c_int64(5), C.c_int32(0),
+                         C.c_int32(1), C.byref(store.s))
+    assert n == g['res_modes'].shape[0]
+    # same multiset of (reservoir, mode): every emitting entry and its particle count
+    ref_r = np.searchsorted(gm['res_facets'], g['res_facet_id'])
+    ref_key = np.sort(ref_r * M + g['res_modes'][:, 0] * J + g['res_modes'][:, 1])
+    my_key = np.sort(res.tap_res[:n].astype(np.int64) * M + store.mode[:n])
+    assert np.array_equal(ref_key, my_key)
+    # level-1 entry times: per reservoir the reference lists the levels c_max .. 1, the level-1 block last (:430-447)
+    dice = g['dice'].reshape(2, M)
+    dt_ref = {}
+    for r in range(2):
+        sel = np.nonzero(ref_r == r)[0]
+        c = np.floor(ep[r]) + (dice[r] <= ep[r] - np.floor(ep[r]))
+        n1 = int((c >= 1).sum())
+        for i in sel[-n1:]:
+            dt_ref[(r, int(g['res_modes'][i, 0] * J + g['res_modes'][i, 1]))] = g['res_dt_in'][i]
+    lvl1 = np.nonzero(res.tap_level[:n] == 1)[0]
+    assert len(lvl1) == len(dt_ref)
+    mine = np.array([res.tap_dt_in[i] for i in lvl1])
+    theirs = np.array([dt_ref[(int(res.tap_res[i]), int(store.mode[i]))] for i in lvl1])
+    assert np.allclose(mine, theirs, rtol=1e-12, atol=1e-13)
+    # higher levels: the law dt (1 - (level - 1 + u) / p) with u in [0, 1)
+    hi = res.tap_level[:n] > 1
+    if hi.any():
+        p = ep[res.tap_res[:n][hi], store.mode[:n][hi]]
+        u = (1.0 - res.tap_dt_in[:n][hi]) * p - (res.tap_level[:n][hi] - 1)
+        assert u.min() >= -1e-12 and u.max() < 1 + 1e-12
+    # the deterministic map (x0, v, dt_in) -> particle state against the reference's add_reservoir_particles outputs
+    vg = ph.group_vel.reshape(-1, 3)
+    vr = np.ascontiguousarray(vg[g['res_modes'][:, 0] * J + g['res_modes'][:, 1]])
+    xr = np.ascontiguousarray(g['res_positions'])
+    m = xr.shape[0]
+    xc = np.zeros((m, 3)); tc = np.zeros(m); fc = np.zeros(m, dtype=np.int32)
+    O.lib().nko_find_boundary(C.byref(mesh), C.c_int64(m), P(xr), P(vr), P(xc), P(tc), P(fc, c_ip))
+    assert np.array_equal(fc, g['new_collision_facets'])
+    assert np.allclose(tc - g['res_dt_in'], g['new_n_timesteps'], rtol=1e-12, atol=1e-12)
+    assert np.allclose(xr + vr * g['res_dt_in'][:, None], g['new_positions'], rtol=1e-13, atol=1e-11)
+    occ = ph.calculate_occupation(np.array([302.0, 298.0])[res.tap_res[:n]], ph.omega.ravel()[store.mode[:n]])
+    assert rel_err(store.occ[:n], occ) < 1e-13
+    assert rel_err(np.sort(store.occ[:n]), np.sort(g['res_occupation'])) < 1e-12
