@@ -42,6 +42,25 @@
 #define NK_TAG_DICE 0x30000u
 #define NK_TAG_INIT 0x40000u      // k_init_particles: 3 tags per draw of a position
 
+// A particle field in HBM.  The store is cut into BLOCKS of 64 slots (one tile of the sweep); a block holds its 64 x, then
+// its 64 y, z, occupations, times to the boundary, (ids,) and packed words one after the other -- 2816 bytes (3328 with
+// ids) that a wave reads as ONE contiguous piece.  (Round 2 kept six separate arrays: six DRAM streams per wave whose
+// relative placement -- the arrays are 2 MB-aligned allocations, so slot i of every array shares its low address bits --
+// decided the memory system's efficiency: the same binary ran 10-25 % apart from one process to the next.)
+// blk = distance between two blocks in units of T; slot i lives at p[(i / 64) * blk + i % 64].  blk = 64 with separate
+// base pointers gives back the plain arrays (NK_LAYOUT=soa, developer comparison).
+template <class T>
+struct NkField {
+    T *p;
+    int32_t blk;
+    __host__ __device__ __forceinline__ int64_t off(int64_t i) const { return (i >> 6) * (int64_t)blk + (i & 63); }
+    __host__ __device__ __forceinline__ T &operator[](int64_t i) const { return p[off(i)]; }
+    __host__ __device__ __forceinline__ T *operator+(int64_t i) const { return p + off(i); }
+    // slot i0 + lane of the tile that starts at slot i0 (a multiple of 64, the same for the whole wave: scalar arithmetic)
+    __host__ __device__ __forceinline__ T *tile(int64_t i0, int lane) const { return p + ((i0 >> 6) * (int64_t)blk + lane); }
+    __host__ __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
+};
+
 struct __attribute__((aligned(16))) NkFacet {   // 96 bytes
     double cx, cy, cz;    // centroid
     double nx, ny, nz;    // outward normal
@@ -144,16 +163,16 @@ struct NkDev {
     double particle_density, T_ref;
     uint64_t seed;
     int32_t rank, nranks;
-    // ---- particles: SoA arrays of nseg * segcap slots; segment s = slots [s*segcap, s*segcap + seg_count[s])
+    // ---- particles: nseg * segcap slots in blocks of 64 (NkField); segment s = slots [s*segcap, s*segcap + seg_count[s])
     int64_t cap;
     int32_t nseg, segcap;
     int32_t *seg_count;               // [nseg] live particles per segment (contiguous from the segment start)
     int32_t *seg_new;                 // [nseg] particles k_emit appended behind them at this step (the sweep takes them in)
     int32_t *seg_bound;               // [nseg] upper bound of the particles that can enter the segment in one step
-    double *x, *y, *z, *occ, *nts;
-    uint32_t *w0;                     // newborn << 31 | (facet + 1) << lb | idx;  idx = the mode's local index in its segment (part) or the mode itself;
+    NkField<double> x, y, z, occ, nts;
+    NkField<uint32_t> w0;             // newborn << 31 | (facet + 1) << lb | idx;  idx = the mode's local index in its segment (part) or the mode itself;
                                       // newborn: appended by k_emit at this step (no relaxation, no drift yet)
-    uint64_t *pid;                    // null: particle ids are not tracked (no per-particle random draws in this configuration)
+    NkField<uint64_t> pid;            // null: particle ids are not tracked (no per-particle random draws in this configuration)
     int32_t part;                     // 1: idx is the local index of a mode of the owning segment; 0: the global mode index
     int32_t lb;                       // bits of idx in w0
     int32_t nlmax;                    // modes per segment, rounded up: ceil(M / nseg)
@@ -181,6 +200,17 @@ struct NkDev {
     int32_t NB;                       // bins per row = 5*S + 5*R + 1
     unsigned long long *stamps;       // developer build NK_STAMPS (make stamps): per-wave cycle sums of the sweep's sections
 };
+
+// Offsets of slot i in the double-sized fields (x y z occ nts pid share their block stride) and in the packed words, computed
+// once for a whole particle (hot paths; the fields' operator[] recomputes them per access).
+struct NkSlot { int64_t od, ow; };
+__device__ __forceinline__ NkSlot nk_slot(const NkDev &d, int64_t i) {
+    const int64_t b = i >> 6, l = i & 63;
+    NkSlot s;
+    s.od = b * (int64_t)d.x.blk + l;
+    s.ow = b * (int64_t)d.w0.blk + l;
+    return s;
+}
 
 // ------------------------------------------------------------------------------------------------ RNG
 // Philox4x32-10, counter = {pid_lo, pid_hi, step, tag}, key = seed.  Stateless: nothing is stored per particle.

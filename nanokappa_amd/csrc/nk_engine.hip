@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <functional>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -121,6 +122,51 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 }
 #define NK_UP(src, n, dst)                                                                             \
     do { int rc_ = nk_upload(ctx, src, n, dst); if (rc_) return rc_; } while (0)
+
+// The particle fields of a store of `cap` slots (a multiple of 64): ONE allocation cut into blocks of 64 slots, every block
+// x | y | z | occ | nts | [pid] | w0 (NkField, nk_device.h).  NK_LAYOUT=soa (developer comparison): one plain array per
+// field, as in round 2.  The allocation is registered in ctx->pallocs.
+static int nk_alloc_fields(nk_ctx *ctx, NkDev &d, int64_t cap, bool with_pid) {
+    const bool soa = getenv("NK_LAYOUT") && !strcmp(getenv("NK_LAYOUT"), "soa");
+    const int64_t nblk = (cap + 63) / 64;
+    const int bd = with_pid ? 6 * 64 + 32 : 5 * 64 + 32;          // doubles per block (the 64 packed words take 32)
+    const size_t bytes = soa ? (size_t)nblk * 64 * (with_pid ? 52 : 44) : (size_t)nblk * bd * 8;
+    void *buf = nullptr;
+    // developer probe (scripts/placement_probe.py): NK_STORE_PAD_KB shifts the store inside a larger allocation
+    const size_t pad = getenv("NK_STORE_PAD_KB") ? (size_t)atol(getenv("NK_STORE_PAD_KB")) * 1024 : 0;
+    NK_HIP(hipMalloc(&buf, (bytes ? bytes : 64) + pad));
+    ctx->pallocs.push_back(buf);
+    NK_HIP(hipMemsetAsync(buf, 0, (bytes ? bytes : 64) + pad, ctx->stream));
+    double *b = (double *)((char *)buf + pad);
+    if (soa) {
+        const int64_t n = nblk * 64;
+        d.x = {b, 64}; d.y = {b + n, 64}; d.z = {b + 2 * n, 64}; d.occ = {b + 3 * n, 64}; d.nts = {b + 4 * n, 64};
+        d.pid = {with_pid ? (uint64_t *)(b + 5 * n) : nullptr, 64};
+        d.w0 = {(uint32_t *)(b + (with_pid ? 6 : 5) * n), 64};
+    } else {
+        d.x = {b, bd}; d.y = {b + 64, bd}; d.z = {b + 128, bd}; d.occ = {b + 192, bd}; d.nts = {b + 256, bd};
+        d.pid = {with_pid ? (uint64_t *)(b + 320) : nullptr, bd};
+        d.w0 = {(uint32_t *)(b + (with_pid ? 384 : 320)), 2 * bd};
+    }
+    return NK_OK;
+}
+// Host copy of a whole field (slot order) and back.
+template <class T>
+static int nk_field_download(nk_ctx *ctx, const NkDev &d, const NkField<T> &f, std::vector<T> &out) {
+    // the field's elements are strided by blocks: copy block-wise with hipMemcpy2D (rows of 64 elements)
+    out.resize((size_t)d.cap);
+    const int64_t nblk = d.cap / 64;
+    if (nblk == 0) return NK_OK;
+    NK_HIP(hipMemcpy2D(out.data(), 64 * sizeof(T), f.p, (size_t)f.blk * sizeof(T), 64 * sizeof(T), (size_t)nblk, hipMemcpyDeviceToHost));
+    return NK_OK;
+}
+template <class T>
+static int nk_field_upload(nk_ctx *ctx, const NkDev &d, const NkField<T> &f, const T *src) {
+    const int64_t nblk = d.cap / 64;
+    if (nblk == 0) return NK_OK;
+    NK_HIP(hipMemcpy2D(f.p, (size_t)f.blk * sizeof(T), src, 64 * sizeof(T), 64 * sizeof(T), (size_t)nblk, hipMemcpyHostToDevice));
+    return NK_OK;
+}
 
 // 1 = ray-casting tables fit LDS, 2 = they stay in global memory
 static inline int nk_geom_mode(const nk_ctx *ctx) { return (ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES) ? 1 : 2; }
@@ -932,25 +978,27 @@ static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
     for (int c : cnt) live += c;
     ctx->h_seg_count = cnt;
     if (!want_all) { h.x.resize((size_t)live); return NK_OK; }
-    std::vector<double> bd((size_t)d.cap);
-    auto pack = [&](const void *src, size_t esz, void *dst) -> int {
-        NK_HIP(hipMemcpy(bd.data(), src, (size_t)d.cap * esz, hipMemcpyDeviceToHost));
-        char *o = (char *)dst;
-        const char *in = (const char *)bd.data();
+    std::vector<double> bd;
+    std::vector<uint32_t> bw;
+    std::vector<uint64_t> bu;
+    // a field comes back whole (slot order), then the live head of every segment is kept
+    auto keep = [&](const auto &all, auto *dst) {
         for (int sgm = 0; sgm < d.nseg; ++sgm) {
-            memcpy(o, in + (size_t)sgm * d.segcap * esz, (size_t)cnt[sgm] * esz);
-            o += (size_t)cnt[sgm] * esz;
+            memcpy(dst, all.data() + (size_t)sgm * d.segcap, (size_t)cnt[sgm] * sizeof(*dst));
+            dst += cnt[sgm];
         }
-        return NK_OK;
     };
     h.x.resize(live); h.y.resize(live); h.z.resize(live); h.occ.resize(live); h.nts.resize(live);
     h.mode.resize(live); h.facet.resize(live); h.pid.assign(live, 0);
     std::vector<uint32_t> w0((size_t)live);
     int rc;
-    if ((rc = pack(d.x, 8, h.x.data())) || (rc = pack(d.y, 8, h.y.data())) || (rc = pack(d.z, 8, h.z.data())) ||
-        (rc = pack(d.occ, 8, h.occ.data())) || (rc = pack(d.nts, 8, h.nts.data())) || (rc = pack(d.w0, 4, w0.data())))
-        return rc;
-    if (d.pid && (rc = pack(d.pid, 8, h.pid.data()))) return rc;
+    if ((rc = nk_field_download(ctx, d, d.x, bd))) return rc; keep(bd, h.x.data());
+    if ((rc = nk_field_download(ctx, d, d.y, bd))) return rc; keep(bd, h.y.data());
+    if ((rc = nk_field_download(ctx, d, d.z, bd))) return rc; keep(bd, h.z.data());
+    if ((rc = nk_field_download(ctx, d, d.occ, bd))) return rc; keep(bd, h.occ.data());
+    if ((rc = nk_field_download(ctx, d, d.nts, bd))) return rc; keep(bd, h.nts.data());
+    if ((rc = nk_field_download(ctx, d, d.w0, bw))) return rc; keep(bw, w0.data());
+    if (d.pid) { if ((rc = nk_field_download(ctx, d, d.pid, bu))) return rc; keep(bu, h.pid.data()); }
     // packed word -> (mode, facet): mode = idx * nseg + segment when the modes are partitioned
     const uint32_t lbmask = (1u << d.lb) - 1u;
     int64_t k = 0;
@@ -993,26 +1041,20 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
         cnt[(size_t)sgm] = (int32_t)(start[(size_t)sgm + 1] - start[(size_t)sgm]);
         NK_ARG(cnt[(size_t)sgm] <= d.segcap, "nk_upload_particles: segment capacity too small");
     }
-    std::vector<double> bd((size_t)d.cap);
-    auto put = [&](const void *src, size_t esz, void *dst) -> int {
+    // a field is laid out whole on the host (slot order: every segment's particles from its start), then uploaded
+    auto put = [&](const auto *src, const auto &field) -> int {
+        typedef typename std::remove_const<typename std::remove_pointer<decltype(src)>::type>::type T;
+        std::vector<T> all((size_t)d.cap, T(0));
         for (int sgm = 0; sgm < d.nseg; ++sgm) {
             const int64_t lo = start[(size_t)sgm], n = cnt[(size_t)sgm];
-            if (esz == 8) {
-                uint64_t *o = (uint64_t *)bd.data() + (size_t)sgm * d.segcap;
-                const uint64_t *in = (const uint64_t *)src;
-                for (int64_t k = 0; k < n; ++k) o[k] = in[order[(size_t)(lo + k)]];
-            } else {
-                uint32_t *o = (uint32_t *)bd.data() + (size_t)sgm * d.segcap;
-                const uint32_t *in = (const uint32_t *)src;
-                for (int64_t k = 0; k < n; ++k) o[k] = in[order[(size_t)(lo + k)]];
-            }
+            T *o = all.data() + (size_t)sgm * d.segcap;
+            for (int64_t k = 0; k < n; ++k) o[k] = src[order[(size_t)(lo + k)]];
         }
-        NK_HIP(hipMemcpy(dst, bd.data(), (size_t)d.cap * esz, hipMemcpyHostToDevice));
-        return NK_OK;
+        return nk_field_upload(ctx, d, field, all.data());
     };
     int rc;
-    if ((rc = put(x, 8, d.x)) || (rc = put(y, 8, d.y)) || (rc = put(z, 8, d.z)) || (rc = put(occ, 8, d.occ))) return rc;
-    if (n_ts && (rc = put(n_ts, 8, d.nts))) return rc;
+    if ((rc = put(x, d.x)) || (rc = put(y, d.y)) || (rc = put(z, d.z)) || (rc = put(occ, d.occ))) return rc;
+    if (n_ts && (rc = put(n_ts, d.nts))) return rc;
     {
         std::vector<uint32_t> w0((size_t)N);
         for (int64_t i = 0; i < N; ++i) {
@@ -1021,14 +1063,14 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
             const uint32_t idx = d.part ? (uint32_t)(ctx->h_m2s[(size_t)mode[i]] / d.nseg) : (uint32_t)mode[i];
             w0[(size_t)i] = ((uint32_t)(fc + 1) << d.lb) | idx;
         }
-        if ((rc = put(w0.data(), 4, d.w0))) return rc;
+        if ((rc = put((const uint32_t *)w0.data(), d.w0))) return rc;
     }
     if (d.pid) {
-        if (pid) { if ((rc = put(pid, 8, d.pid))) return rc; }
+        if (pid) { if ((rc = put(pid, d.pid))) return rc; }
         else {
             std::vector<uint64_t> ids((size_t)N);
             for (int64_t i = 0; i < N; ++i) ids[(size_t)i] = pid_offset + (uint64_t)i;
-            if ((rc = put(ids.data(), 8, d.pid))) return rc;
+            if ((rc = put((const uint64_t *)ids.data(), d.pid))) return rc;
         }
     }
     NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
@@ -1199,11 +1241,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     const double *pd; const uint32_t *pw; const int32_t *pi; const uint64_t *pu;
 #define NK_PALLOC(T, field, ptr, count)                                                                \
     do { int rc_ = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (rc_) return rc_; d.field = (T *)ptr; } while (0)
-    NK_PALLOC(double, x, pd, d.cap); NK_PALLOC(double, y, pd, d.cap); NK_PALLOC(double, z, pd, d.cap);
-    NK_PALLOC(double, occ, pd, d.cap); NK_PALLOC(double, nts, pd, d.cap);
-    NK_PALLOC(uint32_t, w0, pw, d.cap);
-    d.pid = nullptr;
-    if (nk_want_pid(ctx)) NK_PALLOC(uint64_t, pid, pu, d.cap);
+    { int rcf = nk_alloc_fields(ctx, d, d.cap, nk_want_pid(ctx)); if (rcf) return rcf; }
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
@@ -1275,10 +1313,7 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     int rc = NK_OK;
 #define NK_PALLOC(T, field, ptr, count)                                                                \
     do { if (!rc) { rc = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (!rc) d.field = (T *)ptr; } } while (0)
-    NK_PALLOC(double, x, pd, d.cap); NK_PALLOC(double, y, pd, d.cap); NK_PALLOC(double, z, pd, d.cap);
-    NK_PALLOC(double, occ, pd, d.cap); NK_PALLOC(double, nts, pd, d.cap);
-    NK_PALLOC(uint32_t, w0, pw, d.cap);
-    if (old.pid) NK_PALLOC(uint64_t, pid, pu, d.cap);
+    if (!rc) rc = nk_alloc_fields(ctx, d, d.cap, (bool)old.pid);
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
@@ -1377,7 +1412,7 @@ static int nk_check_ready(nk_ctx *ctx) {
         NkHostParticles h;
         int rc = nk_gather_live(ctx, h, true);
         if (rc) return rc;
-        const bool had_pid = d.pid != nullptr;
+        const bool had_pid = (bool)d.pid;
         const int64_t cap_old = d.cap;
         if ((rc = nk_alloc_particles(ctx, cap_old, h.mode.data(), (int64_t)h.mode.size()))) return rc;
         if (!h.x.empty() && (rc = nk_scatter(ctx, (int64_t)h.x.size(), h.x.data(), h.y.data(), h.z.data(), h.mode.data(), h.occ.data(),
@@ -1449,7 +1484,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));   // row_valid = 0
     const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, d.pid ? 3 : 2), lds_e = nk_lds(ctx, true, 1);
     const int gm_ = nk_geom_mode(ctx);
-    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = d.pid != nullptr, split_ = d.qx != nullptr;
+    const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = (bool)d.pid, split_ = d.qx != nullptr;
     const bool lrec_ = nk_want_lrec(ctx);
     (void)nk_sweep_blocks(ctx);
     const int g_sweep = ctx->g_sweep < (d.nseg + 3) / 4 ? ctx->g_sweep : (d.nseg + 3) / 4;
@@ -1544,7 +1579,47 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
                 double sm = 0; for (double x : v) sm += x;
                 fprintf(stderr, "[stamps] %s [us]: min %.1f  p10 %.1f  median %.1f  mean %.1f  p90 %.1f  max %.1f\n", nm, v.front(), v[v.size() / 10], v[v.size() / 2], sm / v.size(), v[v.size() * 9 / 10], v.back());
             };
+            {   // k_emit's marks of the same step (words 4-7 of the second row): entry, tables in LDS, first entries evaluated, done
+                unsigned long long m0 = ~0ull, m3 = 0;
+                std::vector<double> a, b, c, fin2;
+                for (int sgm = 0; sgm < d.nseg; ++sgm) { const unsigned long long *w = &st[((size_t)d.nseg + sgm) * 8 + 4]; if (w[0] && w[3]) { m0 = std::min(m0, w[0]); m3 = std::max(m3, w[3]); } }
+                for (int sgm = 0; sgm < d.nseg; ++sgm) {
+                    const unsigned long long *w = &st[((size_t)d.nseg + sgm) * 8 + 4];
+                    if (!w[0] || !w[3]) continue;
+                    a.push_back((double)(w[1] - w[0]) * 0.01); b.push_back((double)(w[2] - w[1]) * 0.01); c.push_back((double)(w[3] - w[2]) * 0.01);
+                    fin2.push_back((double)(w[3] - m0) * 0.01);
+                }
+                auto q2 = [](std::vector<double> v, const char *nm) {
+                    if (v.empty()) return;
+                    std::sort(v.begin(), v.end());
+                    double sm = 0; for (double x : v) sm += x;
+                    fprintf(stderr, "[stamps] k_emit %s [us]: min %.1f  median %.1f  mean %.1f  p90 %.1f  max %.1f\n", nm, v.front(), v[v.size() / 2], sm / v.size(), v[v.size() * 9 / 10], v.back());
+                };
+                if (!a.empty()) {
+                    fprintf(stderr, "[stamps] k_emit first entry -> last wave done: %.1f us\n", (double)(m3 - m0) * 0.01);
+                    q2(a, "entry -> tables in LDS"); q2(b, "-> first chunk of entries evaluated"); q2(c, "-> particles built and stored"); q2(fin2, "wave done, after the first entry");
+                }
+            }
             fprintf(stderr, "[stamps] first entry -> last exit: %.1f us over %zu waves\n", (double)(x1 - e0) * 0.01, pro.size());
+            {   // where do the slow waves sit?  mean tile-loop time by workgroup index mod 8 (the XCD under round-robin placement),
+                // by wave within the workgroup, and by thirds of the grid
+                double xs[8] = {0}, xn[8] = {0}, ws[4] = {0}, wn[4] = {0}, gs[4] = {0}, gn[4] = {0};
+                for (int sgm = 0; sgm < d.nseg; ++sgm) {
+                    const unsigned long long *w = &st[((size_t)d.nseg + sgm) * 8];
+                    if (!w[0] || !w[3]) continue;
+                    const double t = (double)(w[2] - w[1]) * 0.01;
+                    const int wg = sgm / 4;
+                    xs[wg % 8] += t; xn[wg % 8] += 1; ws[sgm % 4] += t; wn[sgm % 4] += 1;
+                    const int third = (int)((int64_t)sgm * 4 / d.nseg); gs[third] += t; gn[third] += 1;
+                }
+                fprintf(stderr, "[stamps] tile loop mean [us] by workgroup %% 8:");
+                for (int k = 0; k < 8; ++k) fprintf(stderr, " %.1f", xn[k] ? xs[k] / xn[k] : 0.0);
+                fprintf(stderr, " | by wave of the workgroup:");
+                for (int k = 0; k < 4; ++k) fprintf(stderr, " %.1f", wn[k] ? ws[k] / wn[k] : 0.0);
+                fprintf(stderr, " | by quarter of the grid:");
+                for (int k = 0; k < 4; ++k) fprintf(stderr, " %.1f", gn[k] ? gs[k] / gn[k] : 0.0);
+                fprintf(stderr, "\n");
+            }
             q(pro, "entry -> tile loop (tables into LDS, records)"); q(loop, "tile loop"); q(epi, "tile loop end -> wave through (flush, workgroup barrier, tally row)");
             q(fin, "wave through, after the first entry");
             fprintf(stderr, "[stamps] shader clock inside k_sweep: median %.0f MHz (min %.0f, max %.0f)\n", clk[clk.size() / 2] / 10.0, clk.front() / 10.0, clk.back() / 10.0);

@@ -351,9 +351,16 @@ __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t ste
 template <int GEOM>
 __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
     extern __shared__ __align__(16) unsigned char smem[];
+#ifdef NK_STAMPS
+    const unsigned long long em_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
     if (d.halt[0]) return;
     NkLds L;
     nk_lds_setup<GEOM, 1>(d, smem, L);
+#ifdef NK_STAMPS
+    const unsigned long long em_t1 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long em_t2 = 0;
+#endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: segment bookkeeping lives in scalar registers
     unsigned int *sp_pref = L.sp_pref + wave * NK_EMIT_CHUNK, *sp_cnt = L.sp_cnt + wave * NK_EMIT_CHUNK,
                  *sp_rm = L.sp_rm + wave * NK_EMIT_CHUNK;
@@ -404,6 +411,9 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // LDS is in order per wave; keep the compiler honest
                 spn = (int)run;
             }
+#ifdef NK_STAMPS
+            if (!em_t2) em_t2 = __builtin_amdgcn_s_memrealtime();     // the first chunk of entries is evaluated
+#endif
             for (int spj = 0; spj < spn; spj += NK_TILE) {
                 const int j = spj + lane;
                 if (j >= spn) continue;
@@ -468,11 +478,12 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
                 const int o = count + made + j;
                 if (o < d.segcap) {
                     const int64_t i = base + o;
-                    d.x[i] = x0 + vx * dt_in; d.y[i] = y0 + vy * dt_in; d.z[i] = z0 + vz * dt_in;   // :536
-                    d.occ[i] = occ;
-                    d.nts[i] = tc / d.dt - dt_in / d.dt;                                            // :535
-                    d.w0[i] = NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx;
-                    if (d.pid) d.pid[i] = pid;
+                    const NkSlot q = nk_slot(d, i);
+                    d.x.p[q.od] = x0 + vx * dt_in; d.y.p[q.od] = y0 + vy * dt_in; d.z.p[q.od] = z0 + vz * dt_in;   // :536
+                    d.occ.p[q.od] = occ;
+                    d.nts.p[q.od] = tc / d.dt - dt_in / d.dt;                                            // :535
+                    d.w0.p[q.ow] = NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx;
+                    if (d.pid) d.pid.p[q.od] = pid;
                 } else atomicOr(d.overflow, 1);         // more entering particles than free slots
             }
             made += spn;
@@ -485,6 +496,9 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
             d.seg_new[seg] = made < room ? made : (room > 0 ? room : 0);
             d.seg_bound[seg] = sp_bound;
             if (d.res_gen == 2) d.sp_inbox_n[seg] = 0;
+#ifdef NK_STAMPS
+            if (d.stamps) { unsigned long long *w = d.stamps + ((int64_t)d.nseg + seg) * 8 + 4; w[0] = em_t0; w[1] = em_t1; w[2] = em_t2; w[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
         }
     }
 }
@@ -510,9 +524,9 @@ struct NkOut {
                                           double pnts, uint32_t pw0, unsigned long long ppid) {
         if (put) {
             if (o < d.segcap) {
-                const int64_t i = base + o;
-                NK_ST(d.x + i, px); NK_ST(d.y + i, py); NK_ST(d.z + i, pz); NK_ST(d.occ + i, pocc); NK_ST(d.nts + i, pnts); NK_ST(d.w0 + i, pw0);
-                if (PID) NK_ST(d.pid + i, ppid);
+                const NkSlot q = nk_slot(d, base + o);
+                NK_ST(d.x.p + q.od, px); NK_ST(d.y.p + q.od, py); NK_ST(d.z.p + q.od, pz); NK_ST(d.occ.p + q.od, pocc); NK_ST(d.nts.p + q.od, pnts); NK_ST(d.w0.p + q.ow, pw0);
+                if (PID) NK_ST(d.pid.p + q.od, ppid);
             } else atomicOr(d.overflow, 2);     // segment full
         }
     }
@@ -523,9 +537,9 @@ struct NkOut {
             if (put) {
                 const int o = wout + rank;
                 if (o < d.segcap) {
-                    const int64_t i = base + o;
-                    NK_ST(d.x + i, px); NK_ST(d.y + i, py); NK_ST(d.z + i, pz); NK_ST(d.occ + i, pocc); NK_ST(d.nts + i, pnts); NK_ST(d.w0 + i, pw0);
-                    if (PID) NK_ST(d.pid + i, ppid);
+                    const NkSlot q = nk_slot(d, base + o);
+                    NK_ST(d.x.p + q.od, px); NK_ST(d.y.p + q.od, py); NK_ST(d.z.p + q.od, pz); NK_ST(d.occ.p + q.od, pocc); NK_ST(d.nts.p + q.od, pnts); NK_ST(d.w0.p + q.ow, pw0);
+                    if (PID) NK_ST(d.pid.p + q.od, ppid);
                 } else atomicOr(d.overflow, 2);     // segment full
             }
             wout += n;
@@ -588,6 +602,9 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 #ifndef NK_PREFETCH2
 #define NK_PREFETCH2 0
 #endif
+#ifndef NK_PRIO_ROT
+#define NK_PRIO_ROT 0           // log2 of the tiles between two steps of the sweep's issue-priority rotation (0 = off)
+#endif
 #ifndef NK_DEFER_STORE
 #define NK_DEFER_STORE 0      // measured: no gain (profiles/r03_notes.txt); the switch stays in the source
 #endif
@@ -620,6 +637,9 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
     double *const cP = cX + 6 * 64;
     uint32_t *const cW = reinterpret_cast<uint32_t *>(cX + (PID ? 7 : 6) * 64);
     const int nwaves = gridDim.x * (NK_WG / 64);
+#if NK_PRIO_ROT
+    const int prio_phase = (int)(blockIdx.x / (gridDim.x > 3 ? (gridDim.x + 3) / 4 : 1));     // quarter of the grid = dispatch age
+#endif
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int nnew = d.R > 0 ? d.seg_new[seg] : 0;
@@ -657,9 +677,9 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
         double xN = 0, yN = 0, zN = 0, occN = 0, ntsN = 0;
         unsigned long long pidN = 0;
         if (lane < count) {
-            const int64_t i = base + lane;
-            w0N = NK_LD(d.w0 + i); xN = NK_LD(d.x + i); yN = NK_LD(d.y + i); zN = NK_LD(d.z + i); occN = NK_LD(d.occ + i); ntsN = NK_LD(d.nts + i);
-            if (PID) pidN = NK_LD(d.pid + i);
+            const int64_t i0 = base;
+            w0N = NK_LD(d.w0.tile(i0, lane)); xN = NK_LD(d.x.tile(i0, lane)); yN = NK_LD(d.y.tile(i0, lane)); zN = NK_LD(d.z.tile(i0, lane)); occN = NK_LD(d.occ.tile(i0, lane)); ntsN = NK_LD(d.nts.tile(i0, lane));
+            if (PID) pidN = NK_LD(d.pid.tile(i0, lane));
         }
 #if NK_PREFETCH2
         // a second tile on its way (more bytes in flight per wave: the memory system's latency at this load is about one tile's time)
@@ -667,9 +687,9 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
         double xM = 0, yM = 0, zM = 0, occM = 0, ntsM = 0;
         unsigned long long pidM = 0;
         if (NK_TILE + lane < count) {
-            const int64_t i = base + NK_TILE + lane;
-            w0M = NK_LD(d.w0 + i); xM = NK_LD(d.x + i); yM = NK_LD(d.y + i); zM = NK_LD(d.z + i); occM = NK_LD(d.occ + i); ntsM = NK_LD(d.nts + i);
-            if (PID) pidM = NK_LD(d.pid + i);
+            const int64_t i0 = base + NK_TILE;
+            w0M = NK_LD(d.w0.tile(i0, lane)); xM = NK_LD(d.x.tile(i0, lane)); yM = NK_LD(d.y.tile(i0, lane)); zM = NK_LD(d.z.tile(i0, lane)); occM = NK_LD(d.occ.tile(i0, lane)); ntsM = NK_LD(d.nts.tile(i0, lane));
+            if (PID) pidM = NK_LD(d.pid.tile(i0, lane));
         }
 #endif
         // The finished particles of a tile are STORED at the top of the next iteration, between the wait for that iteration's
@@ -684,6 +704,20 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
         unsigned long long spid = 0;
         for (int t = 0; t <= nA; ++t) {
             const bool flush = t == nA;               // one empty tile: drains the carry
+#if NK_PRIO_ROT
+            // The SIMD's issue arbiter prefers the OLDEST wave: of the workgroups resident on a CU the first-dispatched one runs
+            // ahead and the last one behind (stamps: tile loops of 155 / 165 / 179 / 196 us by quarter of the grid for equal
+            // work), and a sweep ends with its slowest wave.  Every wave therefore rotates its issue priority with the tiles,
+            // the phase taken from its workgroup's position in the dispatch order: over a segment every wave has held every level.
+            if ((t & ((1 << NK_PRIO_ROT) - 1)) == 0) {
+                switch (((t >> NK_PRIO_ROT) + prio_phase) & 3) {
+                    case 0: __builtin_amdgcn_s_setprio(0); break;
+                    case 1: __builtin_amdgcn_s_setprio(1); break;
+                    case 2: __builtin_amdgcn_s_setprio(2); break;
+                    default: __builtin_amdgcn_s_setprio(3); break;
+                }
+            }
+#endif
             bool act = false;
             double x = 0, y = 0, z = 0, occ = 0, nts = 0, omega = 0, E0 = 0, vx = 0, vy = 0, vz = 0;
             uint32_t w0 = 0u;
@@ -704,15 +738,15 @@ __global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || 
 #if NK_PREFETCH2
                 w0N = w0M; xN = xM; yN = yM; zN = zM; occN = occM; ntsN = ntsM; pidN = pidM;
                 if (r + 2 * NK_TILE + lane < count) {
-                    const int64_t i = base + r + 2 * NK_TILE + lane;
-                    w0M = NK_LD(d.w0 + i); xM = NK_LD(d.x + i); yM = NK_LD(d.y + i); zM = NK_LD(d.z + i); occM = NK_LD(d.occ + i); ntsM = NK_LD(d.nts + i);
-                    if (PID) pidM = NK_LD(d.pid + i);
+                    const int64_t i0 = base + r + 2 * NK_TILE;
+                    w0M = NK_LD(d.w0.tile(i0, lane)); xM = NK_LD(d.x.tile(i0, lane)); yM = NK_LD(d.y.tile(i0, lane)); zM = NK_LD(d.z.tile(i0, lane)); occM = NK_LD(d.occ.tile(i0, lane)); ntsM = NK_LD(d.nts.tile(i0, lane));
+                    if (PID) pidM = NK_LD(d.pid.tile(i0, lane));
                 }
 #else
                 if (r + NK_TILE + lane < count) {
-                    const int64_t i = base + r + NK_TILE + lane;
-                    w0N = NK_LD(d.w0 + i); xN = NK_LD(d.x + i); yN = NK_LD(d.y + i); zN = NK_LD(d.z + i); occN = NK_LD(d.occ + i); ntsN = NK_LD(d.nts + i);
-                    if (PID) pidN = NK_LD(d.pid + i);
+                    const int64_t i0 = base + r + NK_TILE;
+                    w0N = NK_LD(d.w0.tile(i0, lane)); xN = NK_LD(d.x.tile(i0, lane)); yN = NK_LD(d.y.tile(i0, lane)); zN = NK_LD(d.z.tile(i0, lane)); occN = NK_LD(d.occ.tile(i0, lane)); ntsN = NK_LD(d.nts.tile(i0, lane));
+                    if (PID) pidN = NK_LD(d.pid.tile(i0, lane));
                 }
 #endif
                 const bool newborn = (w0 & NK_NEWBORN) != 0u;
@@ -1068,8 +1102,9 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                 const int o = atomicAdd(d.seg_count + seg, 1);
                 if (o < d.segcap) {
                     const int64_t i = (int64_t)seg * d.segcap + o;
-                    d.x[i] = p.x; d.y[i] = p.y; d.z[i] = p.z; d.occ[i] = p.occ; d.nts[i] = p.nts; d.w0[i] = w0e;
-                    if (PID) d.pid[i] = pid;
+                    const NkSlot q = nk_slot(d, i);
+                    d.x.p[q.od] = p.x; d.y.p[q.od] = p.y; d.z.p[q.od] = p.z; d.occ.p[q.od] = p.occ; d.nts.p[q.od] = p.nts; d.w0.p[q.ow] = w0e;
+                    if (PID) d.pid.p[q.od] = pid;
                 } else atomicOr(d.overflow, 4);
             } else {                                      // (ROUGH) one 64-byte record into the inbox of the segment that owns the new mode
                 const int dst = hseg;
@@ -1575,37 +1610,21 @@ __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
     }
 }
 // Developer probe (NK_PROBE_COPY=8|16 + nk_calibrate_stream): the sweep's wave-per-segment tile loop with one tile prefetched,
-// copying the particle state in place -- the bandwidth floor of that structure with 8-byte (one particle per lane) or 16-byte
-// (two particles per lane) accesses.
+// copying the particle state in place -- the bandwidth floor of that structure (8-byte accesses, one particle per lane).
 template <int W>
 __global__ __launch_bounds__(NK_WG, 3) void k_probe_copy(NkDev d) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NK_WG / 64);
-    constexpr int PPL = W / 8;                         // particles per lane
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
-        const int count = d.seg_count[seg] & ~(64 * PPL - 1);        // whole tiles only (a probe)
-        if (PPL == 1) {
-            double xN = 0, yN = 0, zN = 0, oN = 0, nN = 0; uint32_t wN = 0;
-            if (count > 0) { const int64_t i = base + lane; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; oN = d.occ[i]; nN = d.nts[i]; wN = d.w0[i]; }
-            for (int r = 0; r < count; r += 64) {
-                const double x = xN, y = yN, z = zN, o = oN, n = nN; const uint32_t w = wN;
-                if (r + 64 < count) { const int64_t i = base + r + 64 + lane; xN = d.x[i]; yN = d.y[i]; zN = d.z[i]; oN = d.occ[i]; nN = d.nts[i]; wN = d.w0[i]; }
-                const int64_t i = base + r + lane;
-                d.x[i] = x + 1e-300; d.y[i] = y; d.z[i] = z; d.occ[i] = o; d.nts[i] = n; d.w0[i] = w;
-            }
-        } else {
-            double2 xN = {0, 0}, yN = {0, 0}, zN = {0, 0}, oN = {0, 0}, nN = {0, 0}; uint2 wN = {0, 0};
-            double2 *X = (double2 *)(d.x + base), *Y = (double2 *)(d.y + base), *Z = (double2 *)(d.z + base), *O = (double2 *)(d.occ + base),
-                    *N = (double2 *)(d.nts + base);
-            uint2 *Wp = (uint2 *)(d.w0 + base);
-            if (count > 0) { xN = X[lane]; yN = Y[lane]; zN = Z[lane]; oN = O[lane]; nN = N[lane]; wN = Wp[lane]; }
-            for (int r = 0; r < count / 2; r += 64) {
-                const double2 x = xN, y = yN, z = zN, o = oN, n = nN; const uint2 w = wN;
-                if (r + 64 < count / 2) { const int i = r + 64 + lane; xN = X[i]; yN = Y[i]; zN = Z[i]; oN = O[i]; nN = N[i]; wN = Wp[i]; }
-                const int i = r + lane;
-                X[i] = make_double2(x.x + 1e-300, x.y); Y[i] = y; Z[i] = z; O[i] = o; N[i] = n; Wp[i] = w;
-            }
+        const int count = d.seg_count[seg] & ~63;        // whole tiles only (a probe)
+        double xN = 0, yN = 0, zN = 0, oN = 0, nN = 0; uint32_t wN = 0;
+        if (count > 0) { const int64_t i0 = base; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
+        for (int r = 0; r < count; r += 64) {
+            const double x = xN, y = yN, z = zN, o = oN, n = nN; const uint32_t w = wN;
+            if (r + 64 < count) { const int64_t i0 = base + r + 64; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
+            const int64_t i0 = base + r;
+            *d.x.tile(i0, lane) = x + 1e-300; *d.y.tile(i0, lane) = y; *d.z.tile(i0, lane) = z; *d.occ.tile(i0, lane) = o; *d.nts.tile(i0, lane) = n; *d.w0.tile(i0, lane) = w;
         }
     }
 }
