@@ -313,9 +313,12 @@ class OracleSim(object):
     def init_boundaries(self):
         self.L.nko_init_boundaries(self.ref(self.mesh), self.ref(self.mat), self.ref(self.p), self.ref(self.P.s))
 
-    def run_timestep_sharded(self, allreduce, emit=True, contains_every=100):
+    def run_timestep_sharded(self, allreduce, emit=True, contains_every=100, halt_requests=(0, 0)):
         """run_timestep for one rank of a particle-sharded ensemble: `allreduce(vec)` sums a float64 vector over the
-        ranks in place (the role RCCL plays in the HIP engine).  Tallied vector: E_raw[S] | N_sv[S]."""
+        ranks in place (the role RCCL plays in the HIP engine).  Tallied vector: E_raw[S] | N_sv[S] | N_leaving[R] | the two
+        halt requests that ride on it in the engine (nk_kernels.h k_reduce: "a segment could overflow at the next step",
+        "a segment cannot take the migrants in its inbox"); returns their sums: every rank sees a request of any rank at the
+        same step."""
         L = self.L
         if contains_every and self.step % contains_every == 0:
             L.nko_contains_check(self.ref(self.mat), self.ref(self.mesh), self.ref(self.p),
@@ -332,17 +335,20 @@ class OracleSim(object):
                                   _p(self.res_flux, c_dp))
         L.nko_tally(self.ref(self.mat), self.ref(self.sv), self.ref(self.p), self.ref(self.P.s), _p(self.T_sv, c_dp),
                     _p(self.N_sv, c_lp), _p(self.E_raw, c_dp))
-        vec = np.concatenate((self.E_raw, self.N_sv.astype(np.float64), self.N_leaving[:self.R].astype(np.float64)))
+        vec = np.concatenate((self.E_raw, self.N_sv.astype(np.float64), self.N_leaving[:self.R].astype(np.float64),
+                              np.asarray(halt_requests, dtype=np.float64)))
         allreduce(vec)
         self.E_raw[:] = vec[:self.S]
         self.N_sv[:] = np.rint(vec[self.S:2 * self.S]).astype(np.int64)
         if self.R > 0 and self.res.gen == 2:             # one_to_one: next step emits what left on ALL ranks
-            self.res.n_leaving_array[:] = np.rint(vec[2 * self.S:]).astype(np.int64)
+            self.res.n_leaving_array[:] = np.rint(vec[2 * self.S:2 * self.S + self.R]).astype(np.int64)
+        halts = (float(vec[-2]), float(vec[-1]))
         L.nko_update_T(self.ref(self.mat), self.ref(self.sv), self.ref(self.p), _p(self.N_sv, c_lp), _p(self.E_raw, c_dp),
                        _p(self.T_sv, c_dp), _p(self.E_sv, c_dp))
         L.nko_assign_T(self.ref(self.sv), _p(self.T_sv, c_dp), self.ref(self.P.s))
         L.nko_lifetime_scattering(self.ref(self.mat), self.ref(self.p), self.ref(self.P.s))
         self.step += 1
+        return halts
 
     def run_timestep(self, emit=True, contains_every=100):
         L = self.L

@@ -77,6 +77,77 @@ class Recorder(object):
         return dict(slots=0, live=0)
 
 
+class DeviceRecorder(Recorder):
+    """The same stand-in with the methods of the engine's DEVICE builders (nk_rough_begin / nk_specular_pairs / nk_rough_pairs /
+    nk_rough_finish, nk_build_enter_prob, nk_init_particles, nk_tally_state): `Population(args, <reference geo>, <reference
+    phonon>)` then takes the branch a GPU run takes (population.py: _build_rough_tables, initialise_reservoirs,
+    _init_on_device), and what it hands to those builders -- normals, eta, k-norms, thickness, subvolume shares -- is
+    recorded.  Values the constructor needs back are computed with plain NumPy (enter_prob) or are placeholders (t = 0 tally)."""
+
+    def __init__(self):
+        super(DeviceRecorder, self).__init__()
+        self.normals, self.shares = [], []
+
+    def specular_begin(self, group_vel, omega, delta_omega):
+        self._rec('spec_begin', group_vel=np.asarray(group_vel), omega=np.asarray(omega), delta_omega=np.asarray(delta_omega))
+
+    def specular_pairs(self, normal, crit=1e-3, download=True):
+        self.normals.append(np.asarray(normal, dtype=float))
+        self._rec('spec_pairs', normals=np.array(self.normals), crit=np.array(crit))
+        return (np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int32)) if download else None
+
+    def specular_end(self):
+        pass
+
+    def rough_begin(self, facets, normal_in, eta, k_norm):
+        self._rec('rough_begin', facets=np.asarray(facets), normal_in=np.asarray(normal_in), eta=np.asarray(eta), k_norm=np.asarray(k_norm))
+
+    def rough_pairs(self, idx):
+        self.shares.append(np.asarray(idx))
+        self._rec('rough_pairs', share_flat=np.concatenate(self.shares), share_len=np.array([len(a) for a in self.shares]))
+
+    def rough_finish(self, degeneracies=None, degen_j2=None):
+        self._rec('rough_finish', has_degen=np.array(degeneracies is not None))
+
+    def build_enter_prob(self, normal_in, thickness, dt):
+        self._rec('enter_prob_args', normal_in=np.asarray(normal_in), thickness=np.asarray(thickness), dt=np.array(dt))
+        vg = self.calls['material']['group_vel']
+        p = np.einsum('rd,qjd->rqj', np.asarray(normal_in), vg) * dt / np.asarray(thickness).reshape(-1, 1, 1)
+        return np.where(p < 0, 0, p).reshape(len(thickness), -1)
+
+    def init_particles(self, n, capacity, pid_lo, unique_modes, sv_first=None):
+        self._rec('init_particles', n=np.array(n), capacity=np.array(capacity), pid_lo=np.array(pid_lo), unique_modes=np.asarray(unique_modes),
+                  sv_first=np.asarray(sv_first if sv_first is not None else np.zeros(0)))
+        self._sv_first = None if sv_first is None else np.asarray(sv_first)
+
+    def tally_state(self):
+        S = self.calls['subvols']['centers'].shape[0]
+        N = np.diff(self._sv_first).astype(float) if self._sv_first is not None else np.zeros(S)
+        return np.zeros(S), N, np.zeros((S, 3))
+
+    def comm_info(self):
+        return dict(comm_nranks=0)
+
+
+def build_device(case, particles):
+    """The constructor's DEVICE-builder branch with the reference's objects: arguments only (prefix <case>_dev__)."""
+    argv = H.argv_for(case, particles)
+    args = H.make_args(ref, argv)
+    geo = ref.Geometry(args)
+    ph = H.make_phonon(ref, args, make_material(9, 'Si', temperatures=np.arange(200.0, 401.0, 10.0)))
+    args.results_folder = ''
+    np.random.seed(4321)
+    rec = DeviceRecorder()
+    pop = Population(args, geo, ph, engine=rec)
+    out = {}
+    for name in ('spec_begin', 'spec_pairs', 'rough_begin', 'rough_pairs', 'rough_finish', 'enter_prob_args', 'init_particles'):
+        for k, v in rec.calls.get(name, {}).items():
+            out['%s_dev__%s__%s' % (case, name, k)] = v
+    out['%s_dev__rough_on_device' % case] = np.array(bool(getattr(pop, '_rough_on_device', False)))
+    out['%s_dev__N_p' % case] = np.array(pop.N_p)
+    return out
+
+
 def build(case, particles):
     argv = H.argv_for(case, particles)
     args = H.make_args(ref, argv)
@@ -101,5 +172,7 @@ if __name__ == '__main__':
     out = {}
     out.update(build('ttp', 20000))
     out.update(build('ttrrp', 20000))
+    out.update(build_device('ttp', 200000))         # enough particles for tiled modes: nk_init_particles is taken
+    out.update(build_device('ttrrp', 200000))
     np.savez_compressed(os.path.join(HERE, 'dropin.npz'), **out)
     print('wrote dropin.npz: %d arrays' % len(out))

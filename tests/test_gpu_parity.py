@@ -726,3 +726,37 @@ def test_rough_tables_built_on_device_equal_host_builders_and_goldens():
         sim.run_timestep()
         assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
         assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+
+
+def test_two_rank_shards_grow_with_rough_walls(monkeypatch):
+    """Rough walls on several ranks with a store that is too small (NK_TIGHT_STORE, six times the entry rate): the sweeps'
+    halt requests and -- new in round 3 -- the 'a segment cannot take the migrants in its inbox' flag travel with the tally
+    vector, so a rank grows its store and delivers instead of giving up (round 2 returned NK_ERR_CAPACITY there as soon as
+    nranks > 1).  Two contexts on one GPU (NK_COMM_DRYRUN: no communicator); trajectories do not depend on the
+    temperatures, so the union of the shards must be the single-rank run's particles."""
+    from nanokappa_amd.sharding import shard_range
+    monkeypatch.setenv('NK_TIGHT_STORE', '1')
+    ct = case_tables('ttrrp')
+    n = 24000
+    pos, mode, occ, counter = random_population(ct, n, seed=13)
+    ref = make_engine(ct, pos, mode, occ, counter, seed=5, emit_scale=6.0)
+    slots0 = ref.timing()['slots']
+    ref.step(70)
+    p = ref.download()
+    assert ref.timing()['slots'] > slots0 and ref.timing()['regrows'] > 0
+    ref.close()
+    monkeypatch.setenv('NK_COMM_DRYRUN', '1')
+    parts, grew = [], 0
+    for r in (0, 1):
+        lo, hi = shard_range(n, r, 2)
+        e = make_engine(ct, pos[lo:hi], mode[lo:hi], occ[lo:hi], counter, seed=5, emit_scale=6.0, pid_offset=lo, comm=(bytes(128), r, 2))
+        e.step(70)                           # must not raise: every halt is served by growing the store
+        grew += e.timing()['regrows']
+        parts.append(e.download())
+        e.close()
+    assert grew > 0
+    pid = np.concatenate([q['pid'] for q in parts])
+    o1, o2 = np.argsort(p['pid']), np.argsort(pid)
+    assert np.array_equal(p['pid'][o1], pid[o2])
+    assert np.array_equal(p['mode'][o1], np.concatenate([q['mode'] for q in parts])[o2])
+    assert np.array_equal(p['positions'][o1], np.concatenate([q['positions'] for q in parts])[o2])

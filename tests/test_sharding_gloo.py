@@ -77,6 +77,62 @@ def test_two_rank_union_equals_single_run(tmp_path, gen):
     assert abs(r0['pid'].shape[0] - r1['pid'].shape[0]) < 0.05 * n
 
 
+def _halt_worker(rank, world, port, out_dir):
+    sys.path.insert(0, HERE)
+    import torch
+    import torch.distributed as dist
+    from nanokappa_amd.sharding import shard_range
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    ct = case_tables('ttrrp')
+    pos, mode, occ, counter = random_population(ct, 8000, seed=5)
+    lo, hi = shard_range(pos.shape[0], rank, world)
+    sim = make_oracle_sim(ct, pos[lo:hi], mode[lo:hi], occ[lo:hi], counter, seed=17, cap=30000)
+    sim.P.pid[:hi - lo] = np.arange(lo, hi, dtype=np.uint64)
+    sim.rank, sim.nranks = rank, world
+
+    def allreduce(vec):
+        dist.all_reduce(torch.from_numpy(vec))
+
+    done, seen = 0, None
+    for s in range(NSTEPS):
+        # rank 1's store "cannot take its migrants" during step 4, rank 0 asks for head room during step 7: whichever comes
+        # first stops BOTH ranks after that very step (the engine: halt[0] raised by the update on every rank)
+        req = (1 if (rank == 0 and s == 7) else 0, 1 if (rank == 1 and s == 4) else 0)
+        halts = sim.run_timestep_sharded(allreduce, halt_requests=req)
+        done += 1
+        if halts[0] > 0 or halts[1] > 0:
+            seen = halts
+            break
+    n = sim.P.N
+    np.savez(os.path.join(out_dir, 'halt%d.npz' % rank), done=done, seen=np.array(seen), pid=sim.P.pid[:n], pos=sim.P.pos[:n])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_halt_requests_ride_on_the_tally_vector(tmp_path):
+    """The two halt requests of the engine's step (k_reduce -> all-reduce -> update, csrc/nk_kernels.h) as entries of the
+    summed vector, with rough walls ('ttrrp') on two ranks: a request raised by ONE rank during a step is seen by BOTH after
+    that step's all-reduce, so they stop at the same step with a consistent ensemble -- which the host then grows."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_halt_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / 'halt0.npz'), np.load(tmp_path / 'halt1.npz')
+    assert int(r0['done']) == int(r1['done']) == 5                       # rank 1's request at step index 4 stops both after it
+    assert np.array_equal(r0['seen'], [0.0, 1.0]) and np.array_equal(r1['seen'], [0.0, 1.0])
+    ct = case_tables('ttrrp')
+    pos, mode, occ, counter = random_population(ct, 8000, seed=5)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=17, cap=30000)
+    for _ in range(5):
+        sim.run_timestep()
+    n = sim.P.N
+    pid = np.concatenate((r0['pid'], r1['pid']))
+    o, o1 = np.argsort(pid), np.argsort(sim.P.pid[:n])
+    assert np.array_equal(pid[o], sim.P.pid[:n][o1])
+    assert np.allclose(np.concatenate((r0['pos'], r1['pos']))[o], sim.P.pos[:n][o1], rtol=1e-10, atol=1e-8)
+
+
 def test_sharding_rules():
     from nanokappa_amd.sharding import shard_range, emission_owner, emission_pid
     n = 1000003
