@@ -77,6 +77,9 @@ struct nk_ctx {
     void *mig_buf = nullptr, *mig_n = nullptr;   // migration inboxes (rough facets; sized with nseg and segcap)
     double *ep_p = nullptr, *rc_p = nullptr;     // (reservoir, mode) tables in the segments' order (sized with nseg)
     int rm_nseg = 0;                             // segmentation rc_p was built for (0: the counters live in res_counter)
+    void *pin = nullptr;           // pinned host staging of the history rows + the halt words of a batch
+    size_t pin_bytes = 0;
+    int32_t halt_words[4] = {0, 0, 0, 0};
     double *acc = nullptr;         // [NB + 2]: tally columns, then the two halt requests that travel with them
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -348,6 +351,7 @@ void nk_destroy(nk_ctx *ctx) {
     for (void *p : ctx->allocs) hipFree(p);
     for (void *p : ctx->pallocs) hipFree(p);
     if (ctx->acc) hipFree(ctx->acc);
+    if (ctx->pin) hipHostFree(ctx->pin);
     if (ctx->hist) hipFree(ctx->hist);
     if (ctx->modetab_p) hipFree(ctx->modetab_p);
     if (ctx->m2s_dev) hipFree(ctx->m2s_dev);
@@ -1104,6 +1108,7 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
         NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, lrec_, (e_ = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds_w)));
         if (e_ != hipSuccess || per_cu < 1) per_cu = 1;
         if (per_cu > 8) per_cu = 8;
+        { const int bound = NK_SWEEP_BOUND(gm_, rough_, rbf_, split_); if (per_cu > bound) per_cu = bound; }   // what it was compiled for
         if (const char *e = getenv("NK_SWEEP_PER_CU")) { int v = atoi(e); if (v >= 1 && v < per_cu) per_cu = v; }   // developer probe
         ctx->g_sweep = ctx->num_cu * per_cu;
         ctx->g_sweep_key = key;
@@ -1491,7 +1496,9 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     const int g_emit = ctx->num_cu * 8 < (d.nseg + 3) / 4 ? ctx->num_cu * 8 : (d.nseg + 3) / 4;
     const int g_ev = split_ ? ctx->num_cu * NK_EVENTS_OCC : 0;   // k_events: resident waves drawing from all queues
     const int rows = g_sweep + g_ev;
-    const int nev = nsteps < 16 ? nsteps : 16;          // per-kernel timing on (up to) the first 16 steps of the batch
+    // per-kernel timing on (up to) the first 16 steps of a batch; none for the short calls of a driver that steps one by one
+    // (six event records are a tenth of such a call)
+    const int nev = nsteps < 4 ? 0 : (nsteps < 16 ? nsteps : 16);
     if (ctx->evpool.empty()) {                           // events are created once and reused
         ctx->evpool.resize(16 * 4 + 2);
         for (auto &e : ctx->evpool) NK_HIP(hipEventCreate(&e));
@@ -1502,6 +1509,9 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     NK_HIP(hipEventRecord(t0, ctx->stream));
     bool pending = ctx->pending_relax;
     std::vector<char> relax_flushed((size_t)nsteps, 0);       // steps whose deferred relaxation k_relax ran before them
+    // (Tried: the NEXT step's emission on a second stream beside k_reduce / k_update, its counters double-buffered so that an
+    // emission that ran ahead of a halt could be run again.  The two cross-stream event waits per step cost more than the 12 us
+    // they hid: 0.289 against 0.270 ms per step on config 2, profiles/r03_notes.txt.)
     for (int s = 0; s < nsteps; ++s) {
         const int64_t stepno = ctx->step + s;
         const uint32_t step = (uint32_t)stepno;
@@ -1545,9 +1555,22 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     }
     NK_HIP(hipEventRecord(t1, ctx->stream));
     NK_HIP(hipGetLastError());
+    // the history rows and the halt words come back through pinned memory, enqueued behind the steps: ONE wait per call (a
+    // Population.run_timestep is one such call per step -- the reference driver's granularity, nanokappa.py:91-98)
+    const size_t hbytes = (size_t)nsteps * HROW * sizeof(double);
+    if (hbytes + 64 > ctx->pin_bytes) {
+        if (ctx->pin) hipHostFree(ctx->pin);
+        ctx->pin = nullptr; ctx->pin_bytes = 0;
+        const size_t want = ((size_t)(nsteps < 1024 ? 1024 : nsteps)) * HROW * sizeof(double) + 64;
+        NK_HIP(hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
+        ctx->pin_bytes = want;
+    }
+    NK_HIP(hipMemcpyAsync(ctx->pin, ctx->hist, hbytes, hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipMemcpyAsync((char *)ctx->pin + ctx->pin_bytes - 64, d.halt, 16, hipMemcpyDeviceToHost, ctx->stream));
     NK_HIP(hipStreamSynchronize(ctx->stream));
     h.resize((size_t)nsteps * HROW);
-    NK_HIP(hipMemcpy(h.data(), ctx->hist, h.size() * sizeof(double), hipMemcpyDeviceToHost));
+    memcpy(h.data(), ctx->pin, hbytes);
+    memcpy(ctx->halt_words, (char *)ctx->pin + ctx->pin_bytes - 64, 16);
 #ifdef NK_STAMPS
     if (d.stamps) {                                     // developer build: section shares of the LAST sweep of the batch
         std::vector<unsigned long long> st((size_t)d.nseg * 16);
@@ -1715,8 +1738,8 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         }
         ctx->step += nd;
         s_out += nd;
-        int32_t hw[4] = {0, 0, 0, 0};
-        NK_HIP(hipMemcpy(hw, d.halt, 16, hipMemcpyDeviceToHost));
+        int32_t hw[4];
+        memcpy(hw, ctx->halt_words, 16);                 // as the batch left them (copied with the history rows)
         if (s_out < nsteps || hw[0] || hw[2] || hw[3]) {
             // halted: a segment could overflow at the next step (or could not take its migrants, which then wait in its
             // inbox).  Grow every segment by half (on the device, state intact), deliver, and carry on.
@@ -1952,6 +1975,8 @@ int nk_init_particles(nk_ctx *ctx, int64_t N, int64_t capacity, uint64_t pid_lo,
     int32_t ovf = 0;
     NK_HIP(hipMemcpyAsync(&ovf, d.overflow, 4, hipMemcpyDeviceToHost, ctx->stream));
     NK_HIP(hipStreamSynchronize(ctx->stream));
+    NK_ARG(!(ovf & 64), "nk_init_particles: a particle did not find its subvolume in 4096 draws ('random_subvol' with very small "
+                         "subvolumes): create the particles on the host (NK_HOST_INIT=1)");
     NK_ARG(ovf == 0, "nk_init_particles: a segment overflowed (internal sizing error)");
     ctx->pending_relax = false;
     return NK_OK;

@@ -177,34 +177,61 @@ __device__ __forceinline__ void nk_lds_setup(const NkDev &d, unsigned char *smem
     double *Tsv = const_cast<double *>(L.tb.Tsv), *cen = const_cast<double *>(L.tb.cen);
     NkSv *sv = const_cast<NkSv *>(L.tb.sv);
     const int t = threadIdx.x, nth = blockDim.x;
-    for (int i = t; i < S + d.rbf_P; i += nth) Tsv[i] = d.T_sv[i];
-    for (int i = t; i < 3 * S; i += nth) cen[i] = d.centers[i];
-    for (int i = t; i < S; i += nth) {
+    // Every table is small (a box: 20 + 60 + 192 + 36 + ... entries), so a thread's share of each is one element -- and one
+    // loop per table means one memory round trip per table, nine of them in a row (stamps: 6.3 us of k_emit's 36, 8.5 us of
+    // the sweep's prologue).  The FIRST element of every table is therefore requested up front, all loads in flight
+    // together, and stored afterwards; whatever a table has beyond blockDim.x elements follows in ordinary loops.
+    const int nT = S + d.rbf_P, a = d.sv_axis, nface = Fl * NK_FACE_DOUBLES, nplane = Pl * NK_PLANE_DOUBLES;
+    const int nfw = Fcl * (int)(sizeof(NkFacet) / 4);
+    const int jn = t + 1 < S ? t + 1 : t;
+    const double l_T = t < nT ? d.T_sv[t] : 0.0;
+    const double l_cen = t < 3 * S ? d.centers[t] : 0.0;
+    const double l_c = t < S ? d.centers[3 * t + a] : 0.0, l_cn = t < S ? d.centers[3 * jn + a] : 0.0, l_Tn = t < S ? d.T_sv[jn] : 0.0;
+    const double l_rT = t < R ? d.res_T[t] : 1.0;
+    const double l_face = t < nface ? d.faces[t] : 0.0;
+    const double l_plane = t < nplane ? d.planes[t] : 0.0;
+    const int l_off = (nrf > 0 && t <= R) ? d.res_face_off[t] : 0;
+    const double l_cdf = t < nrf ? d.res_face_cdf[t] : 0.0;
+    const double l_vert = t < 9 * nrf ? d.res_face_verts[t] : 0.0;
+    const int32_t l_fw = t < nfw ? ((const int32_t *)d.facets)[t] : 0;
+    if (t < nT) Tsv[t] = l_T;
+    if (t < 3 * S) cen[t] = l_cen;
+    if (t < S) {
         // per-subvolume record: centre along the slice axis, T, slope of interp1d's bracket (i, i+1), 1 / T
-        const int a = d.sv_axis, j = i + 1 < S ? i + 1 : i;
+        NkSv q;
+        q.c = l_c; q.T = l_T; q.slope = jn > t ? (l_Tn - l_T) / (l_cn - l_c) : 0.0; q.invT = 1.0 / l_T;
+        sv[t] = q;
+    }
+    if (t < R) { L.bins.nleave[t] = 0u; resT[2 * t] = l_rT; resT[2 * t + 1] = 1.0 / l_rT; }
+    if (t < nface) faces[t] = l_face;
+    if (t < nplane) planes[t] = l_plane;
+    if (nrf > 0 && t <= R) rf_off[t] = l_off;
+    if (t < nrf) rf_cdf[t] = l_cdf;
+    if (t < 9 * nrf) rf_verts[t] = l_vert;
+    if (t < nfw) ((int32_t *)facets)[t] = l_fw;
+    for (int i = t; i < NK_NREP * S; i += nth) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
+    for (int i = t; i < NK_NREP * 3 * S; i += nth) L.bins.flux[i] = 0.0;
+    for (int i = t; i < 4 * R; i += nth) L.bins.resb[i] = 0.0;
+    if (t == 0) L.bins.misc[0] = 0u;
+    // the rest of tables that are longer than the workgroup
+    for (int i = t + nth; i < nT; i += nth) Tsv[i] = d.T_sv[i];
+    for (int i = t + nth; i < 3 * S; i += nth) cen[i] = d.centers[i];
+    for (int i = t + nth; i < S; i += nth) {
+        const int j = i + 1 < S ? i + 1 : i;
         const double c = d.centers[3 * i + a], cn = d.centers[3 * j + a], T = d.T_sv[i], Tn = d.T_sv[j];
         NkSv q;
         q.c = c; q.T = T; q.slope = j > i ? (Tn - T) / (cn - c) : 0.0; q.invT = 1.0 / T;
         sv[i] = q;
     }
-    for (int i = t; i < NK_NREP * S; i += nth) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
-    for (int i = t; i < NK_NREP * 3 * S; i += nth) L.bins.flux[i] = 0.0;
-    for (int i = t; i < 4 * R; i += nth) L.bins.resb[i] = 0.0;
-    for (int i = t; i < R; i += nth) { L.bins.nleave[i] = 0u; const double T = d.res_T[i]; resT[2 * i] = T; resT[2 * i + 1] = 1.0 / T; }
-    if (t == 0) L.bins.misc[0] = 0u;
-    for (int i = t; i < Fl * NK_FACE_DOUBLES; i += nth) faces[i] = d.faces[i];
-    for (int i = t; i < Pl * NK_PLANE_DOUBLES; i += nth) planes[i] = d.planes[i];
+    for (int i = t + nth; i < R; i += nth) { L.bins.nleave[i] = 0u; const double T = d.res_T[i]; resT[2 * i] = T; resT[2 * i + 1] = 1.0 / T; }
+    for (int i = t + nth; i < nface; i += nth) faces[i] = d.faces[i];
+    for (int i = t + nth; i < nplane; i += nth) planes[i] = d.planes[i];
     if (nrf > 0) {
-        for (int i = t; i <= R; i += nth) rf_off[i] = d.res_face_off[i];
-        for (int i = t; i < nrf; i += nth) rf_cdf[i] = d.res_face_cdf[i];
-        for (int i = t; i < 9 * nrf; i += nth) rf_verts[i] = d.res_face_verts[i];
+        for (int i = t + nth; i <= R; i += nth) rf_off[i] = d.res_face_off[i];
+        for (int i = t + nth; i < nrf; i += nth) rf_cdf[i] = d.res_face_cdf[i];
+        for (int i = t + nth; i < 9 * nrf; i += nth) rf_verts[i] = d.res_face_verts[i];
     }
-    {
-        const int nw = Fcl * (int)(sizeof(NkFacet) / 4);
-        const int32_t *src = (const int32_t *)d.facets;
-        int32_t *dst = (int32_t *)facets;
-        for (int i = t; i < nw; i += nth) dst[i] = src[i];
-    }
+    for (int i = t + nth; i < nfw; i += nth) ((int32_t *)facets)[i] = ((const int32_t *)d.facets)[i];
     __syncthreads();
 }
 
@@ -614,11 +641,16 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 #ifndef NK_SWEEP_OCC_SPLIT
 #define NK_SWEEP_OCC_SPLIT 4
 #endif
+// workgroups per CU an instantiation is compiled for AND launched at (nk_sweep_blocks caps the grid there: with the machine
+// LICM off the plain sweep needs 128 VGPRs and the hardware would take four, which measured no faster than three -- more,
+// shorter segments -- and less evenly): rough facets on a small mesh fit three (166 VGPRs), RBF temperatures and large
+// meshes in the fused form two.
+#define NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT) ((SPLIT) ? NK_SWEEP_OCC_SPLIT : (((GEOM) == 2 || (RBF)) ? NK_SWEEP_OCC_BIG : NK_SWEEP_OCC))
 // FAST: the commonest configuration compiled without the general branches -- slice subvolumes, 'nearest' (1) or 'linear' (2)
 // particle temperatures, local reference temperature: the run-time switches become constants of a copy of the parameter
 // block (worth 2-3 % of the sweep: fewer instructions in every classification, interpolation and tally).
 template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC, int FAST = 0>
-__global__ __launch_bounds__(NK_WG, SPLIT ? NK_SWEEP_OCC_SPLIT : ((GEOM == 2 || ROUGH || RBF) ? NK_SWEEP_OCC_BIG : NK_SWEEP_OCC)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
+__global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef NK_STAMPS
     const unsigned long long st_entry_r = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
@@ -1428,7 +1460,7 @@ __global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, ui
         if (sv_first) { int lo = 0, hi = d.S; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (sv_first[mid] <= (int64_t)pid) lo = mid; else hi = mid; } want = lo; }
         double x = 0.0, y = 0.0, z = 0.0;
         int s = 0;
-        for (uint32_t t = 0; t < 4096u; ++t) {         // (a subvolume holds at least 1 / 4096 of the volume, or keeps the last draw)
+        for (uint32_t t = 0; t < 4096u; ++t) {         // rejection sampling: a subvolume is expected to hold well over 1 / 4096 of the volume
             double u[6];
             nk_uniform2_dev(d.seed, pid, 0u, NK_TAG_INIT + 3u * t + 0u, u[0], u[1]);
             nk_uniform2_dev(d.seed, pid, 0u, NK_TAG_INIT + 3u * t + 1u, u[2], u[3]);
@@ -1442,6 +1474,7 @@ __global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, ui
             for (int q = 0; q < 4; ++q) { const double wq = a[q] / asum; x += wq * sp[3 * q]; y += wq * sp[3 * q + 1]; z += wq * sp[3 * q + 2]; }
             s = nk_classify(d, L.tb, x, y, z);
             if (want < 0 || s == want) break;
+            if (t == 4095u) atomicOr(d.overflow, 64);     // never found its subvolume: the host refuses the ensemble (nk_init_particles)
         }
         const NkMode *rec = d.modetab + mode;
         const double occ = nk_occupation(d, L.tb.Tsv[s], rec->omega, rec->E0);

@@ -303,6 +303,10 @@ class Population(Constants):
             return False
         if self.args.part_dist[0] not in ('random_domain', 'random_subvol') or self.particles_pmps < 1:
             return False
+        if self.args.part_dist[0] == 'random_subvol' and self.n_of_subvols > 256:
+            # the device samples a subvolume's points by rejection from the whole solid: about S draws per particle, and it
+            # refuses the ensemble when a particle finds its subvolume in none of 4096 -- many small subvolumes take the host path
+            return False
         return getattr(geometry.mesh, 'n_of_simplices', 0) > 0 and hasattr(geometry.mesh, 'simplices_points')
 
     def _subvol_shares(self, geometry):
