@@ -7,10 +7,12 @@
 // owned by one wave at a time.
 // Modes are PARTITIONED over the segments: every mode has a slot = local index * nseg + segment (NkDev::m2s / s2m) and is
 // stored as its local index (a few bits).  The slots are dealt on the host (nk_build_mode_map) in the order of the modes'
-// boundary-event rate, back and forth over the segments, so that every segment gets the same number of modes AND the same
-// share of fast and slow ones: a wave owns a segment for a whole sweep, and with "segment = m % nseg" a segment count that
-// is a multiple of the branch count gave every segment ONE branch -- events per segment between 4 and 22 per step around a
-// mean of 8.6 in the 200 A box, the slowest wave 1.45 x the mean (profiles/r03_notes.txt).  A segment therefore only ever touches its own few dozen 64-byte mode records (they sit contiguously in a
+// boundary-event rate, each mode to the segment that is furthest behind its share of the work (particles + events), so that
+// every segment gets its share of fast and slow modes: a wave owns a segment for a whole sweep, and with "segment = m % nseg"
+// a segment count that is a multiple of the branch count gave every segment ONE branch -- events per segment between 4 and
+// 22 per step around a mean of 8.6 in the 200 A box, the slowest wave 1.45 x the mean (profiles/r03_notes.txt).  The shares
+// are not equal: the SIMD's arbiter issues the oldest wave first, so of the workgroups resident on a CU the first-dispatched
+// runs ahead (tile loops of 164 / 183 / 209 us for equal work); a segment's share follows its workgroup's place in that order.  A segment therefore only ever touches its own few dozen 64-byte mode records (they sit contiguously in a
 // permuted copy of the mode table and stay in L1/L2), and it emits the reservoir particles of its own modes itself: no
 // spawn list, no global atomics, no gathers across an 11 MB table.  (With rough facets a reflection changes the mode: such a
 // particle finishes its step where it is and then migrates to the owning segment through that segment's inbox, k_deliver.)
@@ -86,6 +88,7 @@ struct NkDev {
     const NkMode *modetab_p;          // [nseg * nlmax] permuted copy: record of the mode with slot l * nseg + s at s * nlmax + l
     const int32_t *m2s;               // [M] slot of a mode (slot % nseg = its segment, slot / nseg = its local index there)
     const int32_t *s2m;               // [nseg * nlmax] mode of (segment s, local index l) at s * nlmax + l; -1 where there is none
+    const int32_t *seg_nl;            // [nseg] modes a segment owns (its local indices 0 .. seg_nl - 1)
     int32_t tau_row0;                 // first T_grid row held in NkMode::tau
     double tau_g[NK_TAU_ROWS];        // T_grid[tau_row0 .. tau_row0+2] by value (scalar registers, no loads)
     double tau_ig[NK_TAU_ROWS - 1];   // 1 / (g[k+1] - g[k]) of the two packed intervals

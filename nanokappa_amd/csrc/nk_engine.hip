@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <functional>
+#include <queue>
 #include <string>
 #include <type_traits>
 #include <vector>
@@ -69,14 +70,14 @@ struct nk_ctx {
     bool stepped = false;             // a timestep has run (the emission ownership of a rank is fixed from then on)
     std::vector<double> h_vg;         // host copy of the group velocities (the mode map deals the modes by their event rate)
     std::vector<int32_t> h_m2s, h_s2m;  // host copies of the mode map (NkDev::m2s / s2m), built with the segmentation
-    int32_t *m2s_dev = nullptr, *s2m_dev = nullptr;
+    int32_t *m2s_dev = nullptr, *s2m_dev = nullptr, *nl_dev = nullptr;
     int map_nseg = 0;                 // segmentation the map was dealt for
     NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
     int64_t modetab_p_len = 0;
     void *inbox = nullptr, *inbox_n = nullptr;   // 'one_to_one' spawn inboxes (sized with nseg)
     void *mig_buf = nullptr, *mig_n = nullptr;   // migration inboxes (rough facets; sized with nseg and segcap)
     double *ep_p = nullptr, *rc_p = nullptr;     // (reservoir, mode) tables in the segments' order (sized with nseg)
-    int rm_nseg = 0;                             // segmentation rc_p was built for (0: the counters live in res_counter)
+    int rm_nseg = 0, rm_nlmax = 0;               // segmentation rc_p was built for (0: the counters live in res_counter)
     void *pin = nullptr;           // pinned host staging of the history rows + the halt words of a batch
     size_t pin_bytes = 0;
     int32_t halt_words[4] = {0, 0, 0, 0};
@@ -356,6 +357,7 @@ void nk_destroy(nk_ctx *ctx) {
     if (ctx->modetab_p) hipFree(ctx->modetab_p);
     if (ctx->m2s_dev) hipFree(ctx->m2s_dev);
     if (ctx->s2m_dev) hipFree(ctx->s2m_dev);
+    if (ctx->nl_dev) hipFree(ctx->nl_dev);
     if (ctx->inbox) hipFree(ctx->inbox);
     if (ctx->inbox_n) hipFree(ctx->inbox_n);
     if (ctx->mig_buf) hipFree(ctx->mig_buf);
@@ -742,7 +744,7 @@ static int nk_entry_tables_drop(nk_ctx *ctx, bool keep_counters) {
     NkDev &d = ctx->d;
     if (ctx->rm_nseg > 0 && keep_counters && d.R > 0 && d.res_counter) {
         const int64_t n = (int64_t)d.R * d.M;
-        k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(0, d.R, d.M, ctx->rm_nseg, (d.M + ctx->rm_nseg - 1) / ctx->rm_nseg,
+        k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(0, d.R, d.M, ctx->rm_nseg, ctx->rm_nlmax,
                                                                    d.m2s, d.res_counter, ctx->rc_p);      // (the map the tables were built with)
         NK_HIP(hipGetLastError());
         NK_HIP(hipStreamSynchronize(ctx->stream));
@@ -769,6 +771,7 @@ static int nk_entry_tables_build(nk_ctx *ctx) {
     NK_HIP(hipGetLastError());
     d.ep_p = ctx->ep_p; d.rc_p = ctx->rc_p;
     ctx->rm_nseg = d.nseg;
+    ctx->rm_nlmax = d.nlmax;
     return NK_OK;
 }
 
@@ -1123,41 +1126,98 @@ static inline int nk_mode_seg(const nk_ctx *ctx, int m, int nseg) {
     return (ctx->map_nseg == nseg && !ctx->h_m2s.empty()) ? ctx->h_m2s[(size_t)m] % nseg : m % nseg;
 }
 
-// Deal the modes over the segments (NkDev::m2s / s2m, nk_device.h): in the order of their boundary-event rate -- per step
-// sum_a |v_a| dt / extent_a of the mesh's bounding box --, round by round, forwards and backwards alternately, so that every
-// segment gets M / nseg modes (+1) and an equal share of fast and slow ones; modes that cannot move (never populated) last.
+// Deal the modes over the segments (NkDev::m2s / s2m / seg_nl, nk_device.h).  A mode's work per step = its particles (every
+// active mode holds the same number) + its boundary events, sum_a |v_a| dt / extent_a of the mesh's bounding box per particle,
+// an event weighing NK_EVENT_WEIGHT (0.45: from the stamps' cycles per tile) of a mean particle-step.  In the order of their
+// event rate every mode goes to the segment that is furthest behind its SHARE of the work (longest-processing-time greedy).
+// The shares follow the dispatch order: the SIMD issues the oldest wave first, so the k-th workgroup a CU received runs ahead
+// of the (k+1)-th; share = 1 + NK_AGE_SKEW (0.20) x (1 - 2 k / (per_cu - 1)) -- speed only: if workgroups were dispatched in
+// another order the sweep would merely be as uneven as with equal shares.  Modes that cannot move (never populated) fill up
+// the shortest segments.  d.nlmax is the capacity of a segment's slot range (set by the caller).
 static int nk_build_mode_map(nk_ctx *ctx) {
     NkDev &d = ctx->d;
     if (ctx->m2s_dev) { hipFree(ctx->m2s_dev); ctx->m2s_dev = nullptr; }
     if (ctx->s2m_dev) { hipFree(ctx->s2m_dev); ctx->s2m_dev = nullptr; }
-    d.m2s = nullptr; d.s2m = nullptr;
+    if (ctx->nl_dev) { hipFree(ctx->nl_dev); ctx->nl_dev = nullptr; }
+    d.m2s = nullptr; d.s2m = nullptr; d.seg_nl = nullptr;
     ctx->h_m2s.clear(); ctx->h_s2m.clear(); ctx->map_nseg = 0;
     if (d.M <= 0 || d.nseg <= 0) return NK_OK;
     const int M = d.M, nseg = d.nseg, nlmax = d.nlmax;
-    std::vector<double> w((size_t)M, 0.0);
     const bool plain = !d.part;          // developer probe without the partition: the modes' emission is dealt m % nseg, forwards
-    if (!plain && ctx->have_mesh && ctx->h_vg.size() == (size_t)M * 3) {
-        double inv[3];
-        for (int a = 0; a < 3; ++a) { const double e = d.bbox[3 + a] - d.bbox[a]; inv[a] = e > 0.0 ? 1.0 / e : 0.0; }
-        for (int m = 0; m < M; ++m)
-            w[(size_t)m] = fabs(ctx->h_vg[3 * (size_t)m]) * inv[0] + fabs(ctx->h_vg[3 * (size_t)m + 1]) * inv[1] + fabs(ctx->h_vg[3 * (size_t)m + 2]) * inv[2];
-    }
-    std::vector<int32_t> order((size_t)M);
-    for (int m = 0; m < M; ++m) order[(size_t)m] = m;
-    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return w[(size_t)a] > w[(size_t)b]; });
+    std::vector<int32_t> nl((size_t)nseg, 0);
     ctx->h_m2s.assign((size_t)M, 0);
     ctx->h_s2m.assign((size_t)nseg * nlmax, -1);
-    for (int k = 0; k < M; ++k) {
-        const int round = k / nseg, pos = k - round * nseg;
-        const int seg = (!plain && (round & 1)) ? nseg - 1 - pos : pos;
-        ctx->h_m2s[(size_t)order[(size_t)k]] = round * nseg + seg;
-        ctx->h_s2m[(size_t)seg * nlmax + round] = order[(size_t)k];
+    auto place = [&](int m, int seg) {
+        const int l = nl[(size_t)seg]++;
+        ctx->h_m2s[(size_t)m] = l * nseg + seg;
+        ctx->h_s2m[(size_t)seg * nlmax + l] = m;
+    };
+    if (plain) {
+        for (int m = 0; m < M; ++m) place(m, m % nseg);
+    } else {
+        std::vector<double> rate((size_t)M, 0.0);
+        std::vector<char> active((size_t)M, 1);
+        const bool have_v = ctx->h_vg.size() == (size_t)M * 3;
+        if (have_v) {
+            double inv[3] = {0, 0, 0};
+            if (ctx->have_mesh) for (int a = 0; a < 3; ++a) { const double e = d.bbox[3 + a] - d.bbox[a]; inv[a] = e > 0.0 ? 1.0 / e : 0.0; }
+            for (int m = 0; m < M; ++m) {
+                const double *v = &ctx->h_vg[3 * (size_t)m];
+                active[(size_t)m] = (v[0] != 0.0 || v[1] != 0.0 || v[2] != 0.0) ? 1 : 0;
+                rate[(size_t)m] = fabs(v[0]) * inv[0] + fabs(v[1]) * inv[1] + fabs(v[2]) * inv[2];
+            }
+        }
+        double rsum = 0.0; int64_t nact = 0;
+        for (int m = 0; m < M; ++m) if (active[(size_t)m]) { rsum += rate[(size_t)m]; ++nact; }
+        const double rmean = nact > 0 && rsum > 0.0 ? rsum / (double)nact : 1.0;
+        const double beta = getenv("NK_EVENT_WEIGHT") ? atof(getenv("NK_EVENT_WEIGHT")) : 0.45;
+        // shares by dispatch age: only when every resident wave of the sweep has exactly one segment
+        std::vector<double> share((size_t)nseg, 1.0);
+        const int g = ctx->g_sweep, per_cu = ctx->num_cu > 0 ? g / ctx->num_cu : 0;
+        const double skew = getenv("NK_AGE_SKEW") ? atof(getenv("NK_AGE_SKEW")) : 0.20;
+        if (per_cu > 1 && g == per_cu * ctx->num_cu && nseg == g * (NK_WG / 64) && skew != 0.0)
+            for (int sg = 0; sg < nseg; ++sg) {
+                const int k = (sg / (NK_WG / 64)) / ctx->num_cu;
+                share[(size_t)sg] = 1.0 + skew * (1.0 - 2.0 * (double)k / (double)(per_cu - 1));
+            }
+        std::vector<int32_t> order((size_t)M);
+        for (int m = 0; m < M; ++m) order[(size_t)m] = m;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+            if (active[(size_t)a] != active[(size_t)b]) return active[(size_t)a] > active[(size_t)b];
+            return rate[(size_t)a] > rate[(size_t)b];
+        });
+        // least relative load first; ties to the lower segment index (deterministic)
+        typedef std::pair<double, int> Key;
+        std::priority_queue<Key, std::vector<Key>, std::greater<Key>> heap;
+        std::vector<double> load((size_t)nseg, 0.0);
+        for (int sg = 0; sg < nseg; ++sg) heap.push(Key(0.0, sg));
+        int k = 0;
+        for (; k < M && active[(size_t)order[(size_t)k]]; ++k) {
+            const int m = order[(size_t)k];
+            int sg = -1;
+            while (!heap.empty()) { const Key top = heap.top(); heap.pop(); if (nl[(size_t)top.second] < nlmax) { sg = top.second; break; } }
+            if (sg < 0) { ctx->err = "nk_build_mode_map: the segments' slot ranges are full (internal sizing error)"; return NK_ERR_ARG; }
+            place(m, sg);
+            load[(size_t)sg] += 1.0 + beta * rate[(size_t)m] / rmean;
+            heap.push(Key(load[(size_t)sg] / share[(size_t)sg], sg));
+        }
+        // the modes that never hold a particle: wherever there is most room
+        std::priority_queue<std::pair<int, int>, std::vector<std::pair<int, int>>, std::greater<std::pair<int, int>>> room;
+        for (int sg = 0; sg < nseg; ++sg) room.push(std::make_pair((int)nl[(size_t)sg], sg));
+        for (; k < M; ++k) {
+            const std::pair<int, int> top = room.top(); room.pop();
+            if (top.first >= nlmax) { ctx->err = "nk_build_mode_map: no room for the inactive modes (internal sizing error)"; return NK_ERR_ARG; }
+            place(order[(size_t)k], top.second);
+            room.push(std::make_pair(top.first + 1, top.second));
+        }
     }
     NK_HIP(hipMalloc((void **)&ctx->m2s_dev, (size_t)M * 4));
     NK_HIP(hipMalloc((void **)&ctx->s2m_dev, (size_t)nseg * nlmax * 4));
+    NK_HIP(hipMalloc((void **)&ctx->nl_dev, (size_t)nseg * 4));
     NK_HIP(hipMemcpy(ctx->m2s_dev, ctx->h_m2s.data(), (size_t)M * 4, hipMemcpyHostToDevice));
     NK_HIP(hipMemcpy(ctx->s2m_dev, ctx->h_s2m.data(), (size_t)nseg * nlmax * 4, hipMemcpyHostToDevice));
-    d.m2s = ctx->m2s_dev; d.s2m = ctx->s2m_dev;
+    NK_HIP(hipMemcpy(ctx->nl_dev, nl.data(), (size_t)nseg * 4, hipMemcpyHostToDevice));
+    d.m2s = ctx->m2s_dev; d.s2m = ctx->s2m_dev; d.seg_nl = ctx->nl_dev;
     ctx->map_nseg = nseg;
     return NK_OK;
 }
@@ -1207,7 +1267,9 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         const bool same = ns == nseg;
         nseg = ns;
         d.nseg = (int32_t)nseg;
+        // slots per segment: the mean share of the modes plus head room for the uneven shares of nk_build_mode_map
         d.nlmax = d.M > 0 ? (int32_t)((d.M + nseg - 1) / nseg) : 1;
+        if (d.part && d.M > nseg) d.nlmax += d.nlmax / 6 + 2;
         // the segments' mode records in LDS where a segment's share fits and the LDS they take costs no resident workgroup
         d.nlrec = 0;
         if (d.part && d.nlmax <= NK_LREC) {
@@ -1626,7 +1688,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
             fprintf(stderr, "[stamps] first entry -> last exit: %.1f us over %zu waves\n", (double)(x1 - e0) * 0.01, pro.size());
             {   // where do the slow waves sit?  mean tile-loop time by workgroup index mod 8 (the XCD under round-robin placement),
                 // by wave within the workgroup, and by thirds of the grid
-                double xs[8] = {0}, xn[8] = {0}, ws[4] = {0}, wn[4] = {0}, gs[4] = {0}, gn[4] = {0};
+                double xs[8] = {0}, xn[8] = {0}, ws[4] = {0}, wn[4] = {0}, gs[4] = {0}, gn[4] = {0}, rs[8] = {0}, rn[8] = {0};
                 for (int sgm = 0; sgm < d.nseg; ++sgm) {
                     const unsigned long long *w = &st[((size_t)d.nseg + sgm) * 8];
                     if (!w[0] || !w[3]) continue;
@@ -1634,6 +1696,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
                     const int wg = sgm / 4;
                     xs[wg % 8] += t; xn[wg % 8] += 1; ws[sgm % 4] += t; wn[sgm % 4] += 1;
                     const int third = (int)((int64_t)sgm * 4 / d.nseg); gs[third] += t; gn[third] += 1;
+                    const int rk = wg / ctx->num_cu; if (rk < 8) { rs[rk] += t; rn[rk] += 1; }
                 }
                 fprintf(stderr, "[stamps] tile loop mean [us] by workgroup %% 8:");
                 for (int k = 0; k < 8; ++k) fprintf(stderr, " %.1f", xn[k] ? xs[k] / xn[k] : 0.0);
@@ -1641,6 +1704,8 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
                 for (int k = 0; k < 4; ++k) fprintf(stderr, " %.1f", wn[k] ? ws[k] / wn[k] : 0.0);
                 fprintf(stderr, " | by quarter of the grid:");
                 for (int k = 0; k < 4; ++k) fprintf(stderr, " %.1f", gn[k] ? gs[k] / gn[k] : 0.0);
+                fprintf(stderr, " | by workgroup / CUs (the k-th workgroup of a CU under in-order dispatch):");
+                for (int k = 0; k < 8; ++k) if (rn[k]) fprintf(stderr, " %.1f", rs[k] / rn[k]);
                 fprintf(stderr, "\n");
             }
             q(pro, "entry -> tile loop (tables into LDS, records)"); q(loop, "tile loop"); q(epi, "tile loop end -> wave through (flush, workgroup barrier, tally row)");

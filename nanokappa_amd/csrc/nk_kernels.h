@@ -274,10 +274,7 @@ __device__ __forceinline__ NkSegModes nk_seg_modes(const NkDev &d, int seg) {
     NkSegModes sm;
     sm.rec = d.part ? d.modetab_p + (int64_t)seg * d.nlmax : d.modetab;
     sm.gm = d.part ? d.s2m + (int64_t)seg * d.nlmax : nullptr;
-    // the slots are dealt round by round, forwards in the even rounds and backwards in the odd ones (nk_build_mode_map):
-    // every segment has M / nseg modes, the last, partial round gives one more to its first (even) or last (odd) M % nseg
-    const int full = d.M / d.nseg, rem = d.M - full * d.nseg;
-    sm.nl = d.part ? full + ((rem > 0 && ((full & 1) ? seg >= d.nseg - rem : seg < rem)) ? 1 : 0) : full + (seg < rem ? 1 : 0);
+    sm.nl = d.seg_nl[seg];
     sm.estride = d.nseg; sm.eoff = seg;
     return sm;
 }
