@@ -435,6 +435,9 @@ def main():
             'repeats': a.repeats, 'ms_per_step_min': min(ms), 'ms_per_step_max': max(ms),
             'ms_per_step_repeats': ms, 'sweep_ms_repeats': [r['tm']['step_kernel_ms'] for r in runs],
             'housekeeping_repeats': [r['hk'] for r in runs],
+            # the same regions on the GPU's own clock (HIP events around the enqueued steps): a repeat that is long on the wall
+            # but not here lost its time on the host (launch thread descheduled), not in a kernel
+            'stream_ms_per_step_repeats': [r['tm']['total_ms'] / a.steps for r in runs],
             'timing': 'median of %d timed regions of %d steps each (barrier + drained stream on both sides, max over ranks); %d warm-up '
                       'steps and one untimed region of %d steps before them' % (a.repeats, a.steps, a.warmup, a.steps),
             'config': {'workload': '%s-like synthetic %d^3x6 modes, %s, dt 1 ps, %.3g particles per GPU (BASELINE config %s)'

@@ -32,5 +32,13 @@ cd $R
 CAL=$(grep -h "calibration:" $O/fe.log | tail -1 | sed 's/.*reads \([0-9]*\) B and writes \([0-9]*\) B.*/\1 \2/')
 python3 scripts/pmc_summary.py $O/sq $O/fe $O/wr $CAL > $O/pmc.json && python3 -c "
 import json; j=json.load(open('$O/pmc.json')); k=j['k_sweep']; print('k_sweep read %.3f GB write %.3f GB' % (k['read_bytes']/1e9, k['write_bytes']/1e9)); print(j['calibration'])"
+python3 - $O/pmc.json $TAG > $O/pmc_traffic.json <<'PY'
+import json, sys
+j = json.load(open(sys.argv[1])); k = j['k_sweep']; c = j['calibration']
+print(json.dumps({'k_sweep_hbm_bytes_per_launch': k['read_bytes'] + k['write_bytes'], 'read_bytes': k['read_bytes'], 'write_bytes': k['write_bytes'],
+                  'source': 'profiles/%s_c2_1e7_pmc.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over bench.py --steps 10 --warmup 5 (BASELINE config 2), '
+                            'scaled by the k_cal_stream calibration (read factor %.4f, write factor %.4f); a constant of that profile run, not a measurement of this bench run'
+                            % (sys.argv[2], c['read_factor'], c['write_factor']), 'calibration': c}, indent=1))
+PY
 cp $O/kt/kt_kernel_stats.csv $O/kernel_stats.csv
 python3 bench.py > $O/bench.json 2> $O/bench.err; tail -c 1200 $O/bench.json
