@@ -452,6 +452,9 @@ def main():
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_source,
                          'kernel': 'k_sweep', 'kernel_ms': k_ms, 'emit_count_kernel_ms': tm['emit_kernel_ms'],
                          'reduce_update_ms': tm['events_kernel_ms'], 'stream_ms_per_step': tm['total_ms'] / a.steps,
+                         # True: the next step's emission runs inside the tail launch (k_tail), beside the reduce / update --
+                         # reduce_update_ms then includes it and emit_count_kernel_ms covers only a call's first step
+                         'emission_in_tail_launch': bool(tm.get('emit_fused', 0)),
                          'frac_whole_step': BYTES_PER_PHONON_STEP * value / 1e9 / HBM_PEAK_GBS / max(world, 1),
                          'algorithmic_bytes_per_launch': BYTES_PER_PHONON_STEP * live_rank},
         }

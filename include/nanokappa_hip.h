@@ -162,6 +162,8 @@ typedef struct {
     int64_t halts;           /* batches that ended early on a halt request (every rank at the same step) */
     int64_t tau_rebuilds;    /* rebuilds of the packed mode records (lifetime window / E0 reference moved, or new segmentation) */
     int64_t batches;         /* nk_step_batch calls = stream drains + history copies */
+    int64_t emit_fused;      /* 1: the next step's emission ran inside the tail launch (k_tail) in the last call: emit_kernel_ms then
+                              *    covers only a batch's first step, events_kernel_ms the reduce / update WITH the emission beside it */
 } nk_timing;
 
 /* lifetime: `Population.__init__` / end of run */

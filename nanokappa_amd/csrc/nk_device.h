@@ -145,7 +145,9 @@ struct NkDev {
     const double *enter_prob;         // [R*M]
     double *res_counter;              // [R*M] as uploaded; the live counters are rc_p (nk_engine.hip keeps the two in step)
     const double *ep_p;               // [nseg * R * nlmax] enter_prob in the segments' order: entry (r, l) of segment s at
-    double *rc_p;                     //   (s * R + r) * nlmax + l -- k_emit reads its entries coalesced; rc_p: the counters
+    double *rc_p;                     //   (s * R + r) * nlmax + l -- k_emit reads its entries coalesced; rc_p: the counters,
+    int64_t rc_len;                   //   TWO copies of rc_len entries: step k reads copy k & 1 and writes copy (k + 1) & 1, so the
+                                      //   emission that k_tail runs ahead of a halt can simply be run again (nk_step_batch)
     const double *res_roulette;       // [R*M] 'one_to_one': cumulative enter_prob per reservoir, last = 1 (Population.py:467-468)
     int32_t *nleave_prev;             // [R] 'one_to_one': particles that left at the previous step, all ranks (Population.py:466)
     uint64_t *sp_inbox;               // 'one_to_one': [nseg * sp_icap] spawn records (i << 40 | rm << 12) routed to the owner

@@ -745,7 +745,7 @@ static int nk_entry_tables_drop(nk_ctx *ctx, bool keep_counters) {
     if (ctx->rm_nseg > 0 && keep_counters && d.R > 0 && d.res_counter) {
         const int64_t n = (int64_t)d.R * d.M;
         k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(0, d.R, d.M, ctx->rm_nseg, ctx->rm_nlmax,
-                                                                   d.m2s, d.res_counter, ctx->rc_p);      // (the map the tables were built with)
+                                                                   d.m2s, d.res_counter, ctx->rc_p + (ctx->step & 1) * d.rc_len);      // (the map the tables were built with; the copy the next step reads)
         NK_HIP(hipGetLastError());
         NK_HIP(hipStreamSynchronize(ctx->stream));
     }
@@ -762,12 +762,13 @@ static int nk_entry_tables_build(nk_ctx *ctx) {
     if (rc) return rc;
     const size_t len = (size_t)d.nseg * d.R * d.nlmax;
     NK_HIP(hipMalloc((void **)&ctx->ep_p, len * 8));
-    NK_HIP(hipMalloc((void **)&ctx->rc_p, len * 8));
+    NK_HIP(hipMalloc((void **)&ctx->rc_p, 2 * len * 8));
     NK_HIP(hipMemsetAsync(ctx->ep_p, 0, len * 8, ctx->stream));
-    NK_HIP(hipMemsetAsync(ctx->rc_p, 0, len * 8, ctx->stream));
+    NK_HIP(hipMemsetAsync(ctx->rc_p, 0, 2 * len * 8, ctx->stream));
+    d.rc_len = (int64_t)len;
     const int64_t n = (int64_t)d.R * d.M;
     k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, d.m2s, (double *)d.enter_prob, ctx->ep_p);
-    k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, d.m2s, d.res_counter, ctx->rc_p);
+    k_perm_rm<<<(int)((n + 255) / 256), 256, 0, ctx->stream>>>(1, d.R, d.M, d.nseg, d.nlmax, d.m2s, d.res_counter, ctx->rc_p + (ctx->step & 1) * d.rc_len);
     NK_HIP(hipGetLastError());
     d.ep_p = ctx->ep_p; d.rc_p = ctx->rc_p;
     ctx->rm_nseg = d.nseg;
@@ -1571,9 +1572,13 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     NK_HIP(hipEventRecord(t0, ctx->stream));
     bool pending = ctx->pending_relax;
     std::vector<char> relax_flushed((size_t)nsteps, 0);       // steps whose deferred relaxation k_relax ran before them
-    // (Tried: the NEXT step's emission on a second stream beside k_reduce / k_update, its counters double-buffered so that an
-    // emission that ran ahead of a halt could be run again.  The two cross-stream event waits per step cost more than the 12 us
-    // they hid: 0.289 against 0.270 ms per step on config 2, profiles/r03_notes.txt.)
+    // The next step's emission rides in the same launch as this step's reduce / update (k_tail) wherever it depends on neither
+    // (no rough facets, not 'one_to_one').  (On a second stream instead, the two cross-stream event waits per step cost more
+    // than the 12 us they hid: 0.289 against 0.270 ms per step on config 2, profiles/r03_notes.txt (11).)
+    const bool tail_emit = R > 0 && d.res_gen != 2 && !d.mig_buf && !getenv("NK_NO_TAIL_EMIT");
+    const size_t lds_t = lds_e > (size_t)(NK_WG * 8 + 16) ? lds_e : (size_t)(NK_WG * 8 + 16);
+    bool emitted_ahead = false;                           // this step's emission already ran in the previous step's k_tail
+    ctx->timing.emit_fused = tail_emit ? 1 : 0;
     for (int s = 0; s < nsteps; ++s) {
         const int64_t stepno = ctx->step + s;
         const uint32_t step = (uint32_t)stepno;
@@ -1589,7 +1594,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         const int do_flux = (fe > 0 && ((stepno + 1) % fe) == 0) ? 1 : 0;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
         if (R > 0 && d.res_gen == 2) k_emit_one_to_one<<<ctx->num_cu * 4, NK_WG, 0, ctx->stream>>>(d, step);
-        if (R > 0) NK_GEOM_LAUNCH(k_emit, g_emit, lds_e, d, step);
+        if (R > 0 && !emitted_ahead) NK_GEOM_LAUNCH(k_emit, g_emit, lds_e, d, step);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
         {
             const int rl = pending ? 1 : 0;
@@ -1602,14 +1607,21 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
         double *hrow = ctx->hist + (size_t)s * HROW;
+        const bool ahead = tail_emit && s + 1 < nsteps;        // the next step's emission beside this step's tail
         if (ctx->comm) {
-            k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 0);
+            if (ahead) { if (gm_ == 1) k_tail<1><<<NB + g_emit, NK_WG, lds_t, ctx->stream>>>(d, step + 1u, rows, ctx->acc, hrow, do_flux, 0, NB);
+                         else k_tail<2><<<NB + g_emit, NK_WG, lds_t, ctx->stream>>>(d, step + 1u, rows, ctx->acc, hrow, do_flux, 0, NB); }
+            else k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 0);
             ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB + 2, ncclDouble, ncclSum, ctx->comm, ctx->stream);
             if (nrc != ncclSuccess) { ctx->err = "ncclAllReduce failed"; return NK_ERR_COMM; }
             k_update<<<1, NK_WG, 0, ctx->stream>>>(d, ctx->acc, hrow, do_flux);
+        } else if (ahead) {
+            if (gm_ == 1) k_tail<1><<<NB + g_emit, NK_WG, lds_t, ctx->stream>>>(d, step + 1u, rows, ctx->acc, hrow, do_flux, 1, NB);
+            else k_tail<2><<<NB + g_emit, NK_WG, lds_t, ctx->stream>>>(d, step + 1u, rows, ctx->acc, hrow, do_flux, 1, NB);
         } else {
             k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 1);
         }
+        emitted_ahead = ahead;
         if (d.mig_buf) k_deliver<<<g_emit, NK_WG, 0, ctx->stream>>>(d);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
         pending = true;

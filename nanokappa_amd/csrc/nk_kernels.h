@@ -322,10 +322,10 @@ __device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int
     const double fixed = floor(prob);
     int mask;
     if (d.res_gen == 0) {
-        cv = d.rc_p[at] + (prob - fixed);
+        cv = d.rc_p[(int64_t)(step & 1u) * d.rc_len + at] + (prob - fixed);
         mask = cv >= 1.0;
         cv -= (double)mask;
-        d.rc_p[at] = cv;
+        d.rc_p[(int64_t)((step + 1u) & 1u) * d.rc_len + at] = cv;
     } else {
         double d1;
         nk_uniform2_dev(d.seed, (uint64_t)rm | 0xFFFFFFFF00000000ull, step, NK_TAG_DICE, cv, d1);
@@ -373,8 +373,7 @@ __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t ste
 // :440-443; add_reservoir_particles :525-552) and appends them BEHIND the segment's live particles, marked newborn; the
 // sweep of the same step takes them in (tally, boundary events) without relaxing or drifting them.
 template <int GEOM>
-__global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsigned char *smem, int bid, int nblocks) {
 #ifdef NK_STAMPS
     const unsigned long long em_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -389,8 +388,8 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
     unsigned int *sp_pref = L.sp_pref + wave * NK_EMIT_CHUNK, *sp_cnt = L.sp_cnt + wave * NK_EMIT_CHUNK,
                  *sp_rm = L.sp_rm + wave * NK_EMIT_CHUNK;
     double *sp_cv = L.sp_cv + wave * NK_EMIT_CHUNK, *sp_pr = L.sp_pr + wave * NK_EMIT_CHUNK;
-    const int nwaves = gridDim.x * (NK_WG / 64);
-    for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
+    const int nwaves = nblocks * (NK_WG / 64);
+    for (int seg = bid * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
         const NkSegModes sm = nk_seg_modes(d, seg);
@@ -525,6 +524,12 @@ __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
 #endif
         }
     }
+}
+
+template <int GEOM>
+__global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    nk_emit_body<GEOM>(d, step, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Output ring of a sweep wave: finished particles are staged in LDS and leave for HBM in whole, aligned tiles of 64 --
@@ -1291,11 +1296,10 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
 // fuse != 0 (single rank): the workgroup that finishes last also runs the update, saving a launch.
 // Column NB is the halt request of this step's sweep (halt[1]); halt[0] is only raised by the update at the END of a step,
 // so every kernel of a step sees the same value.
-__global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc, double *hist_row, int do_flux, int fuse) {
-    __shared__ double sh[NK_WG];
-    __shared__ int last;
+__device__ __forceinline__ void nk_reduce_body(const NkDev &d, int rows, double *acc, double *hist_row, int do_flux, int fuse, int b,
+                                               int nblocks, double *sh, int &last) {
     if (d.halt[0]) return;
-    const int b = blockIdx.x, NB = d.NB;
+    const int NB = d.NB;
     double v = 0.0;
     for (int r = threadIdx.x; r < rows; r += NK_WG) v += d.partials[(int64_t)r * NB + b];
     sh[threadIdx.x] = v;
@@ -1317,13 +1321,37 @@ __global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc
     if (!fuse) return;
     if (threadIdx.x == 0) {
         __threadfence();
-        last = (atomicAdd(d.ticket, 1) == (int)gridDim.x - 1);
+        last = (atomicAdd(d.ticket, 1) == nblocks - 1);
     }
     __syncthreads();
     if (!last) return;
     if (threadIdx.x == 0) *d.ticket = 0;
     __threadfence();
     nk_update_body(d, acc, hist_row, do_flux);
+}
+__global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc, double *hist_row, int do_flux, int fuse) {
+    __shared__ double sh[NK_WG];
+    __shared__ int last;
+    nk_reduce_body(d, rows, acc, hist_row, do_flux, fuse, (int)blockIdx.x, (int)gridDim.x, sh, last);
+}
+// The step's tail and the NEXT step's reservoir emission in ONE launch: the first n_reduce workgroups are k_reduce (+ the fused
+// update), the others k_emit for step_next.  The emission needs nothing of this step's tally -- only the segments' ends, which
+// the sweep has left -- and the reduce / update are latency chains of a hundred workgroups that leave the chip idle: side by
+// side they cost the longer of the two (and one launch less).  The update may raise the halt word while the emission of the
+// step that will then NOT run is under way: harmless, its counters are double-buffered (NkDev::rc_len) and it is simply run
+// again once the store has grown.  Not with rough facets (k_deliver, after the update, moves the segments' ends) nor
+// 'one_to_one' (emits what the update says left).
+template <int GEOM>
+__global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int rows, double *acc, double *hist_row, int do_flux, int fuse,
+                                                int n_reduce) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if ((int)blockIdx.x < n_reduce) {
+        double *sh = reinterpret_cast<double *>(smem);
+        int &last = *reinterpret_cast<int *>(smem + NK_WG * sizeof(double));
+        nk_reduce_body(d, rows, acc, hist_row, do_flux, fuse, (int)blockIdx.x, n_reduce, sh, last);
+    } else {
+        nk_emit_body<GEOM>(d, step_next, smem, (int)blockIdx.x - n_reduce, (int)gridDim.x - n_reduce);
+    }
 }
 
 // The update as its own launch (after the RCCL all-reduce when nranks > 1).
