@@ -3,17 +3,19 @@
 // Stream order of one timestep (reference Population.run_timestep, Population.py:1724-1769):
 //   [k_relax + k_contains every `contains_every` steps]            contains_check       :1712-1722
 //   [k_emit_one_to_one: only for the 'one_to_one' generator]        fill_reservoirs      :457-489
-//   k_sweep       per segment (one wave): relax(previous step) -> drift -> boundary events -> tally -> compaction,
-//                 then the reservoir particles of the segment's own modes
+//   k_emit        per segment (one wave): the reservoir particles of the segment's own modes, appended behind its live ones
+//                                                                   fill_reservoirs      :356-455
+//                                                                   add_reservoir_particles :525-552
+//   k_sweep       per segment (one wave): relax(previous step) -> drift -> boundary events -> tally -> compaction
 //                                                                   lifetime_scattering  :1701-1710 (deferred)
 //                                                                   drift                :790-795
 //                                                                   boundary_scattering  :1546-1683
-//                                                                   fill_reservoirs      :356-455
-//                                                                   add_reservoir_particles :525-552
 //                                                                   calculate_energy     :704-717
 //   k_reduce      deterministic column sums of the per-workgroup tally rows; single rank: the last workgroup also
 //                 normalises, inverts E -> T and writes the history row    calculate_energy :719-728, refresh_temperatures :692
 //   (nranks > 1: RCCL all-reduce of the tally vector, then k_update does that part)
+//   (k_tail = k_reduce and the NEXT step's k_emit in one launch, wherever the emission depends on neither the update nor
+//    k_deliver: no rough facets, not 'one_to_one')
 //
 // Deferred relaxation: the reference relaxes occupations at the END of step k with the temperatures of step k.  Those
 // need the global tally of step k, so the relaxation is carried into the BEGINNING of the sweep of step k+1 (same
