@@ -457,6 +457,10 @@ def main():
                          'emission_in_tail_launch': bool(tm.get('emit_fused', 0)),
                          'frac_whole_step': BYTES_PER_PHONON_STEP * value / 1e9 / HBM_PEAK_GBS / max(world, 1),
                          'algorithmic_bytes_per_launch': BYTES_PER_PHONON_STEP * live_rank},
+            # where the particle store lies in memory decides between two speeds of the sweep (profiles/r03_notes.txt (9), (17)):
+            # the library times an in-place copy over candidate allocations and keeps the fastest
+            'store_placement': {'allocations_timed': tm.get('place_tries', 0), 'kept_copy_GBps': tm.get('place_gbps', 0.0),
+                                'slowest_copy_GBps': tm.get('place_worst_gbps', 0.0)},
         }
         if world > 1 and not os.environ.get('NK_COMM_DRYRUN') and (ranks[0]['comm_nranks'] != world or not out['rccl']['all_ranks_agree']):
             raise SystemExit('bench.py: RCCL reports %d ranks, the launcher %d' % (ranks[0]['comm_nranks'], world))

@@ -164,6 +164,10 @@ typedef struct {
     int64_t batches;         /* nk_step_batch calls = stream drains + history copies */
     int64_t emit_fused;      /* 1: the next step's emission ran inside the tail launch (k_tail) in the last call: emit_kernel_ms then
                               *    covers only a batch's first step, events_kernel_ms the reduce / update WITH the emission beside it */
+    int64_t place_tries;     /* allocations of the particle store that were timed when it was last (re)allocated (0: small store, not
+                              * timed): where a store lies in memory decides between two speeds of the sweep, 15 % apart */
+    double place_gbps;       /* GB/s of an in-place copy pass over the store that was kept ... */
+    double place_worst_gbps; /* ... and over the slowest candidate */
 } nk_timing;
 
 /* lifetime: `Population.__init__` / end of run */

@@ -11,6 +11,7 @@
 #include <queue>
 #include <string>
 #include <type_traits>
+#include <chrono>
 #include <vector>
 
 #include <rccl/rccl.h>
@@ -37,6 +38,9 @@ struct nk_ctx {
     NkDev d;                       // device view (pointers into `allocs` / `pallocs`)
     std::vector<void *> allocs;    // everything hipMalloc'ed except the particle arrays
     std::vector<void *> pallocs;   // particle arrays (re-allocated by nk_reserve)
+    void *store_buf = nullptr;     // the one among them that holds the particle fields (nk_alloc_fields)
+    size_t store_pad = 0;
+    bool store_pid = false;
     bool have_material = false, have_mesh = false, have_sv = false, have_params = false;
     int64_t step = 0;
     bool pending_relax = false;
@@ -130,19 +134,18 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 // The particle fields of a store of `cap` slots (a multiple of 64): ONE allocation cut into blocks of 64 slots, every block
 // x | y | z | occ | nts | [pid] | w0 (NkField, nk_device.h).  NK_LAYOUT=soa (developer comparison): one plain array per
 // field, as in round 2.  The allocation is registered in ctx->pallocs.
-static int nk_alloc_fields(nk_ctx *ctx, NkDev &d, int64_t cap, bool with_pid) {
-    const bool soa = getenv("NK_LAYOUT") && !strcmp(getenv("NK_LAYOUT"), "soa");
+static inline bool nk_layout_soa() { return getenv("NK_LAYOUT") && !strcmp(getenv("NK_LAYOUT"), "soa"); }
+static inline size_t nk_store_bytes(int64_t cap, bool with_pid) {
     const int64_t nblk = (cap + 63) / 64;
     const int bd = with_pid ? 6 * 64 + 32 : 5 * 64 + 32;          // doubles per block (the 64 packed words take 32)
-    const size_t bytes = soa ? (size_t)nblk * 64 * (with_pid ? 52 : 44) : (size_t)nblk * bd * 8;
-    void *buf = nullptr;
-    // developer probe (scripts/placement_probe.py): NK_STORE_PAD_KB shifts the store inside a larger allocation
-    const size_t pad = getenv("NK_STORE_PAD_KB") ? (size_t)atol(getenv("NK_STORE_PAD_KB")) * 1024 : 0;
-    NK_HIP(hipMalloc(&buf, (bytes ? bytes : 64) + pad));
-    ctx->pallocs.push_back(buf);
-    NK_HIP(hipMemsetAsync(buf, 0, (bytes ? bytes : 64) + pad, ctx->stream));
-    double *b = (double *)((char *)buf + pad);
-    if (soa) {
+    const size_t bytes = nk_layout_soa() ? (size_t)nblk * 64 * (with_pid ? 52 : 44) : (size_t)nblk * bd * 8;
+    return bytes ? bytes : 64;
+}
+// the fields of a store of `cap` slots that starts at b
+static void nk_point_fields(NkDev &d, double *b, int64_t cap, bool with_pid) {
+    const int64_t nblk = (cap + 63) / 64;
+    const int bd = with_pid ? 6 * 64 + 32 : 5 * 64 + 32;
+    if (nk_layout_soa()) {
         const int64_t n = nblk * 64;
         d.x = {b, 64}; d.y = {b + n, 64}; d.z = {b + 2 * n, 64}; d.occ = {b + 3 * n, 64}; d.nts = {b + 4 * n, 64};
         d.pid = {with_pid ? (uint64_t *)(b + 5 * n) : nullptr, 64};
@@ -152,6 +155,17 @@ static int nk_alloc_fields(nk_ctx *ctx, NkDev &d, int64_t cap, bool with_pid) {
         d.pid = {with_pid ? (uint64_t *)(b + 320) : nullptr, bd};
         d.w0 = {(uint32_t *)(b + (with_pid ? 384 : 320)), 2 * bd};
     }
+}
+static int nk_alloc_fields(nk_ctx *ctx, NkDev &d, int64_t cap, bool with_pid) {
+    const size_t bytes = nk_store_bytes(cap, with_pid);
+    void *buf = nullptr;
+    // developer probe (scripts/placement_probe.py): NK_STORE_PAD_KB shifts the store inside a larger allocation
+    const size_t pad = getenv("NK_STORE_PAD_KB") ? (size_t)atol(getenv("NK_STORE_PAD_KB")) * 1024 : 0;
+    NK_HIP(hipMalloc(&buf, bytes + pad));
+    ctx->pallocs.push_back(buf);
+    NK_HIP(hipMemsetAsync(buf, 0, bytes + pad, ctx->stream));
+    ctx->store_buf = buf; ctx->store_pad = pad; ctx->store_pid = with_pid;
+    nk_point_fields(d, (double *)((char *)buf + pad), cap, with_pid);
     return NK_OK;
 }
 // Host copy of a whole field (slot order) and back.
@@ -1236,6 +1250,85 @@ static int64_t nk_spawn_bound(const nk_ctx *ctx, int nseg) {
     return (mx + d.nranks - 1) / d.nranks + d.R;
 }
 
+// Where the store's allocation lies in memory decides between two speeds of everything that streams it -- the sweep and a
+// plain copy alike, 15 % apart (profiles/r03_notes.txt (9), (17)); which one an allocation gets depends on what was
+// allocated and freed before it (a process's first large allocation is usually fast, the one made while that one still
+// exists slow, ...).  So the store that is about to be used is timed with k_probe_place, then up to NK_PLACE_TRIES - 1 (default
+// 23) further allocations of the same size are, all held at once so that they cannot be the same memory; as soon as two of
+// them differ by more than 6 % both speeds have been seen and the search ends.  The fastest one becomes the store (its
+// contents are copied over: the layout is the same), the others are freed.  Small stores (< 64 MB) are left alone.
+static int nk_place_store(nk_ctx *ctx) {
+    NkDev &d = ctx->d;
+    ctx->timing.place_tries = 0; ctx->timing.place_gbps = 0.0; ctx->timing.place_worst_gbps = 0.0;
+    const int tries = getenv("NK_PLACE_TRIES") ? atoi(getenv("NK_PLACE_TRIES")) : 24;
+    const size_t bytes = nk_store_bytes(d.cap, ctx->store_pid);
+    // test hooks: NK_PLACE_MIN_MB (stores below it are not timed; default 64), NK_PLACE_FORCE=1 (always move into the last candidate)
+    const size_t min_mb = getenv("NK_PLACE_MIN_MB") ? (size_t)atol(getenv("NK_PLACE_MIN_MB")) : 64;
+    const bool force = getenv("NK_PLACE_FORCE") != nullptr;
+    if (tries < 1 || !ctx->store_buf || ctx->store_pad != 0 || bytes < (min_mb << 20) || d.nseg <= 0 || d.segcap < 64) return NK_OK;
+    size_t free_b = 0, total_b = 0;
+    NK_HIP(hipMemGetInfo(&free_b, &total_b));
+    const auto wall0 = std::chrono::steady_clock::now();
+    const int g = std::max(1, std::min(nk_sweep_blocks(ctx), (d.nseg + NK_WG / 64 - 1) / (NK_WG / 64)));
+    const int tiles = d.segcap / 64;
+    hipEvent_t e0, e1;
+    NK_HIP(hipEventCreate(&e0)); NK_HIP(hipEventCreate(&e1));
+    auto probe = [&](void *buf, double &ms) -> int {
+        NkDev t = d;
+        nk_point_fields(t, (double *)buf, d.cap, ctx->store_pid);
+        k_probe_place<<<g, NK_WG, 0, ctx->stream>>>(t, tiles);           // untimed: page tables, caches
+        NK_HIP(hipEventRecord(e0, ctx->stream));
+        for (int k = 0; k < 3; ++k) k_probe_place<<<g, NK_WG, 0, ctx->stream>>>(t, tiles);
+        NK_HIP(hipEventRecord(e1, ctx->stream));
+        NK_HIP(hipGetLastError());
+        NK_HIP(hipStreamSynchronize(ctx->stream));
+        float f = 0.f;
+        NK_HIP(hipEventElapsedTime(&f, e0, e1));
+        ms = (double)f / 3.0;
+        return NK_OK;
+    };
+    std::vector<void *> cand(1, ctx->store_buf);
+    std::vector<double> ms(1, 0.0);
+    int rc = probe(cand[0], ms[0]);
+    while (!rc && (int)cand.size() < tries) {
+        double lo = ms[0], hi = ms[0];
+        for (double v : ms) { lo = std::min(lo, v); hi = std::max(hi, v); }
+        if (hi > 1.06 * lo && !force) break;                             // both speeds seen
+        if (bytes * cand.size() > free_b / 4) break;                     // the extra ones: never more than a quarter of what is free
+        void *buf = nullptr;
+        if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
+        cand.push_back(buf); ms.push_back(0.0);
+        if (hipMemsetAsync(buf, 0, bytes, ctx->stream) != hipSuccess) { rc = NK_ERR_HIP; ctx->err = "nk_place_store: hipMemsetAsync failed"; break; }
+        rc = probe(buf, ms.back());
+    }
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    size_t best = 0, worst = 0;
+    for (size_t k = 1; k < cand.size(); ++k) { if (ms[k] < ms[best]) best = k; if (ms[k] > ms[worst]) worst = k; }
+    if (force) best = cand.size() - 1;
+    if (!rc && best != 0 && (ms[best] < 0.97 * ms[0] || force)) {        // move in
+        if (hipMemcpyAsync(cand[best], cand[0], bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipStreamSynchronize(ctx->stream) != hipSuccess) { rc = NK_ERR_HIP; ctx->err = "nk_place_store: copy into the chosen store failed"; }
+        else {
+            for (void *&p : ctx->pallocs) if (p == cand[0]) p = cand[best];
+            ctx->store_buf = cand[best];
+            nk_point_fields(d, (double *)cand[best], d.cap, ctx->store_pid);
+            std::swap(cand[0], cand[best]);                              // cand[0] stays, the rest goes
+        }
+    } else best = 0;
+    for (size_t k = 1; k < cand.size(); ++k) hipFree(cand[k]);
+    const double gb = 2.0 * (double)d.nseg * tiles * 64 * 44 / 1e9;      // read + written by one probe launch
+    ctx->timing.place_tries = (int64_t)cand.size();
+    ctx->timing.place_gbps = ms[best] > 0.0 ? gb / (ms[best] * 1e-3) : 0.0;
+    ctx->timing.place_worst_gbps = ms[worst] > 0.0 ? gb / (ms[worst] * 1e-3) : 0.0;
+    if (getenv("NK_VERBOSE")) {
+        fprintf(stderr, "[nanokappa_hip] store placement: %zu allocation(s) of %.0f MB probed:", cand.size(), (double)bytes / 1048576.0);
+        for (size_t k = 0; k < ms.size(); ++k) fprintf(stderr, " %.1f", ms[k] * 1e3);
+        fprintf(stderr, " us per pass; kept number %zu (%.2f TB/s); %.1f ms\n", best, ctx->timing.place_gbps / 1e3,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+    }
+    return rc;
+}
+
 // (Re)allocate the particle store for `capacity` particles, `max_seg` of them at most in one segment when the modes are
 // partitioned (0 = unknown: even spread assumed).
 // particles of the tiled rule (particle p has mode umodes[p % nu]) per unique mode, for p in [pid_lo, pid_lo + N)
@@ -1334,6 +1427,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     if (ctx->mig_buf) { hipFree(ctx->mig_buf); ctx->mig_buf = nullptr; }
     if (ctx->mig_n) { hipFree(ctx->mig_n); ctx->mig_n = nullptr; }
     d.mig_buf = nullptr; d.mig_n = nullptr; d.mig_cap = 0;
+    { int rcp = nk_place_store(ctx); if (rcp) return rcp; }
     return nk_entry_tables_build(ctx);
 }
 
@@ -1373,6 +1467,7 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     const NkDev old = d;
     std::vector<void *> old_allocs;
     old_allocs.swap(ctx->pallocs);
+    void *const old_store = ctx->store_buf; const size_t old_pad = ctx->store_pad;
     segcap_new = ((segcap_new + 63) / 64) * 64;
     NK_ARG((int64_t)old.nseg * segcap_new < (1ll << 31), "particle store too large for 32-bit slot arithmetic");
     d.segcap = (int32_t)segcap_new;
@@ -1396,6 +1491,7 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     if (rc) {                                            // out of memory: keep the old store
         for (void *p : ctx->pallocs) hipFree(p);
         ctx->pallocs.swap(old_allocs);
+        ctx->store_buf = old_store; ctx->store_pad = old_pad;
         d = old;
         return rc;
     }
@@ -1405,7 +1501,7 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     NK_HIP(hipStreamSynchronize(ctx->stream));
     for (void *p : old_allocs) hipFree(p);
     ctx->timing.slots = d.cap;
-    return NK_OK;
+    return nk_place_store(ctx);       // (the old store's memory is free again: often the better place)
 }
 
 int nk_reserve(nk_ctx *ctx, int64_t capacity) {

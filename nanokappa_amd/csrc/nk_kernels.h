@@ -1688,6 +1688,28 @@ __global__ __launch_bounds__(NK_WG, 3) void k_probe_copy(NkDev d) {
         }
     }
 }
+// Placement probe of the particle store (nk_place_store, nk_engine.hip): the same wave-per-segment tile loop over the first
+// `tiles` tiles of EVERY segment, every value written back exactly as it was read -- harmless on a live store, and its time
+// tells the two speeds apart that one and the same store shows depending on where its allocation lies in memory
+// (profiles/r03_notes.txt (9), (17)).
+__global__ __launch_bounds__(NK_WG, 3) void k_probe_place(NkDev d, int tiles) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = gridDim.x * (NK_WG / 64);
+    for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int64_t step = 64;
+        const int count = tiles;
+        double xN = 0, yN = 0, zN = 0, oN = 0, nN = 0; uint32_t wN = 0;
+        if (count > 0) { const int64_t i0 = base; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
+        for (int r = 0; r < count; ++r) {
+            double x = xN, y = yN, z = zN, o = oN, n = nN; uint32_t w = wN;
+            if (r + 1 < count) { const int64_t i0 = base + (r + 1) * step; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
+            asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(o), "+v"(n), "+v"(w));     // (a store of the value just loaded would be dropped)
+            const int64_t i0 = base + r * step;
+            *d.x.tile(i0, lane) = x; *d.y.tile(i0, lane) = y; *d.z.tile(i0, lane) = z; *d.occ.tile(i0, lane) = o; *d.nts.tile(i0, lane) = n; *d.w0.tile(i0, lane) = w;
+        }
+    }
+}
 __global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *out) {
     double a, b;
     nk_uniform2_dev(seed, pid, step, tag, a, b);

@@ -71,7 +71,7 @@ class nk_timing(C.Structure):
                 ('total_ms', C.c_double),
                 ('slots', C.c_int64), ('live', C.c_int64),
                 ('regrows', C.c_int64), ('halts', C.c_int64), ('tau_rebuilds', C.c_int64), ('batches', C.c_int64),
-                ('emit_fused', C.c_int64)]
+                ('emit_fused', C.c_int64), ('place_tries', C.c_int64), ('place_gbps', C.c_double), ('place_worst_gbps', C.c_double)]
 
 
 class nk_comm_report(C.Structure):
@@ -408,7 +408,8 @@ class Engine(object):
         return dict(step_kernel_ms=t.step_kernel_ms, emit_kernel_ms=t.emit_kernel_ms, events_kernel_ms=t.events_kernel_ms,
                     total_ms=t.total_ms,
                     slots=int(t.slots), live=int(t.live), regrows=int(t.regrows), halts=int(t.halts),
-                    tau_rebuilds=int(t.tau_rebuilds), batches=int(t.batches), emit_fused=int(t.emit_fused))
+                    tau_rebuilds=int(t.tau_rebuilds), batches=int(t.batches), emit_fused=int(t.emit_fused),
+                    place_tries=int(t.place_tries), place_gbps=t.place_gbps, place_worst_gbps=t.place_worst_gbps)
 
     # ---- set-up table builder (find_specular_correspondences 'velocity', Population.py:1241-1454)
     def specular_begin(self, group_vel, omega, delta_omega):

@@ -121,6 +121,28 @@ def test_store_grows_by_itself(case, monkeypatch):
     compare_by_pid(eng.download(), sim)
 
 
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
+def test_store_placement_choice_moves_the_store(case, monkeypatch):
+    """nk_place_store (the store's allocation is timed against further candidates, the particles move into the fastest):
+    with the test hooks every store -- the first one and each one the growing ensemble forces -- is timed however small it
+    is, and the particles always move into the last candidate.  The run equals the oracle's throughout."""
+    monkeypatch.setenv('NK_TIGHT_STORE', '1')
+    monkeypatch.setenv('NK_PLACE_MIN_MB', '0')
+    monkeypatch.setenv('NK_PLACE_TRIES', '3')
+    monkeypatch.setenv('NK_PLACE_FORCE', '1')
+    ct = case_tables(case)
+    pos, mode, occ, counter = random_population(ct, 20000, seed=19)
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=5, cap=600000, emit_scale=6.0)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=5, emit_scale=6.0)
+    tm = eng.timing()
+    slots0 = tm['slots']
+    assert tm['place_tries'] == 3 and tm['place_gbps'] > 0.0
+    steps_agree(eng, sim, 60, chunk=30)
+    tm = eng.timing()
+    assert tm['slots'] > slots0 and tm['regrows'] > 0 and tm['place_tries'] == 3     # grown, and placed again
+    compare_by_pid(eng.download(), sim)
+
+
 def test_wide_temperature_range_vs_oracle():
     """Reservoirs at 340 K and 290 K, start at 340 K: the subvolume temperatures sweep a range wider than the two grid
     intervals packed into the mode records and further from the reference temperature of the precomputed exponentials
