@@ -369,6 +369,14 @@ __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t ste
     }
 }
 
+// add_reservoir_particles (Population.py:535-536): an entering particle that left its reservoir at (x0, y0, z0) dt_in before the
+// end of the step and meets its first boundary after tc: where it stands at the end of the step, and its timesteps to that boundary.
+__device__ __forceinline__ void nk_newborn_place(const NkDev &d, double x0, double y0, double z0, double vx, double vy, double vz,
+                                                 double dt_in, double tc, double &x, double &y, double &z, double &nts) {
+    x = x0 + vx * dt_in; y = y0 + vy * dt_in; z = z0 + vz * dt_in;       // :536
+    nts = tc / d.dt - dt_in / d.dt;                                      // :535
+}
+
 // Reservoir emission as its own (small) kernel: fill_reservoirs + add_reservoir_particles for the modes a segment owns.
 // A wave evaluates its segment's (reservoir, mode) entries 128 at a time ('one_to_one': reads the segment's inbox), builds
 // the entering particles in whole tiles (Mesh.sample_surface, Mesh.py:923-951; entry times Population.py:391-394 /
@@ -391,6 +399,7 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
                  *sp_rm = L.sp_rm + wave * NK_EMIT_CHUNK;
     double *sp_cv = L.sp_cv + wave * NK_EMIT_CHUNK, *sp_pr = L.sp_pr + wave * NK_EMIT_CHUNK;
     const int nwaves = nblocks * (NK_WG / 64);
+    const bool to_queue = GEOM == 2 && d.NG > 0 && d.qx != nullptr;      // first casts by k_events (below)
     for (int seg = bid * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
@@ -491,6 +500,24 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
                 else nk_sample_res_face(d.res_face_off, d.res_face_cdf, d.res_face_verts, r, uf, us, ur, x0, y0, z0);
                 const double omega = ra.x, vx = ra.y, vy = ra.z, vz = ra.w;
                 const double occ = nk_be(omega * d.c_hk, E0, L.resT[2 * r + 1], d.invT0);   // Population.py:506
+                if (GEOM == 2 && to_queue) {
+                    // split sweep over a face tree: the particle's first ray cast is a tree walk like any other, and k_events runs
+                    // those with its lanes interleaved.  The particle goes into the segment's event queue as it stands on the
+                    // reservoir -- position, entry time in the nts field, the reservoir's facet in the packed word -- and
+                    // k_events finishes what follows here (nk_newborn_place)
+                    const int o = made + j;
+                    if (o < d.segcap) {
+                        const int64_t i = base + o;
+                        const int rf = d.res_facet[r];
+                        const NkFacet &fq = d.facets[rf];
+                        // the facet field: the reservoir's facet if the walk may skip the nodes that hold only its faces, else none
+                        const int skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
+                        d.qx[i] = x0; d.qy[i] = y0; d.qz[i] = z0; d.qocc[i] = occ; d.qnts[i] = dt_in;
+                        d.qw0[i] = NK_NEWBORN | ((uint32_t)((skip == rf ? rf : -1) + 1) << d.lb) | (uint32_t)idx;
+                        if (d.qpid) d.qpid[i] = pid;
+                    } else atomicOr(d.overflow, 1);
+                    continue;
+                }
                 double tc;
                 int facet;
                 int skip = NK_TREE_NO_SKIP;               // the particle starts on its reservoir's facet
@@ -504,9 +531,11 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
                 if (o < d.segcap) {
                     const int64_t i = base + o;
                     const NkSlot q = nk_slot(d, i);
-                    d.x.p[q.od] = x0 + vx * dt_in; d.y.p[q.od] = y0 + vy * dt_in; d.z.p[q.od] = z0 + vz * dt_in;   // :536
+                    double xa, ya, za, na;
+                    nk_newborn_place(d, x0, y0, z0, vx, vy, vz, dt_in, tc, xa, ya, za, na);
+                    d.x.p[q.od] = xa; d.y.p[q.od] = ya; d.z.p[q.od] = za;
                     d.occ.p[q.od] = occ;
-                    d.nts.p[q.od] = tc / d.dt - dt_in / d.dt;                                            // :535
+                    d.nts.p[q.od] = na;
                     d.w0.p[q.ow] = NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx;
                     if (d.pid) d.pid.p[q.od] = pid;
                 } else atomicOr(d.overflow, 1);         // more entering particles than free slots
@@ -518,7 +547,8 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
         for (int o = 32; o > 0; o >>= 1) sp_bound += __shfl_xor(sp_bound, o, 64);
         if (lane == 0) {
             const int room = d.segcap - count;
-            d.seg_new[seg] = made < room ? made : (room > 0 ? room : 0);
+            if (GEOM == 2 && to_queue) { d.seg_new[seg] = 0; d.seg_evq[seg] = made < d.segcap ? made : d.segcap; }
+            else d.seg_new[seg] = made < room ? made : (room > 0 ? room : 0);
             d.seg_bound[seg] = sp_bound;
             if (d.res_gen == 2) d.sp_inbox_n[seg] = 0;
 #ifdef NK_STAMPS
@@ -701,45 +731,72 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
         const int nA = (count + NK_TILE - 1) / NK_TILE;
         NkOut<PID> O;                                 // finished particles on their way back to the segment
         O.init(L, wave);
-        int qn = 0;                                   // SPLIT: entries in the segment's event queue
+        int qn = SPLIT ? d.seg_evq[seg] : 0;          // SPLIT: entries in the segment's event queue (k_emit may have put the entering particles there:
+        if (SPLIT && lane == 0 && qn > 0) atomicAdd(&L.bins.misc[0], (unsigned int)qn);     //  they count as "emitted" here)
         int cn = 0;                                   // particles in the carry (lanes [0, cn))
 #ifdef NK_STAMPS
         unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st_last;
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_last)::"memory");
         const unsigned long long st_c0 = st_last, st_r0 = __builtin_amdgcn_s_memrealtime();   // shader clock against the 100 MHz counter
 #endif
-        // next tile is requested before the current tile's arithmetic
-        uint32_t w0N = 0u;
-        double xN = 0, yN = 0, zN = 0, occN = 0, ntsN = 0;
-        unsigned long long pidN = 0;
-        if (lane < count) {
-            const int64_t i0 = base;
-            w0N = NK_LD(d.w0.tile(i0, lane)); xN = NK_LD(d.x.tile(i0, lane)); yN = NK_LD(d.y.tile(i0, lane)); zN = NK_LD(d.z.tile(i0, lane)); occN = NK_LD(d.occ.tile(i0, lane)); ntsN = NK_LD(d.nts.tile(i0, lane));
-            if (PID) pidN = NK_LD(d.pid.tile(i0, lane));
-        }
-#if NK_PREFETCH2
-        // a second tile on its way (more bytes in flight per wave: the memory system's latency at this load is about one tile's time)
-        uint32_t w0M = 0u;
-        double xM = 0, yM = 0, zM = 0, occM = 0, ntsM = 0;
-        unsigned long long pidM = 0;
-        if (NK_TILE + lane < count) {
-            const int64_t i0 = base + NK_TILE;
-            w0M = NK_LD(d.w0.tile(i0, lane)); xM = NK_LD(d.x.tile(i0, lane)); yM = NK_LD(d.y.tile(i0, lane)); zM = NK_LD(d.z.tile(i0, lane)); occM = NK_LD(d.occ.tile(i0, lane)); ntsM = NK_LD(d.nts.tile(i0, lane));
-            if (PID) pidM = NK_LD(d.pid.tile(i0, lane));
-        }
-#endif
+        // The tiles come through two register sets that take turns (NkTileBuf): a set is read once its tile has arrived and at once
+        // refilled with the tile two turns ahead (NK_PREFETCH2; else one set, one tile ahead).  Nothing ever copies a set that a
+        // load is still to fill -- such a copy waits for that load, which is what made an earlier "second prefetched tile" (one set
+        // shifted into the other every iteration) a second tile in name only: the compiler had to drain the counter at the top of
+        // every iteration (s_waitcnt vmcnt(0)).  Every turn issues the same loads (beyond the segment's particles the address is
+        // clamped into its slots and the lanes are masked), after the deferred stores of the previous turn: "all but the newest
+        // loads" (vmcnt(6), (7) with ids) then leaves exactly the other set's tile in flight.
+        constexpr bool PF2 = NK_PREFETCH2 || SPLIT;
+        constexpr bool DEFER = (NK_DEFER_STORE || PF2) && !NK_OUT_RING;
+        struct NkTileBuf { uint32_t w0; double x, y, z, occ, nts; unsigned long long pid; };
+        NkTileBuf bA = {0u, 0, 0, 0, 0, 0, 0ull}, bB = bA;
+        auto fetch = [&](NkTileBuf &b, int r) {
+            int rr = r < d.segcap - NK_TILE ? r : d.segcap - NK_TILE;
+            const int64_t i0 = base + rr;
+            if (PF2) {
+                // Loads the compiler does not know to be loads: it keeps the memory counter itself, and with the event pass's loops
+                // and branches between a load and its use it gives up and drains the counter (vmcnt(0)) at the top of every turn.
+                // These leave the counting to `arrived` below.  What the compiler issues itself only makes its own waits stricter
+                // (the counter retires in order), and it never touches a set between its loads and the wait: the set is live, and
+                // only `arrived` reads it (the GPU parity tests run every instantiation: a copy of a set in flight would be garbage).
+                const uint32_t *pw = d.w0.tile(i0, lane);
+                const double *px = d.x.tile(i0, lane), *py = d.y.tile(i0, lane), *pz = d.z.tile(i0, lane), *po = d.occ.tile(i0, lane), *pn = d.nts.tile(i0, lane);
+                asm volatile("global_load_dword %0, %1, off" : "=v"(b.w0) : "v"(pw) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.x) : "v"(px) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.y) : "v"(py) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.z) : "v"(pz) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.occ) : "v"(po) : "memory");
+                asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.nts) : "v"(pn) : "memory");
+                if (PID) { const uint64_t *pp = d.pid.tile(i0, lane); asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.pid) : "v"(pp) : "memory"); }
+                return;
+            }
+            b.w0 = NK_LD(d.w0.tile(i0, lane)); b.x = NK_LD(d.x.tile(i0, lane)); b.y = NK_LD(d.y.tile(i0, lane)); b.z = NK_LD(d.z.tile(i0, lane)); b.occ = NK_LD(d.occ.tile(i0, lane)); b.nts = NK_LD(d.nts.tile(i0, lane));
+            if (PID) b.pid = NK_LD(d.pid.tile(i0, lane));
+        };
+        // the set's tile is there: everything but the loads issued last -- the other set's -- has retired
+        auto arrived = [&](NkTileBuf &b) {
+            if (!PF2) return;
+            if (PID) asm volatile("s_waitcnt vmcnt(7)" : "+v"(b.w0), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.occ), "+v"(b.nts), "+v"(b.pid) : : "memory");
+            else asm volatile("s_waitcnt vmcnt(6)" : "+v"(b.w0), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.occ), "+v"(b.nts) : : "memory");
+        };
+        auto drained = [&](NkTileBuf &b) {
+            if (PF2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(b.w0), "+v"(b.x), "+v"(b.y), "+v"(b.z), "+v"(b.occ), "+v"(b.nts), "+v"(b.pid) : : "memory");
+        };
+        fetch(bA, 0);
+        if (PF2) fetch(bB, NK_TILE);
         // The finished particles of a tile are STORED at the top of the next iteration, between the wait for that iteration's
         // tile and the next prefetch (NK_DEFER_STORE): a wave's memory counter retires in order, so the wait for a tile also
         // waits for every store issued after its loads -- stores issued at the end of the previous iteration are the youngest
         // operations in the queue and their acknowledgement is a full memory round trip; issued an iteration earlier they
         // have long retired.  Their slots are taken at once (reserve), so the event pass appends behind them as before.
-        bool sdone = false;
-        int so = 0;
+        bool sdone = false, sev = false;
+        int so = 0, sq = 0;
         double sx = 0, sy = 0, sz = 0, socc = 0, snts = 0;
         uint32_t sw0 = 0u;
         unsigned long long spid = 0;
-        for (int t = 0; t <= nA; ++t) {
+        auto turn = [&](NkTileBuf &buf, const int t) __attribute__((always_inline)) {
             const bool flush = t == nA;               // one empty tile: drains the carry
+            arrived(buf);
 #if NK_PRIO_ROT
             // The SIMD's issue arbiter prefers the OLDEST wave: of the workgroups resident on a CU the first-dispatched one runs
             // ahead and the last one behind (stamps: tile loops of 155 / 165 / 179 / 196 us by quarter of the grid for equal
@@ -762,29 +819,25 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 // ---- relax (deferred from the previous step), drift
                 const int r = t * NK_TILE;
                 act = r + lane < count;
-                w0 = w0N; x = xN; y = yN; z = zN; occ = occN; nts = ntsN; pid = pidN;
+                w0 = buf.w0; x = buf.x; y = buf.y; z = buf.z; occ = buf.occ; nts = buf.nts; pid = buf.pid;
             }
-            if (NK_DEFER_STORE && !NK_OUT_RING) {       // the previous tile's finished particles leave now
+            if (DEFER) {                                // the previous tile's finished particles leave now
                 asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(occ), "+v"(nts), "+v"(w0));   // behind the wait for this tile
                 O.store(d, base, sdone, so, sx, sy, sz, socc, snts, sw0, spid);
                 sdone = false;
+                if (SPLIT && sev) {                     // ... and its event particles, for the queue
+                    if (sq < d.segcap) {
+                        const int64_t i = base + sq;
+                        d.qx[i] = sx; d.qy[i] = sy; d.qz[i] = sz; d.qocc[i] = socc; d.qnts[i] = snts; d.qw0[i] = sw0;
+                        if (PID) d.qpid[i] = spid;
+                    }
+                }
+                sev = false;
             }
+            if (PF2) fetch(buf, (t + 2) * NK_TILE);   // every turn, also the empty one: the count of loads in flight is fixed
             if (!flush) {
                 const int r = t * NK_TILE;
-#if NK_PREFETCH2
-                w0N = w0M; xN = xM; yN = yM; zN = zM; occN = occM; ntsN = ntsM; pidN = pidM;
-                if (r + 2 * NK_TILE + lane < count) {
-                    const int64_t i0 = base + r + 2 * NK_TILE;
-                    w0M = NK_LD(d.w0.tile(i0, lane)); xM = NK_LD(d.x.tile(i0, lane)); yM = NK_LD(d.y.tile(i0, lane)); zM = NK_LD(d.z.tile(i0, lane)); occM = NK_LD(d.occ.tile(i0, lane)); ntsM = NK_LD(d.nts.tile(i0, lane));
-                    if (PID) pidM = NK_LD(d.pid.tile(i0, lane));
-                }
-#else
-                if (r + NK_TILE + lane < count) {
-                    const int64_t i0 = base + r + NK_TILE;
-                    w0N = NK_LD(d.w0.tile(i0, lane)); xN = NK_LD(d.x.tile(i0, lane)); yN = NK_LD(d.y.tile(i0, lane)); zN = NK_LD(d.z.tile(i0, lane)); occN = NK_LD(d.occ.tile(i0, lane)); ntsN = NK_LD(d.nts.tile(i0, lane));
-                    if (PID) pidN = NK_LD(d.pid.tile(i0, lane));
-                }
-#endif
+                if (!PF2) fetch(buf, r + NK_TILE);
                 const bool newborn = (w0 & NK_NEWBORN) != 0u;
                 w0 &= ~NK_NEWBORN;
                 const int idx = act ? (int)(w0 & lbmask) : 0;
@@ -815,13 +868,14 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
             const bool done = act && !ev;
             const unsigned long long mD = __ballot(done), mE = __ballot(ev);
             if (done) nk_tally_one(d, L.tb, L.bins, x, y, z, occ, omega, E0, vx, vy, vz, do_flux, rep);
-            if (NK_DEFER_STORE && !NK_OUT_RING) {
+            if (DEFER) {
                 so = O.reserve(nk_rank(mD), __popcll(mD));
                 sdone = done; sx = x; sy = y; sz = z; socc = occ; snts = nts; sw0 = w0; spid = pid;
             } else O.push(d, base, lane, done, nk_rank(mD), __popcll(mD), x, y, z, occ, nts, w0, pid);
             NK_STAMP(2);
             if (SPLIT) {                               // the tile's event particles leave for the queue; k_events takes over
-                if (ev) {
+                if (DEFER) { sev = ev; sq = qn + nk_rank(mE); }     // (a particle is final or has an event: the same held values)
+                else if (ev) {
                     const int o = qn + nk_rank(mE);
                     if (o < d.segcap) {
                         const int64_t i = base + o;
@@ -830,7 +884,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                     }
                 }
                 qn += __popcll(mE);
-                continue;
+                return;
             }
             // ---- drain (Population.py:1546-1683): the tile's event particles are parked in the wave's carry (LDS); whenever it
             // holds 64 (or on the last, empty tile) the whole wave runs one boundary event per particle; finished particles
@@ -927,7 +981,9 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 NK_STAMP(5);
             }
             NK_STAMP(3);
-        }
+        };
+        if (PF2) { for (int t = 0; t <= nA; t += 2) { turn(bA, t); if (t + 1 <= nA) turn(bB, t + 1); } drained(bA); drained(bB); }
+        else for (int t = 0; t <= nA; ++t) turn(bA, t);
 #ifdef NK_STAMPS
         if (lane == 0 && d.stamps) {
             unsigned long long *o = d.stamps + (int64_t)seg * 8;
@@ -1042,6 +1098,8 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
     unsigned long long pid = 0;
     double cts = 0.0;
     int idx0 = 0, seg = 0;
+    bool first = false;                               // the lane holds an entering particle before its first ray cast (k_emit)
+    int skipl = NK_TREE_NO_SKIP;                      // facet whose nodes this lane's walk skips (nk_tree_skip)
     p.x = p.y = p.z = p.occ = p.nts = p.omega = p.E0 = p.vx = p.vy = p.vz = 0.0; p.mode = 0; p.facet = -1;
     nk_walk_begin(d, W, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0);
 #ifdef NK_STAMPS
@@ -1076,9 +1134,18 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                     const double4 ra = *reinterpret_cast<const double4 *>(rec);
                     p.omega = ra.x; p.vx = ra.y; p.vy = ra.z; p.vz = ra.w;
                     p.E0 = rec->E0;
-                    p.facet = (int)(w0 >> d.lb) - 1;
+                    p.facet = (int)((w0 & ~NK_NEWBORN) >> d.lb) - 1;
                     cts = 0.0; evc = 0u;
                     phase = NK_PH_PRE;
+                    first = (w0 & NK_NEWBORN) != 0u;
+                    skipl = NK_TREE_NO_SKIP;
+                    if (first) {
+                        // an entering particle as k_emit left it on its reservoir (position, entry time in nts, in the facet field
+                        // the facet its walk may skip): its first ray cast is this walk; nk_newborn_place follows in the POST block
+                        skipl = p.facet >= 0 ? p.facet : NK_TREE_NO_SKIP;
+                        nk_walk_begin(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz);
+                        phase = NK_PH_WALK;
+                    }
 #ifdef NK_STAMPS
                     st_got += 1;
 #endif
@@ -1089,7 +1156,7 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
         if (phase == NK_PH_PRE) {
             const int st = nk_event_pre<ROUGH, RBF>(d, L.facets, L.tb, L.resT, L.bins, p, cts, evc, pid, step);
             if (st == NK_EV_DEAD) phase = NK_PH_NEED;
-            else if (tree) { nk_walk_begin(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz); phase = NK_PH_WALK; }
+            else if (tree) { nk_walk_begin(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz); skipl = NK_TREE_NO_SKIP; phase = NK_PH_WALK; }
             else {
                 nk_find_boundary(L.planes, L.faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, W.h.t, W.h.facet);
                 phase = NK_PH_POST;
@@ -1108,6 +1175,9 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                 if (nw <= low) break;
                 // the faces once enough lanes wait at a leaf (or none has boxes to do), else the boxes
                 if (nl >= NK_EVENTS_LEAVES || nl == nw) { if (phase == NK_PH_WALK && W.leaf >= 0) nk_walk_leaf(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz); }
+                // (the entering particles sit together at the head of every segment's queue, so few passes hold a lane whose walk
+                // skips a facet: those passes alone pay for the facet tags)
+                else if (__ballot(phase == NK_PH_WALK && skipl != NK_TREE_NO_SKIP) != 0ull) { if (phase == NK_PH_WALK && W.leaf < 0 && nk_walk_boxes(d, skipl, W)) phase = NK_PH_POST; }
                 else if (phase == NK_PH_WALK && W.leaf < 0 && nk_walk_boxes(d, NK_TREE_NO_SKIP, W)) phase = NK_PH_POST;
 #ifdef NK_STAMPS
                 st_pass += 1;
@@ -1121,8 +1191,17 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
         // ---- the cast's result: another event, or the particle is final
         bool fin = false;
         if (phase == NK_PH_POST) {
-            const int st = nk_event_post(d, p, cts, evc, W.h.t, W.h.facet);
-            if (st == NK_EV_MORE) phase = NK_PH_PRE; else { fin = true; phase = NK_PH_NEED; }
+            if (first) {                                  // the entering particle's first cast is in: end-of-step position, timesteps to go;
+                first = false;                            // inside this step -> its first event, else it is final (as the sweep decides, k_sweep)
+                double xa, ya, za, na;
+                nk_newborn_place(d, p.x, p.y, p.z, p.vx, p.vy, p.vz, p.nts, W.h.t, xa, ya, za, na);
+                p.x = xa; p.y = ya; p.z = za; p.nts = na;
+                p.facet = W.h.facet;
+                if (na < 0.0) phase = NK_PH_PRE; else { fin = true; phase = NK_PH_NEED; }
+            } else {
+                const int st = nk_event_post(d, p, cts, evc, W.h.t, W.h.facet);
+                if (st == NK_EV_MORE) phase = NK_PH_PRE; else { fin = true; phase = NK_PH_NEED; }
+            }
         }
         if (fin) {
             nk_tally_one(d, L.tb, L.bins, p.x, p.y, p.z, p.occ, p.omega, p.E0, p.vx, p.vy, p.vz, do_flux, rep);
