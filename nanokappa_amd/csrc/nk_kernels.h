@@ -770,8 +770,10 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 if (PID) { const uint64_t *pp = d.pid.tile(i0, lane); asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.pid) : "v"(pp) : "memory"); }
                 return;
             }
-            b.w0 = NK_LD(d.w0.tile(i0, lane)); b.x = NK_LD(d.x.tile(i0, lane)); b.y = NK_LD(d.y.tile(i0, lane)); b.z = NK_LD(d.z.tile(i0, lane)); b.occ = NK_LD(d.occ.tile(i0, lane)); b.nts = NK_LD(d.nts.tile(i0, lane));
-            if (PID) b.pid = NK_LD(d.pid.tile(i0, lane));
+            if (r + lane < count) {                       // (one tile ahead, the compiler's own counting: only what will be used)
+                b.w0 = NK_LD(d.w0.tile(i0, lane)); b.x = NK_LD(d.x.tile(i0, lane)); b.y = NK_LD(d.y.tile(i0, lane)); b.z = NK_LD(d.z.tile(i0, lane)); b.occ = NK_LD(d.occ.tile(i0, lane)); b.nts = NK_LD(d.nts.tile(i0, lane));
+                if (PID) b.pid = NK_LD(d.pid.tile(i0, lane));
+            }
         };
         // the set's tile is there: everything but the loads issued last -- the other set's -- has retired
         auto arrived = [&](NkTileBuf &b) {
