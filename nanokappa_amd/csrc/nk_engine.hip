@@ -18,6 +18,13 @@
 
 #include "../../include/nanokappa_hip.h"
 #include "nk_kernels.h"
+// instantiated in nk_sweep_plain.hip (compiled with the machine LICM on; see there; -DNK_PLAIN_IN_ENGINE: here, for comparisons)
+#ifndef NK_PLAIN_IN_ENGINE
+extern template __global__ void k_sweep<1, false, false, false, false, true, 1>(NkDev, uint32_t, int, int);
+extern template __global__ void k_sweep<1, false, false, false, false, true, 2>(NkDev, uint32_t, int, int);
+extern template __global__ void k_sweep<1, false, false, false, false, false, 1>(NkDev, uint32_t, int, int);
+extern template __global__ void k_sweep<1, false, false, false, false, false, 2>(NkDev, uint32_t, int, int);
+#endif
 
 struct NkRccl {      // symbols resolved lazily with dlopen: a single-GPU run never loads librccl
     void *lib = nullptr;

@@ -33,6 +33,10 @@
 //   * the modes a segment owns (nk_device.h) enter through the reservoirs in the same loop: the wave evaluates its
 //     (reservoir, mode) entries, keeps their counts in LDS and builds the entering particles in whole tiles.
 #pragma once
+// non-template kernels get internal linkage in a second translation unit that only wants a template (nk_sweep_plain.hip)
+#ifndef NK_KERNEL_LINKAGE
+#define NK_KERNEL_LINKAGE
+#endif
 #include "nk_device.h"
 
 #define NK_TILE 64           // particles per tile = lanes of a wave
@@ -346,7 +350,7 @@ __device__ __forceinline__ void nk_emit_entry(const NkDev &d, uint32_t step, int
 // reservoir at the previous step (all ranks; nleave_prev is written by the update after the all-reduce).  One thread
 // per candidate: owner test, mode from the cumulative enter_prob (np.searchsorted :472), record (i << 40 | rm << 12)
 // appended to the inbox of the segment that owns the mode.
-__global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t step) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_emit_one_to_one(NkDev d, uint32_t step) {
     if (d.halt[0]) return;
     int64_t total = 0;
     for (int r = 0; r < d.R; ++r) total += d.nleave_prev[r];
@@ -1048,7 +1052,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
 #define NK_PH_PRE 1
 #define NK_PH_WALK 2
 #define NK_PH_POST 3
-__global__ __launch_bounds__(1024) void k_events_begin(NkDev d) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(1024) void k_events_begin(NkDev d) {
     __shared__ int part[1024];
     if (d.halt[0]) return;
     const int t = threadIdx.x, per = (d.nseg + 1023) / 1024;
@@ -1069,7 +1073,7 @@ __global__ __launch_bounds__(1024) void k_events_begin(NkDev d) {
     if (t == 1023) pf[d.nseg] = part[1023];
     if (t == 0) *d.ev_ticket = 0;
 }
-__global__ __launch_bounds__(256) void k_events_end(NkDev d) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_events_end(NkDev d) {
     if (d.halt[0]) return;
     const int seg = blockIdx.x * blockDim.x + threadIdx.x;
     if (seg >= d.nseg) return;
@@ -1251,7 +1255,7 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
 }
 
 // nk_reserve with an unchanged number of segments: every segment's particles move to the start of its longer successor.
-__global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkDev n) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkDev n) {
     for (int seg = blockIdx.x; seg < o.nseg; seg += gridDim.x) {
         const int cnt = o.seg_count[seg];
         const int64_t a = (int64_t)seg * o.segcap, b = (int64_t)seg * n.segcap;
@@ -1268,7 +1272,7 @@ __global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkDev n) {
 // Rough facets: the particles whose reflection moved them to a mode of another segment wait in that segment's inbox; after
 // the step's update they are appended to the segment (one wave per segment, coalesced stores).  A segment that cannot
 // take its migrants keeps them in the inbox and raises the halt word: the host grows the store and delivers again.
-__global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
@@ -1412,7 +1416,7 @@ __device__ __forceinline__ void nk_reduce_body(const NkDev &d, int rows, double 
     __threadfence();
     nk_update_body(d, acc, hist_row, do_flux);
 }
-__global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc, double *hist_row, int do_flux, int fuse) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int rows, double *acc, double *hist_row, int do_flux, int fuse) {
     __shared__ double sh[NK_WG];
     __shared__ int last;
     nk_reduce_body(d, rows, acc, hist_row, do_flux, fuse, (int)blockIdx.x, (int)gridDim.x, sh, last);
@@ -1438,13 +1442,13 @@ __global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int
 }
 
 // The update as its own launch (after the RCCL all-reduce when nranks > 1).
-__global__ __launch_bounds__(NK_WG) void k_update(NkDev d, const double *acc, double *hist_row, int do_flux) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_update(NkDev d, const double *acc, double *hist_row, int do_flux) {
     if (d.halt[0]) return;
     nk_update_body(d, acc, hist_row, do_flux);
 }
 
 // Stand-alone lifetime_scattering (flushes the deferred relaxation).
-__global__ __launch_bounds__(NK_WG) void k_relax(NkDev d, int honor_halt) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d, int honor_halt) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (honor_halt && d.halt[0]) return;
     NkLds L;
@@ -1503,7 +1507,7 @@ __device__ __forceinline__ uint64_t nk_state_key(int mode, double x, double y, d
 // same distance (rounded to 1e-8: a ray through a shared edge or vertex) counted once.  One thread per ray, the triangles
 // pass through LDS in tiles.  A ray with more than NK_XMAX distinct crossings gets -1 (the host counts that one itself).
 #define NK_XMAX 24
-__global__ __launch_bounds__(NK_WG) void k_mesh_crossings(int64_t n, const double *orig, const double *dir, int64_t F, const double *v0,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_mesh_crossings(int64_t n, const double *orig, const double *dir, int64_t F, const double *v0,
                                                           const double *e1, const double *e2, int skip_self, int32_t *counts) {
 #pragma clang fp contract(off)
     __shared__ double tile[NK_WG * 9];
@@ -1553,7 +1557,7 @@ __global__ __launch_bounds__(NK_WG) void k_mesh_crossings(int64_t n, const doubl
 // and draws are repeated until one falls into it), occupation = Bose-Einstein
 // at the temperature of the subvolume the particle is in (:280).  A particle takes the next free slot of the segment that
 // owns its mode (cursor = seg_count, zeroed before the launch).
-__global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, uint64_t pid_lo, const int32_t *umodes, int32_t nu,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, uint64_t pid_lo, const int32_t *umodes, int32_t nu,
                                                           const int64_t *sv_first) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
@@ -1595,7 +1599,7 @@ __global__ __launch_bounds__(NK_WG) void k_init_particles(NkDev d, int64_t n, ui
     }
 }
 // calculate_energy + the heat-flux sums of the particles where they stand (Population.py:704-717, :734-736): the t = 0 row.
-__global__ __launch_bounds__(NK_WG) void k_tally_state(NkDev d) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_tally_state(NkDev d) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
     nk_lds_setup<0, 0>(d, smem, L);
@@ -1655,7 +1659,7 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
 }
 
 // (reservoir, mode) tables between the caller's order [r * M + m] and the segments' order (nk_device.h ep_p / rc_p)
-__global__ void k_perm_rm(int to_seg_order, int R, int M, int nseg, int nlmax, const int32_t *m2s, double *canon, double *perm) {
+NK_KERNEL_LINKAGE __global__ void k_perm_rm(int to_seg_order, int R, int M, int nseg, int nlmax, const int32_t *m2s, double *canon, double *perm) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (int64_t)R * M) return;
     const int r = (int)(i / M), m = (int)(i - (int64_t)r * M);
@@ -1665,7 +1669,7 @@ __global__ void k_perm_rm(int to_seg_order, int R, int M, int nseg, int nlmax, c
 }
 
 // {omega, v, E0, tau[row0..row0+2]} records, by mode index and (part) in the segments' order
-__global__ void k_build_modetab(const double *omega, const double *vg, const double *tau, int M, int NT, int row0, double c_hk,
+NK_KERNEL_LINKAGE __global__ void k_build_modetab(const double *omega, const double *vg, const double *tau, int M, int NT, int row0, double c_hk,
                                 double invT0, int nseg, int nlmax, const int32_t *m2s, NkMode *out, NkMode *out_p) {
     int m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= M) return;
@@ -1694,14 +1698,14 @@ __global__ __launch_bounds__(NK_WG) void k_tap_find_boundary(NkDev d, int64_t n,
     tc[i] = t; fc[i] = f;
     for (int k = 0; k < 3; ++k) xc[3 * i + k] = x[3 * i + k] + t * v[3 * i + k];
 }
-__global__ __launch_bounds__(NK_WG) void k_tap_classify(NkDev d, int64_t n, const double *x, int32_t *id) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_tap_classify(NkDev d, int64_t n, const double *x, int32_t *id) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
     nk_lds_setup<0, 0>(d, smem, L);
     int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i < n) id[i] = nk_classify(d, L.tb, x[3 * i], x[3 * i + 1], x[3 * i + 2]);
 }
-__global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, int what, int64_t n, const double *a, const int32_t *mode,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, int what, int64_t n, const double *a, const int32_t *mode,
                                                     double *out) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
@@ -1717,7 +1721,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, int what, int64_t n
         default: { double invT; out[i] = nk_interp_T(d, L.tb, a[3 * i], a[3 * i + 1], a[3 * i + 2], invT); break; }
     }
 }
-__global__ __launch_bounds__(NK_WG) void k_tap_reflect(NkDev d, int64_t n, const int32_t *facet, const int32_t *mode_in,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_tap_reflect(NkDev d, int64_t n, const int32_t *facet, const int32_t *mode_in,
                                                        const double *col, const double *n_in, const double *om_in,
                                                        const double *r_spec, const double *r_deg, const double *r_diff,
                                                        int32_t *mode_out, double *n_out, double *om_out) {
@@ -1734,7 +1738,7 @@ __global__ __launch_bounds__(NK_WG) void k_tap_reflect(NkDev d, int64_t n, const
 // Counter calibration: coalesced 8-byte-per-lane sweeps with a KNOWN byte count (44 B read + 32 B written per live
 // particle), so FETCH_SIZE / WRITE_SIZE readings of k_sweep can be scaled (MI355X_MICROARCH.md: FETCH_SIZE is
 // uncalibrated for accesses other than 16 B/lane).
-__global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d) {
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
@@ -1773,7 +1777,7 @@ __global__ __launch_bounds__(NK_WG, 3) void k_probe_copy(NkDev d) {
 // `tiles` tiles of EVERY segment, every value written back exactly as it was read -- harmless on a live store, and its time
 // tells the two speeds apart that one and the same store shows depending on where its allocation lies in memory
 // (profiles/r03_notes.txt (9), (17)).
-__global__ __launch_bounds__(NK_WG, 3) void k_probe_place(NkDev d, int tiles) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG, 3) void k_probe_place(NkDev d, int tiles) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
@@ -1791,7 +1795,7 @@ __global__ __launch_bounds__(NK_WG, 3) void k_probe_place(NkDev d, int tiles) {
         }
     }
 }
-__global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *out) {
+NK_KERNEL_LINKAGE __global__ void k_tap_uniform(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *out) {
     double a, b;
     nk_uniform2_dev(seed, pid, step, tag, a, b);
     out[0] = a; out[1] = b;
@@ -1809,7 +1813,7 @@ struct NkSpecMode { double vx, vy, vz, nrm, om, dl, vdn, pad; };     // 64 bytes
 // The records go out in the order of the modes' x-velocity (`rank` = position of mode m in that order), the original mode
 // index in `pad`: a thread of k_specular_pairs then only looks at the window of that order that the first criterion
 // |v_ref.x - v_out.x| / max(|v_ref|, |v_out|) < crit can reach (|v| <= vmax), instead of at all M modes.
-__global__ __launch_bounds__(NK_WG) void k_specular_prepare(int M, const double *v, const double *omega, const double *delta,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_specular_prepare(int M, const double *v, const double *omega, const double *delta,
                                                             const int32_t *rank, double nx, double ny, double nz, NkSpecMode *out) {
 #pragma clang fp contract(off)
     const int m = blockIdx.x * NK_WG + threadIdx.x;
@@ -1821,7 +1825,7 @@ __global__ __launch_bounds__(NK_WG) void k_specular_prepare(int M, const double 
     r.om = omega[m]; r.dl = delta[m]; r.pad = (double)m;
     out[rank[m]] = r;
 }
-__global__ __launch_bounds__(NK_WG) void k_specular_pairs(int M, const NkSpecMode *modes, const double *sorted_vx, double vmax,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_specular_pairs(int M, const NkSpecMode *modes, const double *sorted_vx, double vmax,
                                                           double nx, double ny, double nz, double crit, int64_t cap,
                                                           int32_t *pin, int32_t *pout, unsigned long long *count) {
 #pragma clang fp contract(off)
@@ -1873,7 +1877,7 @@ __device__ __forceinline__ double nk_spec0(const double *v, const double *k2, in
     const double sp = exp(-(e * e) * k2[m / J]);               // exp(-(2 eta cos)^2 k^2), :873-875
     return isnan(sp) ? 0.0 : sp;
 }
-__global__ __launch_bounds__(NK_WG) void k_rough_pairs(int M, int J, const double *v, const double *k2, int64_t npairs, const int32_t *pin,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_rough_pairs(int M, int J, const double *v, const double *k2, int64_t npairs, const int32_t *pin,
                                                       const int32_t *pout, int nf, const int32_t *fidx, const double *nin,
                                                       const double *eta, uint8_t *true_spec, unsigned int *spec_map, double *sub) {
     const int64_t p = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
@@ -1890,7 +1894,7 @@ __global__ __launch_bounds__(NK_WG) void k_rough_pairs(int M, int J, const doubl
 }
 // per (facet, mode): specularity = true_specular * spec0 (:1459); creation rate = max(v.n, 0) - what the pairs took, rounded to
 // ten decimals (np.around, :933)
-__global__ __launch_bounds__(NK_WG) void k_rough_finish(int Fr, int M, int J, const double *v, const double *k2, const double *nin,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_rough_finish(int Fr, int M, int J, const double *v, const double *k2, const double *nin,
                                                        const double *eta, const uint8_t *true_spec, int32_t *spec_map, const double *sub,
                                                        double *specularity, double *rate, int round_now) {
     const int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
@@ -1911,7 +1915,7 @@ __global__ __launch_bounds__(NK_WG) void k_rough_finish(int Fr, int M, int J, co
 // with the smallest relative frequency difference is taken (the first of equals).  The nearest grid point is searched
 // over ALL q-points, staged through LDS in tiles (what scipy's NearestNDInterpolator answers).
 // a2q, q2k: row-major 3 x 3, q = k . a2q and k = q . q2k (Phonon.k_to_q / q_to_k).
-__global__ __launch_bounds__(NK_WG) void k_kspec_pairs(int Q, int J, const double *v, const double *om, const double *kv, const double *a2q,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_kspec_pairs(int Q, int J, const double *v, const double *om, const double *kv, const double *a2q,
                                                        const double *q2k, double tx, double ty, double tz, double nx, double ny, double nz,
                                                        int64_t cap, int32_t *pin, int32_t *pout, unsigned long long *count) {
     // The normal-process test is a comparison of norms that TIE on the zone boundary; which of the equals is a hair smaller
@@ -1986,7 +1990,7 @@ __global__ __launch_bounds__(NK_WG) void k_kspec_pairs(int Q, int J, const doubl
 }
 // 'k' model: creation rates of degenerate branches are averaged (Population.py:926-930), pair after pair in the list's order,
 // before they are rounded.  One thread per rough facet.
-__global__ void k_rough_degen(int Fr, int M, int J, int nd, const int32_t *degen, double *rate) {
+NK_KERNEL_LINKAGE __global__ void k_rough_degen(int Fr, int M, int J, int nd, const int32_t *degen, double *rate) {
     const int f = blockIdx.x * blockDim.x + threadIdx.x;
     if (f >= Fr) return;
     double *r = rate + (int64_t)f * M;
@@ -1996,13 +2000,13 @@ __global__ void k_rough_degen(int Fr, int M, int J, int nd, const int32_t *degen
         r[(int64_t)q * J + j1] = m; r[(int64_t)q * J + j2] = m;
     }
 }
-__global__ void k_rough_round(int64_t n, double *rate) {
+NK_KERNEL_LINKAGE __global__ void k_rough_round(int64_t n, double *rate) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rate[i] = rint(rate[i] * 1e10) / 1e10;
 }
 // creation_roulette = cumsum(rate) / max(cumsum) per facet (:938-939), the running sum in np.cumsum's own order: one wave per
 // facet reads 64 rates at a time (coalesced) and every lane adds them up one by one, keeping the sum at its own position.
-__global__ __launch_bounds__(64) void k_rough_cumsum(int M, double *rate_roul) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(64) void k_rough_cumsum(int M, double *rate_roul) {
     double *r = rate_roul + (int64_t)blockIdx.x * M;
     const int lane = threadIdx.x;
     double run = 0.0, mx = -__builtin_inf();
@@ -2019,7 +2023,7 @@ __global__ __launch_bounds__(64) void k_rough_cumsum(int M, double *rate_roul) {
     for (int m = lane; m < M; m += 64) r[m] = r[m] / mx;
 }
 // bucket index of the roulette search (nk_reflect): lut[f][k] = first position with roulette >= k / nlut * last
-__global__ __launch_bounds__(NK_WG) void k_rough_lut(int Fr, int M, int nlut, const double *roul, int32_t *lut) {
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_rough_lut(int Fr, int M, int nlut, const double *roul, int32_t *lut) {
     const int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= (int64_t)Fr * (nlut + 1)) return;
     const int f = (int)(i / (nlut + 1)), k = (int)(i - (int64_t)f * (nlut + 1));
@@ -2028,12 +2032,12 @@ __global__ __launch_bounds__(NK_WG) void k_rough_lut(int Fr, int M, int nlut, co
     const double thr = ((double)k / (double)nlut) * ro[M - 1];
     lut[i] = nk_ss_left(ro, M, thr);
 }
-__global__ void k_fill_u32(unsigned int *p, int64_t n, unsigned int v) {
+NK_KERNEL_LINKAGE __global__ void k_fill_u32(unsigned int *p, int64_t n, unsigned int v) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
 }
 // enter_probability (Population.py:146-161): p[r, m] = max(0, v . n_in) * dt / thickness_r
-__global__ __launch_bounds__(NK_WG) void k_enter_prob(int R, int M, const double *v, const double *nin, const double *thick, double dt,
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_enter_prob(int R, int M, const double *v, const double *nin, const double *thick, double dt,
                                                      double *out) {
     const int64_t i = (int64_t)blockIdx.x * NK_WG + threadIdx.x;
     if (i >= (int64_t)R * M) return;
