@@ -297,21 +297,31 @@ __device__ __forceinline__ double nk_rcp(double x) {
     e = __builtin_fma(-x, y, 1.0);
     return __builtin_fma(y, e, y);
 }
+// One Horner step p * r + c with a coefficient that is not an inline constant, as ONE instruction.  Left to itself the
+// compiler builds these steps as v_fmac_f64 (accumulate into the addend's register), and since the coefficient must survive
+// -- it sits in a register across the tile loop -- it copies it first: v_mov_b64 + v_fmac_f64, two vector instructions per
+// step, ~30 per particle (profiles/r03_notes.txt (23)).  v_fma_f64 takes the coefficient as a third source.  Same operation,
+// same rounding.
+__device__ __forceinline__ double nk_fma_c(double p, double r, double c) {
+    double o;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(o) : "v"(p), "v"(r), "v"(c));
+    return o;
+}
 __device__ __forceinline__ double nk_exp(double x) {
     const double k = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);
     r = __builtin_fma(-k, 1.90821492927058770002e-10, r);
     double p = 1.6059043836821613e-10;
-    p = __builtin_fma(p, r, 2.08767569878681e-09);
-    p = __builtin_fma(p, r, 2.505210838544172e-08);
-    p = __builtin_fma(p, r, 2.755731922398589e-07);
-    p = __builtin_fma(p, r, 2.7557319223985893e-06);
-    p = __builtin_fma(p, r, 2.48015873015873e-05);
-    p = __builtin_fma(p, r, 1.984126984126984e-04);
-    p = __builtin_fma(p, r, 0.001388888888888889);
-    p = __builtin_fma(p, r, 0.008333333333333333);
-    p = __builtin_fma(p, r, 0.041666666666666664);
-    p = __builtin_fma(p, r, 0.16666666666666666);
+    p = nk_fma_c(p, r, 2.08767569878681e-09);
+    p = nk_fma_c(p, r, 2.505210838544172e-08);
+    p = nk_fma_c(p, r, 2.755731922398589e-07);
+    p = nk_fma_c(p, r, 2.7557319223985893e-06);
+    p = nk_fma_c(p, r, 2.48015873015873e-05);
+    p = nk_fma_c(p, r, 1.984126984126984e-04);
+    p = nk_fma_c(p, r, 0.001388888888888889);
+    p = nk_fma_c(p, r, 0.008333333333333333);
+    p = nk_fma_c(p, r, 0.041666666666666664);
+    p = nk_fma_c(p, r, 0.16666666666666666);
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -320,13 +330,13 @@ __device__ __forceinline__ double nk_exp(double x) {
 }
 __device__ __forceinline__ double nk_exp_small(double dl) {      // exp(dl), |dl| < 1/8: dl^11 / 11! < 3e-18
     double p = 2.755731922398589e-07;
-    p = __builtin_fma(p, dl, 2.7557319223985893e-06);
-    p = __builtin_fma(p, dl, 2.48015873015873e-05);
-    p = __builtin_fma(p, dl, 1.984126984126984e-04);
-    p = __builtin_fma(p, dl, 0.001388888888888889);
-    p = __builtin_fma(p, dl, 0.008333333333333333);
-    p = __builtin_fma(p, dl, 0.041666666666666664);
-    p = __builtin_fma(p, dl, 0.16666666666666666);
+    p = nk_fma_c(p, dl, 2.7557319223985893e-06);
+    p = nk_fma_c(p, dl, 2.48015873015873e-05);
+    p = nk_fma_c(p, dl, 1.984126984126984e-04);
+    p = nk_fma_c(p, dl, 0.001388888888888889);
+    p = nk_fma_c(p, dl, 0.008333333333333333);
+    p = nk_fma_c(p, dl, 0.041666666666666664);
+    p = nk_fma_c(p, dl, 0.16666666666666666);
     p = __builtin_fma(p, dl, 0.5);
     p = __builtin_fma(p, dl, 1.0);
     p = __builtin_fma(p, dl, 1.0);
