@@ -1257,17 +1257,17 @@ static int64_t nk_spawn_bound(const nk_ctx *ctx, int nseg) {
     return (mx + d.nranks - 1) / d.nranks + d.R;
 }
 
-// Where the store's allocation lies in memory decides between two speeds of everything that streams it -- the sweep and a
-// plain copy alike, 15 % apart (profiles/r03_notes.txt (9), (17)); which one an allocation gets depends on what was
-// allocated and freed before it (a process's first large allocation is usually fast, the one made while that one still
-// exists slow, ...).  So the store that is about to be used is timed with k_probe_place, then up to NK_PLACE_TRIES - 1 (default
-// 23) further allocations of the same size are, all held at once so that they cannot be the same memory; as soon as two of
-// them differ by more than 12 % both speeds have been seen and the search ends.  The fastest one becomes the store (its
-// contents are copied over: the layout is the same), the others are freed.  Small stores (< 64 MB) are left alone.
+// Where the store's allocation lies in memory decides how fast everything that streams it runs -- the sweep and a plain copy
+// alike: three speeds, 4.97 / 5.2 / 5.65 TB/s for the in-place copy; of 200 successive 833 MB allocations on one box 119 were
+// slow, 70 in between and 11 fast, scattered (profiles/r03_notes.txt (9), (17), (26)).  So the store that is about to be used
+// is timed with k_probe_place, then up to NK_PLACE_TRIES - 1 (default 95) further allocations of the same size are, all held at
+// once so that they cannot be the same memory (never more than a third of the free memory); as soon as two of them differ by
+// more than 12 % the fast speed has been seen and the search ends.  The fastest one becomes the store (its contents are copied
+// over: the layout is the same), the others are freed.  Small stores (< 64 MB) are left alone.
 static int nk_place_store(nk_ctx *ctx) {
     NkDev &d = ctx->d;
     ctx->timing.place_tries = 0; ctx->timing.place_gbps = 0.0; ctx->timing.place_worst_gbps = 0.0;
-    const int tries = getenv("NK_PLACE_TRIES") ? atoi(getenv("NK_PLACE_TRIES")) : 24;
+    const int tries = getenv("NK_PLACE_TRIES") ? atoi(getenv("NK_PLACE_TRIES")) : 96;
     const size_t bytes = nk_store_bytes(d.cap, ctx->store_pid);
     // test hooks: NK_PLACE_MIN_MB (stores below it are not timed; default 64), NK_PLACE_FORCE=1 (always move into the last candidate)
     const size_t min_mb = getenv("NK_PLACE_MIN_MB") ? (size_t)atol(getenv("NK_PLACE_MIN_MB")) : 64;
@@ -1301,7 +1301,7 @@ static int nk_place_store(nk_ctx *ctx) {
         double lo = ms[0], hi = ms[0];
         for (double v : ms) { lo = std::min(lo, v); hi = std::max(hi, v); }
         if (hi > 1.12 * lo && !force) break;                             // both speeds seen (they are 13-20 % apart; in-between ones occur)
-        if (bytes * cand.size() > free_b / 4) break;                     // the extra ones: never more than a quarter of what is free
+        if (bytes * cand.size() > free_b / 3) break;                     // the extra ones: never more than a third of what is free
         void *buf = nullptr;
         if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
         cand.push_back(buf); ms.push_back(0.0);

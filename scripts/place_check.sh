@@ -1,7 +1,7 @@
 #!/bin/bash
 # The store-placement choice (nk_place_store) on one box: plain bench twice, under rocprofv3, and across re-allocations
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/place; mkdir -p $O; cd $R
-for i in 0 1 2; do
+for i in 0 1 2 3; do
   NK_VERBOSE=1 timeout -k 10 300 python3 bench.py --no-cpu-baseline --sustained 0 --per-call 0 > $O/plain_$i.json 2> $O/plain_$i.err || { echo FAILED; tail -5 $O/plain_$i.err; exit 1; }
   grep -h "store placement" $O/plain_$i.err
   python3 -c "

@@ -147,8 +147,9 @@ __global__ __launch_bounds__(256) void k_linear(double2 *b, size_t n) {
     }
 }
 
+static int g_nseg = 3072;       // streams (waves) of the stream kernels: third argument
 static double time_kernel(int streams, void *buf, size_t bytes, hipEvent_t e0, hipEvent_t e1) {
-    const int nseg = 3072, blocks = (int)(bytes / 2816 / nseg);
+    const int nseg = g_nseg, blocks = (int)(bytes / 2816 / nseg);
     auto go = [&]() {
         if (streams == 4) k_streams4<<<nseg / 4, 256>>>((double *)buf, nseg, blocks);
         else if (streams == 3) k_streams3<<<nseg / 4, 256>>>((double *)buf, nseg, blocks);
@@ -170,6 +171,7 @@ int main(int argc, char **argv) {
     const size_t mb = argc > 1 ? atol(argv[1]) : 833;
     const int count = argc > 2 ? atoi(argv[2]) : 8;
     const size_t bytes = mb << 20;
+    if (argc > 3) g_nseg = atoi(argv[3]);
     CK(hipSetDevice(0));
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
