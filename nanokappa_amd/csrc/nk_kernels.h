@@ -762,7 +762,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 // and branches between a load and its use it gives up and drains the counter (vmcnt(0)) at the top of every turn.
                 // These leave the counting to `arrived` below.  What the compiler issues itself only makes its own waits stricter
                 // (the counter retires in order), and it never touches a set between its loads and the wait: the set is live, and
-                // only `arrived` reads it (the GPU parity tests run every instantiation: a copy of a set in flight would be garbage).
+                // only `arrived` reads it (tests/test_isa_inflight.py walks the assembly for any instruction that does; a copy of a
+                // set in flight would also be garbage in every GPU parity test).
                 const uint32_t *pw = d.w0.tile(i0, lane);
                 const double *px = d.x.tile(i0, lane), *py = d.y.tile(i0, lane), *pz = d.z.tile(i0, lane), *po = d.occ.tile(i0, lane), *pn = d.nts.tile(i0, lane);
                 asm volatile("global_load_dword %0, %1, off" : "=v"(b.w0) : "v"(pw) : "memory");
