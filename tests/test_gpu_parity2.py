@@ -143,6 +143,30 @@ def test_store_placement_choice_moves_the_store(case, monkeypatch):
     compare_by_pid(eng.download(), sim)
 
 
+@pytest.mark.parametrize('gen', [1, 2])
+def test_other_generators_on_a_large_mesh(gen):
+    """'fixed_rate' and 'one_to_one' reservoirs on the 72-sided wire (288 faces: split sweep, face tree): their entering
+    particles take their first ray cast in k_events' walks, from the segment's event queue, like those of 'constant' --
+    engine and oracle step by step, then particle by particle."""
+    from util import case_from_args, population_in_mesh
+    from test_gpu_parity import EXTRA_CASES, COMMON_ARGS
+    argv, species = EXTRA_CASES['wire72']
+    ct = case_from_args(argv + COMMON_ARGS, species)
+    pos, mode, occ, counter = population_in_mesh(ct, 30000, seed=21)
+    nsteps = 20
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=77, cap=120000, gen=gen)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=77, gen=gen)
+    t = eng.step(nsteps)
+    for s in range(nsteps):
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+        if gen == 2 and s > 0:
+            assert t['N_emitted'][s] == t['N_leaving'][s - 1].sum()
+    assert t['N_emitted'].sum() > 0
+    compare_by_pid(eng.download(), sim)
+
+
 def test_wide_temperature_range_vs_oracle():
     """Reservoirs at 340 K and 290 K, start at 340 K: the subvolume temperatures sweep a range wider than the two grid
     intervals packed into the mode records and further from the reference temperature of the precomputed exponentials
