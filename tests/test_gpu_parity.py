@@ -584,7 +584,7 @@ def test_rccl_path_single_rank(monkeypatch):
     assert np.allclose(t0['T_sv'], t1['T_sv'], rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
+@pytest.mark.parametrize('case', ['ttp', 'ttrrp', 'wire72'])
 def test_two_rank_sharding_on_one_gpu(case, monkeypatch):
     """The engine's rank-dependent code -- particle ids offset by the shard, every rank advancing all reservoir counters
     and keeping the entering particles it owns -- with two contexts on one GPU (NK_COMM_DRYRUN: no communicator, so the
@@ -592,9 +592,15 @@ def test_two_rank_sharding_on_one_gpu(case, monkeypatch):
     (in 'ttrrp': which mode a diffuse reflection draws does not, only its occupation), so the union of the two shards
     must hold exactly the single-rank run's particles: same ids, modes and positions."""
     from nanokappa_amd.sharding import shard_range
-    ct = case_tables(case)
     n = 40000
-    pos, mode, occ, counter = random_population(ct, n, seed=3)
+    if case == 'wire72':                               # large mesh: split sweep, entering particles through the event queue
+        from util import case_from_args, population_in_mesh
+        argv, species = EXTRA_CASES['wire72']
+        ct = case_from_args(argv + COMMON_ARGS, species)
+        pos, mode, occ, counter = population_in_mesh(ct, n, seed=3)
+    else:
+        ct = case_tables(case)
+        pos, mode, occ, counter = random_population(ct, n, seed=3)
     ref = make_engine(ct, pos, mode, occ, counter, seed=5)
     t = ref.step(12)
     p = ref.download()
