@@ -1261,8 +1261,8 @@ static int64_t nk_spawn_bound(const nk_ctx *ctx, int nseg) {
 // alike: three speeds, 4.97 / 5.2 / 5.65 TB/s for the in-place copy; of 200 successive 833 MB allocations on one box 119 were
 // slow, 70 in between and 11 fast, scattered (profiles/r03_notes.txt (9), (17), (26)).  So the store that is about to be used
 // is timed with k_probe_place, then up to NK_PLACE_TRIES - 1 (default 95) further allocations of the same size are, all held at
-// once so that they cannot be the same memory (never more than a third of the free memory); as soon as two of them differ by
-// more than 12 % the fast speed has been seen and the search ends.  The fastest one becomes the store (its contents are copied
+// once so that they cannot be the same memory (never more than a third of the free memory); as soon as one is 12 % faster than the
+// slowest and at the fast level (5.5 TB/s and more) the search ends.  The fastest one becomes the store (its contents are copied
 // over: the layout is the same), the others are freed.  Small stores (< 64 MB) are left alone.
 static int nk_place_store(nk_ctx *ctx) {
     NkDev &d = ctx->d;
@@ -1300,8 +1300,12 @@ static int nk_place_store(nk_ctx *ctx) {
     while (!rc && (int)cand.size() < tries) {
         double lo = ms[0], hi = ms[0];
         for (double v : ms) { lo = std::min(lo, v); hi = std::max(hi, v); }
-        if (hi > 1.12 * lo && !force) break;                             // both speeds seen (they are 13-20 % apart; in-between ones occur)
+        // the fast speed has been seen: 12 % above the slowest candidate AND at the level the fast memory of an MI355X gives this
+        // copy (5.6-5.9 TB/s; the level in between, 5.2, does not end the search)
+        const double gb_ = 2.0 * (double)d.nseg * tiles * 64 * 44 / 1e9;
+        if (hi > 1.12 * lo && gb_ / (lo * 1e-3) >= 5500.0 && !force) break;
         if (bytes * cand.size() > free_b / 3) break;                     // the extra ones: never more than a third of what is free
+        if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count() > 1000.0) break;   // ... nor more than a second (large stores: 0.1 s per allocation)
         void *buf = nullptr;
         if (hipMalloc(&buf, bytes) != hipSuccess) { (void)hipGetLastError(); break; }
         cand.push_back(buf); ms.push_back(0.0);
