@@ -475,6 +475,11 @@ def main():
             out['per_call'] = per_call
         if sustained is not None:
             out['sustained'] = sustained
+            # kappa is half of BASELINE's metric: a line whose sustained leg recorded convergence rows but no finite kappa
+            # (BENCH_r03: the engine's flux phase and Population's row phase apart) is not a result
+            if sustained['kappa_samples'] > 0 and not np.isfinite(sustained['kappa_mean']):
+                print(json.dumps(out))
+                raise SystemExit('bench.py: %d convergence rows in the sustained leg and no finite kappa' % sustained['kappa_samples'])
         if cpu_legs:
             rough = None
             if rough_cfg:                    # the tables the Population built (on the device), handed to the oracle

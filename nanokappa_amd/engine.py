@@ -380,6 +380,12 @@ class Engine(object):
         self._ck(self.L.nk_step(self.h, int(nsteps), C.byref(t)), 'nk_step')
         return out
 
+    def get_step(self):
+        """Timesteps this engine has completed (the library's absolute step counter: flux and contains_check cadence)."""
+        n = C.c_int64(0)
+        self._ck(self.L.nk_get_step(self.h, C.byref(n)), 'nk_get_step')
+        return int(n.value)
+
     def download(self):
         n = C.c_int64(0)
         self._ck(self.L.nk_download_particles(self.h, 0, None, None, None, None, None, None, None, None, C.byref(n)),

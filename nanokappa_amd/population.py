@@ -123,6 +123,7 @@ class Population(Constants):
         self.n_mean = int(args.n_mean[0])
         self._geo, self._ph = geometry, phonon
         self.current_timestep = 0
+        self._bal_steps = 0
         self.seed = int(getattr(args, 'seed', [0])[0])
         self.rng = np.random.default_rng(self.seed)
 
@@ -595,13 +596,34 @@ class Population(Constants):
         """Population.py:1685-1693."""
         if self.n_of_reservoirs > 0:
             A = geometry.facets_area[self.res_facet].reshape(-1, 1)
-            c = phonon.number_of_active_modes / (self.particle_density * self.dt * self.n_dt_to_conv)
+            # the steps the sums cover: n_dt_to_conv (:1688), fewer only in the first window after the engine was
+            # stepped behind this object's back (_sync_clock)
+            nw = self._bal_steps if getattr(self, '_bal_steps', 0) > 0 else self.n_dt_to_conv
+            c = phonon.number_of_active_modes / (self.particle_density * self.dt * nw)
             self.res_heat_flux = phonon.normalise_to_density(self.res_heat_flux * c / A) * self.eVpsa2_in_Wm2
             self.res_energy_balance = phonon.normalise_to_density(self.res_energy_balance * c)
 
     def restart_reservoir_balance(self):
         self.res_heat_flux = np.zeros((self.n_of_reservoirs, 3))                    # Population.py:1695-1699
         self.res_energy_balance = np.zeros(self.n_of_reservoirs)
+        self._bal_steps = 0
+
+    def _sync_clock(self):
+        """ONE step counter: the engine's.  The library tallies the heat flux on its own absolute step ((step + 1) % flux_every,
+        nk_step) and runs contains_check on it; the convergence rows (Population.py:1762-1767, n_dt_to_conv :41) and the
+        100-step bookkeeping (:1729-1741) are keyed on current_timestep.  A caller that also steps the engine directly
+        (nk_step through the C ABI, bench.py's timed regions) moves the former only; before every run the latter follows, so
+        that every convergence row lands on a step whose flux was tallied.  The reservoir sums of the steps taken behind
+        this object's back were not collected: the window in progress restarts here and is normalised by the steps it
+        really covers (adjust_reservoir_balance)."""
+        get = getattr(self.engine, 'get_step', None)
+        if get is None:
+            return
+        es = int(get())
+        if es != self.current_timestep:
+            self.current_timestep = es
+            self.t = es * self.dt
+            self.restart_reservoir_balance()
 
     # ------------------------------------------------------------------------------- time loop
     def run_timestep(self, geometry, phonon):
@@ -614,6 +636,7 @@ class Population(Constants):
         geometry = geometry if geometry is not None else self._geo
         phonon = phonon if phonon is not None else self._ph
         self._geo, self._ph = geometry, phonon
+        self._sync_clock()
         done = 0
         while done < nsteps:
             if self.current_timestep == 0:
@@ -646,6 +669,7 @@ class Population(Constants):
                     for q in range(s0, s1):                     # same summation order as stepping one by one
                         self.res_energy_balance = self.res_energy_balance + t['res_energy'][q]
                         self.res_heat_flux = self.res_heat_flux + t['res_flux'][q]
+                    self._bal_steps += s1 - s0
                 if (self.current_timestep % self.n_dt_to_conv) == 0:                # Population.py:1762-1767
                     self.subvol_heat_flux = self._normalise_flux(phonon, t['flux_raw'][s], self.subvol_N_p)
                     self.calculate_kappa(geometry)

@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import pytest
 
-from util import case_from_dropin, case_tables, golden_phonon, make_engine, make_oracle_sim, rel_err
+from util import case_from_dropin, case_tables, golden_phonon, make_engine, make_oracle_sim, rel_err, allclose
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
 
@@ -24,9 +24,9 @@ def test_tables_from_reference_objects_equal_own(case):
     assert rel_err(t['T_array'], o['T_array']) < 1e-13 and rel_err(t['energy_array'], o['energy_array']) < 1e-12
     m, om = ct['mesh'], own['mesh']
     for k in ('face_normals', 'face_k', 'face_bounds', 'face_basis_matrix', 'face_origins', 'facets_normal', 'facet_centroid', 'bounds'):
-        assert np.allclose(m[k], om[k], rtol=0, atol=1e-12), k
+        assert allclose(m[k], om[k], rtol=0, atol=1e-12), k
     assert np.array_equal(m['face_facets'], om['face_facets']) and np.array_equal(m['bound_cond'], om['bound_cond'])
-    assert np.allclose(ct['centers'], own['centers']) and np.allclose(ct['volumes'], own['volumes'])
+    assert allclose(ct['centers'], own['centers'], rtol=1e-12) and allclose(ct['volumes'], own['volumes'], rtol=1e-12)
     assert np.array_equal(ct['res_facets'], own['res_facets']) and np.array_equal(ct['res_T'], own['res_T'])
     # the fixture was made at 2e4 particles, the set-up golden at 1e5: entry probabilities scale with the density
     scale = ct['particle_density'] / own['particle_density']
@@ -64,12 +64,12 @@ def test_engine_on_dropin_tables_follows_oracle(case):
     for s in range(25):
         sim.run_timestep()
         assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
-        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+        assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
     p = eng.download()
     n = sim.P.N
     o1, o2 = np.argsort(p['pid']), np.argsort(sim.P.pid[:n])
     assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2]) and np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
-    assert np.allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=1e-8)
+    assert allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=1e-8)
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
@@ -93,10 +93,10 @@ def test_device_branch_arguments_from_reference_objects(case):
     ph = golden_phonon()
     m = ct['mesh']
     ea = {k.split('__', 1)[1]: v for k, v in d.items() if k.startswith('enter_prob_args__')}
-    assert np.allclose(ea['normal_in'], -m['facets_normal'][ct['res_facets']], rtol=0, atol=1e-12) and float(ea['dt']) == 1.0
+    assert allclose(ea['normal_in'], -m['facets_normal'][ct['res_facets']], rtol=0, atol=1e-12) and float(ea['dt']) == 1.0
     # thickness = M / (rho A): the fixture was made at 2e5 particles in the 200 A box with 200 x 200 facets
     rho = 200000 / 200.0 ** 3
-    assert np.allclose(ea['thickness'], ph.number_of_active_modes / (rho * 200.0 * 200.0), rtol=1e-12)
+    assert allclose(ea['thickness'], ph.number_of_active_modes / (rho * 200.0 * 200.0), rtol=1e-12)
     ip = {k.split('__', 1)[1]: v for k, v in d.items() if k.startswith('init_particles__')}
     assert int(ip['n']) == 200000 and int(ip['pid_lo']) == 0 and int(d['N_p']) == 200000
     active = np.nonzero(~ph.inactive_modes_mask.ravel())[0]
@@ -107,12 +107,12 @@ def test_device_branch_arguments_from_reference_objects(case):
         assert bool(d['rough_on_device'])
         rb = {k.split('__', 1)[1]: v for k, v in d.items() if k.startswith('rough_begin__')}
         assert np.array_equal(rb['facets'], own['rough']['facets'])
-        assert np.allclose(rb['normal_in'], -m['facets_normal'][rb['facets']], rtol=0, atol=1e-12)
+        assert allclose(rb['normal_in'], -m['facets_normal'][rb['facets']], rtol=0, atol=1e-12)
         assert np.array_equal(rb['eta'], [5.0, 5.0])
-        assert np.allclose(rb['k_norm'], np.sum(ph.wavevectors ** 2, axis=1) ** 0.5, rtol=1e-13)
+        assert allclose(rb['k_norm'], np.sum(ph.wavevectors ** 2, axis=1) ** 0.5, rtol=1e-13)
         sb = {k.split('__', 1)[1]: v for k, v in d.items() if k.startswith('spec_begin__')}
-        assert np.allclose(sb['group_vel'], ph.group_vel.reshape(-1, 3), rtol=0, atol=1e-12)
-        assert np.allclose(sb['omega'], ph.omega.ravel(), rtol=1e-14)
+        assert allclose(sb['group_vel'], ph.group_vel.reshape(-1, 3), rtol=0, atol=1e-12)
+        assert allclose(sb['omega'], ph.omega.ravel(), rtol=1e-14)
         assert d['spec_pairs__normals'].shape == (2, 3) and np.array_equal(np.sort(d['rough_pairs__share_flat']), [0, 1])
     else:
         assert not bool(d['rough_on_device'])

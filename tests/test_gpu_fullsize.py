@@ -17,6 +17,8 @@ import sys
 import numpy as np
 import pytest
 
+from util import allclose
+
 pytestmark = pytest.mark.gpu
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)
@@ -83,7 +85,7 @@ def test_full_size_properties(cfg, total, monkeypatch):
     pop2.engine.close()
     for k in ('N_sv', 'N_emitted', 'N_leaving'):
         assert np.array_equal(t[k], t2[k]), k
-    assert np.allclose(t['T_sv'], t2['T_sv'], rtol=0, atol=1e-9)
+    assert allclose(t['T_sv'], t2['T_sv'], rtol=0, atol=1e-9)
     # sharding (counts only: with local tallies the temperatures differ, trajectories do not depend on them)
     monkeypatch.setenv('NK_COMM_DRYRUN', '1')
     em, census = 0, 0

@@ -9,7 +9,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from util import rel_err, case_tables, random_population, make_oracle_sim, make_engine
+from util import rel_err, case_tables, random_population, make_oracle_sim, make_engine, allclose
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
@@ -22,8 +22,8 @@ def compare_by_pid(p, sim, pos_atol=1e-8):
     assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
     assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
     assert np.array_equal(p['facet'][o1], sim.P.facet[:n][o2])
-    assert np.allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=pos_atol)
-    assert np.allclose(p['n_timesteps'][o1], sim.P.n_ts[:n][o2], rtol=1e-9, atol=1e-9)
+    assert allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=pos_atol)
+    assert allclose(p['n_timesteps'][o1], sim.P.n_ts[:n][o2], rtol=1e-9, atol=1e-9)
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
@@ -36,7 +36,7 @@ def compare_by_state(p, sim):
     o2 = np.lexsort((q[:, 2], q[:, 1], q[:, 0], sim.P.mode[:n]))
     assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
     assert np.array_equal(p['facet'][o1], sim.P.facet[:n][o2])
-    assert np.allclose(p['positions'][o1], q[o2], rtol=1e-10, atol=1e-8)
+    assert allclose(p['positions'][o1], q[o2], rtol=1e-10, atol=1e-8)
     assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
 
 
@@ -48,7 +48,7 @@ def steps_agree(eng, sim, nsteps, chunk=50):
         for s in range(k):
             sim.run_timestep()
             assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % (done + s)
-            assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % (done + s)
+            assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % (done + s)
         done += k
 
 
@@ -160,7 +160,7 @@ def test_other_generators_on_a_large_mesh(gen):
     for s in range(nsteps):
         sim.run_timestep()
         assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
-        assert np.allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+        assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
         if gen == 2 and s > 0:
             assert t['N_emitted'][s] == t['N_leaving'][s - 1].sum()
     assert t['N_emitted'].sum() > 0

@@ -14,7 +14,7 @@ import sys
 import numpy as np
 import pytest
 
-from util import golden, golden_material
+from util import golden, golden_material, allclose
 
 pytestmark = pytest.mark.gpu
 
@@ -176,8 +176,8 @@ def test_part_dist_center_subvol():
     x = p['positions']
     assert x.shape[0] == 20000
     cx = np.unique(np.round(x[:, 0], 9))
-    assert cx.shape[0] == 20 and np.allclose(cx, np.sort(np.asarray(geo.subvol_center)[:, 0]))
-    assert np.allclose(x[:, 1], 100.0) and np.allclose(x[:, 2], 100.0)
+    assert cx.shape[0] == 20 and allclose(cx, np.sort(np.asarray(geo.subvol_center)[:, 0]), rtol=1e-12)
+    assert allclose(x[:, 1], 100.0, rtol=1e-12) and allclose(x[:, 2], 100.0, rtol=1e-12)
     pop.run(5, geo, ph)
     assert abs(pop.N_p - 20000) < 2000
     pop.engine.close()
@@ -334,3 +334,20 @@ def test_parameter_file_front_end(tmp_path, monkeypatch):
     assert len(conv) == 1 + 1 + 23                       # header, t = 0, one row per 10 steps
     assert abs(pop.N_p - 40000) < 4000 and np.all(np.isfinite(pop.subvol_temperature))
     pop.engine.close()
+
+
+@pytest.mark.gpu
+def test_bench_line_carries_a_finite_kappa_with_the_drivers_arguments():
+    """`bench.py --steps 20 --warmup 5` steps the engine 525 times before the sustained leg; the rows of
+    that leg must still land on steps whose flux the library tallied (one step clock, tests/test_step_clock.py).  A reduced
+    ensemble and material keep this a matter of seconds; the code path is the default line's."""
+    import json
+    import subprocess
+    root = os.path.join(os.path.dirname(__file__), '..')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '20', '--warmup', '5',
+                        '--particles', '300000', '--mesh-n', '9', '--sustained', '300', '--per-call', '25', '--no-cpu-baseline'],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    s = line['sustained']
+    assert s['kappa_samples'] > 0 and np.isfinite(s['kappa_mean']) and s['kappa_mean'] > 0

@@ -8,7 +8,7 @@ import re
 import numpy as np
 import pytest
 
-from util import golden, sub, golden_phonon
+from util import golden, sub, golden_phonon, allclose
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF = os.path.join(HERE, 'golden', 'ref_outputs')
@@ -155,7 +155,7 @@ def test_kappa_and_reservoir_balance_formulas(variant, tmp_path):
     pop.N_p = int(gs['post_subvol_N_p'].sum())
     pop.res_facet_temperature = gs['res_facet_temperature']
     pop.calculate_kappa(geo)
-    assert np.allclose(pop.subvol_kappa, gs['subvol_kappa'], rtol=1e-12, atol=0)
+    assert allclose(pop.subvol_kappa, gs['subvol_kappa'], rtol=1e-12, atol=0)
     assert np.isclose(pop.kappa, float(gs['kappa']), rtol=1e-12, atol=0)
     pop.res_facet = gm['res_facets']
     pop.res_energy_balance = gs['mid_res_energy_balance'].copy()
@@ -164,5 +164,5 @@ def test_kappa_and_reservoir_balance_formulas(variant, tmp_path):
     pop.n_dt_to_conv = 10
     geo.facets_area = gm['facets_area']
     pop.adjust_reservoir_balance(geo, ph)
-    assert np.allclose(pop.res_energy_balance, gs['adj_res_energy_balance'], rtol=1e-12, atol=0)
-    assert np.allclose(pop.res_heat_flux, gs['adj_res_heat_flux'], rtol=1e-12, atol=1e-300)
+    assert allclose(pop.res_energy_balance, gs['adj_res_energy_balance'], rtol=1e-12, atol=0)
+    assert allclose(pop.res_heat_flux, gs['adj_res_heat_flux'], rtol=1e-12, atol=1e-300)

@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from util import golden_phonon
+from util import golden_phonon, allclose
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), 'golden'))
 
@@ -30,7 +30,7 @@ def test_fixed_point_recovers_the_profile():
     sv = np.repeat(np.arange(S), 2 * active.shape[0])
     occ = ph.calculate_occupation(T_true[sv], ph.omega[modes[:, 0], modes[:, 1]])
     T = pop._resume_temperatures(ph, sv, modes, occ, np.full(S, 298.0))
-    assert np.allclose(T, T_true, rtol=0, atol=2e-4)            # the E <-> T tables step by 0.1 K, linear in between
+    assert allclose(T, T_true, rtol=0, atol=2e-4)            # the E <-> T tables step by 0.1 K, linear in between
 
 
 @pytest.mark.gpu

@@ -1,5 +1,6 @@
 """Shared helpers for the tests: golden loading and builders for the oracle structs."""
 import os
+import sys
 
 import numpy as np
 
@@ -42,6 +43,24 @@ def golden_phonon():
     return _PHONON
 
 
+# Every comparison of reals in the GPU tests goes through rel_err / allclose below, which also RECORD the largest
+# deviation seen at each call site; conftest.py writes them to gpurun_out/parity_margins.txt at the end of a `-m gpu` run
+# (committed per round as profiles/rNN_parity_margins.txt).  The tolerances in the tests are set from those measurements
+# (<= 10 x the measured margin), not guessed.
+MARGINS = {}
+
+
+def _record(kind, value, bound, depth=2):
+    f = sys._getframe(depth)
+    key = '%s:%d' % (os.path.basename(f.f_code.co_filename), f.f_lineno)
+    test = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0].split('::')[-1]
+    m = MARGINS.setdefault(key, dict(kind=kind, worst=0.0, bound=bound, calls=0, tests=set()))
+    m['worst'] = max(m['worst'], float(value))
+    m['bound'] = bound if bound is not None else m['bound']
+    m['calls'] += 1
+    m['tests'].add(test)
+
+
 def rel_err(a, b):
     a = np.asarray(a, dtype=float)
     b = np.asarray(b, dtype=float)
@@ -49,7 +68,35 @@ def rel_err(a, b):
     with np.errstate(invalid='ignore'):
         e = np.abs(a - b) / scale
     e = np.where((a == b) | (np.isnan(a) & np.isnan(b)), 0.0, e)
-    return float(np.nanmax(e)) if e.size else 0.0
+    r = float(np.nanmax(e)) if e.size else 0.0
+    _record('rel', r, None)
+    return r
+
+
+def allclose(a, b, rtol=0.0, atol=0.0):
+    """np.allclose with the same meaning (|a - b| <= atol + rtol |b|), recording the largest excess ratio
+    |a - b| / (atol + rtol |b|) and the largest absolute deviation at this call site."""
+    a = np.asarray(a, dtype=float)
+    b = np.asarray(b, dtype=float)
+    with np.errstate(invalid='ignore'):
+        dev = np.abs(a - b)
+    dev = np.where((a == b) | (np.isnan(a) & np.isnan(b)), 0.0, dev)
+    worst = float(np.nanmax(dev)) if dev.size else 0.0
+    _record('abs', worst, 'rtol %g atol %g' % (rtol, atol))
+    return bool(np.allclose(a, b, rtol=rtol, atol=atol, equal_nan=True))
+
+
+def write_margins(path):
+    if not MARGINS:
+        return
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as f:
+        f.write('# largest deviation seen at each comparison of reals in this `pytest -m gpu` run (tests/util.py)\n')
+        f.write('# site | kind (rel = max |a-b|/|b|, abs = max |a-b|) | worst | bound in the test | calls | tests\n')
+        for k in sorted(MARGINS):
+            m = MARGINS[k]
+            f.write('%-32s %-4s %-12.3e %-24s %5d  %s\n' % (k, m['kind'], m['worst'], m['bound'] or '(see the test)', m['calls'],
+                                                          ','.join(sorted(m['tests']))[:160]))
 
 
 # ---------------------------------------------------------------------------------------------------
