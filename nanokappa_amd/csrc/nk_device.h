@@ -36,6 +36,7 @@
 #define NK_EMIT_CHUNK 128    // (reservoir, mode) entries a wave evaluates at a time (two per lane)
 #define NK_LREC 128          // most mode records a wave of the sweep stages in LDS (segments that own more read them from L2)
 #define NK_NEWBORN 0x80000000u
+#define NK_LOST 0x40000000u  // box store (NkDev::box): the particle's last ray cast was a miss -- the reference's n_timesteps = inf, facet -1
 
 // RNG stream tags (shared spec with the oracle; DESIGN.md "RNG")
 #define NK_TAG_REFLECT 0x00000u
@@ -116,6 +117,15 @@ struct NkDev {
     const NkFacet *facets;            // [Fc]
     double tol;
     double bbox[6];
+    // ---- box store (round 4): the mesh is an axis-aligned box whose six sides are its six facets (nk_set_mesh decides).  The
+    // particles then carry NO cached next hit (no nts field, no facet bits): whether a particle meets a wall inside the step is
+    // read off its end-of-step position (outside a wall and flying outwards), and the hit itself -- time and facet -- is
+    // evaluated when the event is run, with the reference's own expression t = -(x.n + k) / (v.n) (Mesh.py:818; for unit axis
+    // normals the two dot products are exact, x.n + k is one rounding).  36 B per particle instead of 44.
+    int32_t box;                      // 1: box store
+    double box_k[6];                  // plane constants k (n.x + k = 0) of the walls: [2 a] the wall with normal -e_a, [2 a + 1] +e_a
+    int32_t box_facet[6];             // their facets
+    int32_t box_face0[6];             // lowest face index of each wall (Mesh.find_boundary: the lowest face index wins a tie)
     const double *face_verts;         // [F*9] original face order
     const int32_t *facet_face_off;    // [Fc+1]
     const int32_t *facet_face_idx;
@@ -174,9 +184,10 @@ struct NkDev {
     int32_t *seg_count;               // [nseg] live particles per segment (contiguous from the segment start)
     int32_t *seg_new;                 // [nseg] particles k_emit appended behind them at this step (the sweep takes them in)
     int32_t *seg_bound;               // [nseg] upper bound of the particles that can enter the segment in one step
-    NkField<double> x, y, z, occ, nts;
+    NkField<double> x, y, z, occ, nts;   // nts: null in a box store
     NkField<uint32_t> w0;             // newborn << 31 | (facet + 1) << lb | idx;  idx = the mode's local index in its segment (part) or the mode itself;
                                       // newborn: appended by k_emit at this step (no relaxation, no drift yet)
+                                      // box store: newborn << 31 | lost << 30 | idx
     NkField<uint64_t> pid;            // null: particle ids are not tracked (no per-particle random draws in this configuration)
     int32_t part;                     // 1: idx is the local index of a mode of the owning segment; 0: the global mode index
     int32_t lb;                       // bits of idx in w0
@@ -607,6 +618,43 @@ __device__ __forceinline__ void nk_find_boundary(const double *planes, const dou
     nk_fb_planes(planes, faces, 0, NP, tol, x, y, z, vx, vy, vz, h);
     tc = h.t;
     fc = h.facet;
+}
+// ---- box store (NkDev::box): the next hit is not cached, it is read off the position.
+// Does the particle at (x, y, z) -- its end-of-step position -- lie beyond a wall it is flying towards?  Then it crossed that
+// wall inside this step (it was inside the solid when the step began: every particle is, after its last event, emission or
+// resampling; a particle behind its reservoir face with a negative entry time flies INWARDS and is not caught here, like in
+// the reference, whose cached next hit is the far wall).  x_a > -k exactly when the reference's numerator x.n + k rounds above
+// zero, so this is the sign of the very t the event pass then computes.
+__device__ __forceinline__ bool nk_box_out(const NkDev &d, double x, double y, double z, double vx, double vy, double vz) {
+    const bool ox = vx > 0.0 ? x > -d.box_k[1] : (vx < 0.0 ? x < d.box_k[0] : false);
+    const bool oy = vy > 0.0 ? y > -d.box_k[3] : (vy < 0.0 ? y < d.box_k[2] : false);
+    const bool oz = vz > 0.0 ? z > -d.box_k[5] : (vz < 0.0 ? z < d.box_k[4] : false);
+    return ox | oy | oz;
+}
+// The wall such a particle crossed FIRST and when, in timesteps counted from the end of the step (negative): for every wall it
+// lies beyond, t = -(x.n + k) / (v.n) as Mesh.find_boundary evaluates it (Mesh.py:816-818; unit axis normal: x.n = +-x_a and
+// v.n = +-v_a exactly), the earliest wins, the lowest face index among equals (:846-848).  What the reference holds in
+// n_timesteps / collision_facets at this point is the same hit, cast from where the particle's free flight began and
+// decremented once per step (Population.py:795): equal up to the rounding of the drift.
+__device__ __forceinline__ void nk_box_first_hit(const NkDev &d, double x, double y, double z, double vx, double vy, double vz,
+                                                 double &nts, int &facet) {
+#pragma clang fp contract(off)
+    double tb = __builtin_inf();
+    int fb = -1, f0b = 0x7fffffff;
+    const double xs[3] = {x, y, z}, vs[3] = {vx, vy, vz};
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const double xa = xs[a], va = vs[a];
+        double num, den;
+        int w;
+        if (va > 0.0 && xa > -d.box_k[2 * a + 1]) { num = xa + d.box_k[2 * a + 1]; den = va; w = 2 * a + 1; }
+        else if (va < 0.0 && xa < d.box_k[2 * a]) { num = -xa + d.box_k[2 * a]; den = -va; w = 2 * a; }
+        else continue;
+        const double t = -num / den;
+        if (t < tb || (t == tb && d.box_face0[w] < f0b)) { tb = t; fb = d.box_facet[w]; f0b = d.box_face0[w]; }
+    }
+    nts = tb / d.dt;
+    facet = fb;
 }
 // Large meshes (tables in global memory): a 4-ary tree of bounding boxes over the FACES, walked by every lane on its own.
 // The faces are sorted along a space-filling curve; a leaf is 4 consecutive faces, node i of level l + 1 the union of

@@ -386,7 +386,8 @@ __device__ __forceinline__ void nk_newborn_place(const NkDev &d, double x0, doub
 // the entering particles in whole tiles (Mesh.sample_surface, Mesh.py:923-951; entry times Population.py:391-394 /
 // :440-443; add_reservoir_particles :525-552) and appends them BEHIND the segment's live particles, marked newborn; the
 // sweep of the same step takes them in (tally, boundary events) without relaxing or drifting them.
-template <int GEOM>
+// BOX (box store): no first ray cast -- the sweep reads a newborn particle's first event off its position like anyone's.
+template <int GEOM, bool BOX = false>
 __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsigned char *smem, int bid, int nblocks) {
 #ifdef NK_STAMPS
     const unsigned long long em_t0 = __builtin_amdgcn_s_memrealtime();
@@ -522,15 +523,15 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
                     } else atomicOr(d.overflow, 1);
                     continue;
                 }
-                double tc;
-                int facet;
+                double tc = 0.0;
+                int facet = -1;
                 int skip = NK_TREE_NO_SKIP;               // the particle starts on its reservoir's facet
                 if (GEOM == 2 && d.NG > 0) {
                     const int rf = d.res_facet[r];
                     const NkFacet &fq = d.facets[rf];
                     skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
                 }
-                NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
+                if (!BOX) NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
                 const int o = count + made + j;
                 if (o < d.segcap) {
                     const int64_t i = base + o;
@@ -539,8 +540,8 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
                     nk_newborn_place(d, x0, y0, z0, vx, vy, vz, dt_in, tc, xa, ya, za, na);
                     d.x.p[q.od] = xa; d.y.p[q.od] = ya; d.z.p[q.od] = za;
                     d.occ.p[q.od] = occ;
-                    d.nts.p[q.od] = na;
-                    d.w0.p[q.ow] = NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx;
+                    if (!BOX) d.nts.p[q.od] = na;
+                    d.w0.p[q.ow] = BOX ? (NK_NEWBORN | (uint32_t)idx) : (NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx);
                     if (d.pid) d.pid.p[q.od] = pid;
                 } else atomicOr(d.overflow, 1);         // more entering particles than free slots
             }
@@ -562,10 +563,10 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
     }
 }
 
-template <int GEOM>
+template <int GEOM, bool BOX = false>
 __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
     extern __shared__ __align__(16) unsigned char smem[];
-    nk_emit_body<GEOM>(d, step, smem, (int)blockIdx.x, (int)gridDim.x);
+    nk_emit_body<GEOM, BOX>(d, step, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Output ring of a sweep wave: finished particles are staged in LDS and leave for HBM in whole, aligned tiles of 64 --
@@ -585,17 +586,19 @@ struct NkOut {
     }
     // the same in two halves (plain cursor only): the slots are taken now, the stores are issued later (the sweep's tile commit)
     __device__ __forceinline__ int reserve(int rank, int n) { const int o = wout + rank; wout += n; return o; }
+    template <bool BOX = false>
     __device__ __forceinline__ void store(const NkDev &d, int64_t base, bool put, int o, double px, double py, double pz, double pocc,
                                           double pnts, uint32_t pw0, unsigned long long ppid) {
         if (put) {
             if (o < d.segcap) {
                 const NkSlot q = nk_slot(d, base + o);
-                NK_ST(d.x.p + q.od, px); NK_ST(d.y.p + q.od, py); NK_ST(d.z.p + q.od, pz); NK_ST(d.occ.p + q.od, pocc); NK_ST(d.nts.p + q.od, pnts); NK_ST(d.w0.p + q.ow, pw0);
+                NK_ST(d.x.p + q.od, px); NK_ST(d.y.p + q.od, py); NK_ST(d.z.p + q.od, pz); NK_ST(d.occ.p + q.od, pocc); if (!BOX) NK_ST(d.nts.p + q.od, pnts); NK_ST(d.w0.p + q.ow, pw0);
                 if (PID) NK_ST(d.pid.p + q.od, ppid);
             } else atomicOr(d.overflow, 2);     // segment full
         }
     }
     // lanes with `put` append their particle (rank = position among them, n = how many); a full tile leaves at once
+    template <bool BOX = false>
     __device__ __forceinline__ void push(const NkDev &d, int64_t base, int lane, bool put, int rank, int n, double px, double py,
                                          double pz, double pocc, double pnts, uint32_t pw0, unsigned long long ppid) {
         if (!NK_OUT_RING) {                           // straight to the write cursor
@@ -603,7 +606,7 @@ struct NkOut {
                 const int o = wout + rank;
                 if (o < d.segcap) {
                     const NkSlot q = nk_slot(d, base + o);
-                    NK_ST(d.x.p + q.od, px); NK_ST(d.y.p + q.od, py); NK_ST(d.z.p + q.od, pz); NK_ST(d.occ.p + q.od, pocc); NK_ST(d.nts.p + q.od, pnts); NK_ST(d.w0.p + q.ow, pw0);
+                    NK_ST(d.x.p + q.od, px); NK_ST(d.y.p + q.od, py); NK_ST(d.z.p + q.od, pz); NK_ST(d.occ.p + q.od, pocc); if (!BOX) NK_ST(d.nts.p + q.od, pnts); NK_ST(d.w0.p + q.ow, pw0);
                     if (PID) NK_ST(d.pid.p + q.od, ppid);
                 } else atomicOr(d.overflow, 2);     // segment full
             }
@@ -687,8 +690,12 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 // FAST: the commonest configuration compiled without the general branches -- slice subvolumes, 'nearest' (1) or 'linear' (2)
 // particle temperatures, local reference temperature: the run-time switches become constants of a copy of the parameter
 // block (worth 2-3 % of the sweep: fewer instructions in every classification, interpolation and tally).
-template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC, int FAST = 0>
+// BOX (axis-aligned box meshes, NkDev::box): the store holds no cached next hit -- no nts field to stream, no facet bits; a
+// particle has an event when its end-of-step position lies beyond a wall it flies towards (nk_box_out), and the event pass
+// evaluates that hit itself (nk_box_first_hit) before it runs the event.  72 B moved per phonon-step instead of 88.
+template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC, int FAST = 0, bool BOX = false>
 __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
+    static_assert(!BOX || (GEOM == 1 && !SPLIT && !NK_PREFETCH2 && !NK_OUT_RING), "the box store goes with the fused sweep over LDS tables");
     extern __shared__ __align__(16) unsigned char smem[];
 #ifdef NK_STAMPS
     const unsigned long long st_entry_r = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
@@ -776,7 +783,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 return;
             }
             if (r + lane < count) {                       // (one tile ahead, the compiler's own counting: only what will be used)
-                b.w0 = NK_LD(d.w0.tile(i0, lane)); b.x = NK_LD(d.x.tile(i0, lane)); b.y = NK_LD(d.y.tile(i0, lane)); b.z = NK_LD(d.z.tile(i0, lane)); b.occ = NK_LD(d.occ.tile(i0, lane)); b.nts = NK_LD(d.nts.tile(i0, lane));
+                b.w0 = NK_LD(d.w0.tile(i0, lane)); b.x = NK_LD(d.x.tile(i0, lane)); b.y = NK_LD(d.y.tile(i0, lane)); b.z = NK_LD(d.z.tile(i0, lane)); b.occ = NK_LD(d.occ.tile(i0, lane));
+                if (!BOX) b.nts = NK_LD(d.nts.tile(i0, lane));
                 if (PID) b.pid = NK_LD(d.pid.tile(i0, lane));
             }
         };
@@ -830,7 +838,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
             }
             if (DEFER) {                                // the previous tile's finished particles leave now
                 asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(occ), "+v"(nts), "+v"(w0));   // behind the wait for this tile
-                O.store(d, base, sdone, so, sx, sy, sz, socc, snts, sw0, spid);
+                O.template store<BOX>(d, base, sdone, so, sx, sy, sz, socc, snts, sw0, spid);
                 sdone = false;
                 if (SPLIT && sev) {                     // ... and its event particles, for the queue
                     if (sq < d.segcap) {
@@ -863,7 +871,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 if (act && !newborn) {
                     if (do_relax) occ = nk_relax<RBF>(d, L, ra, rb, x, y, z, occ, sm, idx);
                     x += vx * d.dt; y += vy * d.dt; z += vz * d.dt;                 // drift, Population.py:793
-                    nts -= 1.0;                                                     // :795
+                    if (!BOX) nts -= 1.0;                                           // :795
                 }
 #ifdef NK_STAMPS
                 { const double fence_ = x + occ; asm volatile("" ::"v"(fence_)); }
@@ -871,14 +879,16 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 NK_STAMP(1);
             }
             // ---- commit: final particles -> tally + compacted store; boundary particles -> the carry
-            const bool ev = act && nts < 0.0;
+            // (box store: the reference's "n_timesteps < 0" read off the position; a particle whose last cast missed -- the
+            // reference's n_timesteps = inf -- never has an event)
+            const bool ev = BOX ? (act && (w0 & NK_LOST) == 0u && nk_box_out(d, x, y, z, vx, vy, vz)) : (act && nts < 0.0);
             const bool done = act && !ev;
             const unsigned long long mD = __ballot(done), mE = __ballot(ev);
             if (done) nk_tally_one(d, L.tb, L.bins, x, y, z, occ, omega, E0, vx, vy, vz, do_flux, rep);
             if (DEFER) {
                 so = O.reserve(nk_rank(mD), __popcll(mD));
                 sdone = done; sx = x; sy = y; sz = z; socc = occ; snts = nts; sw0 = w0; spid = pid;
-            } else O.push(d, base, lane, done, nk_rank(mD), __popcll(mD), x, y, z, occ, nts, w0, pid);
+            } else O.template push<BOX>(d, base, lane, done, nk_rank(mD), __popcll(mD), x, y, z, occ, nts, w0, pid);
             NK_STAMP(2);
             if (SPLIT) {                               // the tile's event particles leave for the queue; k_events takes over
                 if (DEFER) { sev = ev; sq = qn + nk_rank(mE); }     // (a particle is final or has an event: the same held values)
@@ -948,6 +958,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                     p.slot = (int)cslot;
                 }
                 p.facet = (int)(cw0 >> d.lb) - 1;
+                // box store: a particle's FIRST event of the step is the wall it lies beyond (the carry holds no hit for it yet)
+                if (BOX && eact && evc == 0u) nk_box_first_hit(d, p.x, p.y, p.z, p.vx, p.vy, p.vz, p.nts, p.facet);
                 if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, cpid, step);
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
 #ifdef NK_STAMPS
@@ -963,10 +975,11 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                     if (d.part) { const uint32_t hi = (uint32_t)p.slot / (uint32_t)d.nseg; hseg = (int)((uint32_t)p.slot - hi * (uint32_t)d.nseg); stay = hseg == seg; idxe = hi; }
                     else idxe = (uint32_t)p.mode;
                 }
-                const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
+                const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;       // (the carry's own format, also in a box store)
+                const uint32_t w0s = BOX ? (idxe | (p.facet < 0 ? NK_LOST : 0u)) : w0e;  // what the store keeps
                 const bool home = alive && stay, away = alive && !stay;
                 const unsigned long long mA = __ballot(home), mM = __ballot(more);
-                O.push(d, base, lane, home, nk_rank(mA), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0e, cpid);
+                O.template push<BOX>(d, base, lane, home, nk_rank(mA), __popcll(mA), p.x, p.y, p.z, p.occ, p.nts, w0s, cpid);
                 if (ROUGH && away) {                       // one 64-byte record into the inbox of the segment that owns the new mode
                     const int dst = hseg;
                     const int at = atomicAdd(d.mig_n + dst, 1);
@@ -974,7 +987,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                         double2 *r = d.mig_buf + ((int64_t)dst * d.mig_cap + at) * 4;
                         r[0] = make_double2(p.x, p.y); r[1] = make_double2(p.z, p.occ);
                         r[2] = make_double2(p.nts, __longlong_as_double((long long)cpid));
-                        r[3] = make_double2(__longlong_as_double((long long)w0e), 0.0);
+                        r[3] = make_double2(__longlong_as_double((long long)w0s), 0.0);
                     } else atomicOr(d.overflow, 32);      // inbox full: the particle is lost (k_deliver asks for larger inboxes long before)
                 }
                 cn = __popcll(mM);
@@ -1289,7 +1302,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
         for (int j = lane; j < n; j += 64) {
             const double2 *r = d.mig_buf + ((int64_t)seg * d.mig_cap + j) * 4;
             const double2 a = r[0], b = r[1], c = r[2], e = r[3];
-            d.x[base + j] = a.x; d.y[base + j] = a.y; d.z[base + j] = b.x; d.occ[base + j] = b.y; d.nts[base + j] = c.x;
+            d.x[base + j] = a.x; d.y[base + j] = a.y; d.z[base + j] = b.x; d.occ[base + j] = b.y; if (d.nts) d.nts[base + j] = c.x;
             d.pid[base + j] = (uint64_t)__double_as_longlong(c.y);
             d.w0[base + j] = (uint32_t)__double_as_longlong(e.x);
         }
@@ -1429,7 +1442,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int
 // step that will then NOT run is under way: harmless, its counters are double-buffered (NkDev::rc_len) and it is simply run
 // again once the store has grown.  Not with rough facets (k_deliver, after the update, moves the segments' ends) nor
 // 'one_to_one' (emits what the update says left).
-template <int GEOM>
+template <int GEOM, bool BOX = false>
 __global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int rows, double *acc, double *hist_row, int do_flux, int fuse,
                                                 int n_reduce) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -1438,7 +1451,7 @@ __global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int
         int &last = *reinterpret_cast<int *>(smem + NK_WG * sizeof(double));
         nk_reduce_body(d, rows, acc, hist_row, do_flux, fuse, (int)blockIdx.x, n_reduce, sh, last);
     } else {
-        nk_emit_body<GEOM>(d, step_next, smem, (int)blockIdx.x - n_reduce, (int)gridDim.x - n_reduce);
+        nk_emit_body<GEOM, BOX>(d, step_next, smem, (int)blockIdx.x - n_reduce, (int)gridDim.x - n_reduce);
     }
 }
 
@@ -1470,8 +1483,11 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d, int 
 }
 
 // timesteps_to_boundary for every particle (Population.py:310-314)
+// Box store: nothing to cache but the "lost" mark of a particle whose cast misses.  What the store cannot express -- a
+// particle that starts outside the box and would meet a wall from behind -- is counted in *anomalies; the host then goes back
+// to the cached layout for this context (nk_init_boundaries).
 template <int GEOM>
-__global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
+__global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d, int32_t *anomalies) {
     extern __shared__ __align__(16) unsigned char smem[];
     NkLds L;
     nk_lds_setup<GEOM, 0>(d, smem, L);
@@ -1485,9 +1501,53 @@ __global__ __launch_bounds__(NK_WG) void k_init_boundaries(NkDev d) {
             const uint32_t idx = d.w0[i] & lbmask;
             const NkMode *rec = sm.rec + idx;
             double tc; int fc;
-            NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, d.x[i], d.y[i], d.z[i], rec->vx, rec->vy, rec->vz, tc, fc);
-            d.nts[i] = tc / d.dt;
-            d.w0[i] = ((uint32_t)(fc + 1) << d.lb) | idx;
+            const double x = d.x[i], y = d.y[i], z = d.z[i];
+            NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
+            if (d.box) {
+                const bool inside = x >= d.box_k[0] && x <= -d.box_k[1] && y >= d.box_k[2] && y <= -d.box_k[3] && z >= d.box_k[4] && z <= -d.box_k[5];
+                if (!inside && fc >= 0) atomicAdd(anomalies, 1);
+                d.w0[i] = (fc < 0 ? NK_LOST : 0u) | idx;
+            } else {
+                d.nts[i] = tc / d.dt;
+                d.w0[i] = ((uint32_t)(fc + 1) << d.lb) | idx;
+            }
+        }
+    }
+}
+// The next boundary hit of every live particle where it stands, in slot order: what the reference keeps in n_timesteps /
+// collision_facets (Population.py:797-830), for the callers that ask for it when the store does not hold it (box store:
+// nk_download_particles, re-dealing).  A particle marked lost reports (inf, -1).  A particle behind a wall it flies towards
+// from outside (negative entry time, SURVEY quirk list) is cast from where it enters, as the reference cast it from its
+// reservoir face, and the flight up to there is added.
+template <int GEOM>
+__global__ __launch_bounds__(NK_WG) void k_next_hit(NkDev d, double *nts_out, int32_t *facet_out) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    NkLds L;
+    nk_lds_setup<GEOM, 0>(d, smem, L);
+    const uint32_t lbmask = (1u << d.lb) - 1u;
+    for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
+        const int64_t base = (int64_t)seg * d.segcap;
+        const int count = d.seg_count[seg];
+        const NkSegModes sm = nk_seg_modes(d, seg);
+        for (int k = threadIdx.x; k < count; k += NK_WG) {
+            const int64_t i = base + k;
+            const uint32_t w0 = d.w0[i];
+            if (w0 & NK_LOST) { nts_out[i] = __builtin_inf(); facet_out[i] = -1; continue; }
+            const NkMode *rec = sm.rec + (w0 & lbmask);
+            double x = d.x[i], y = d.y[i], z = d.z[i];
+            const double vx = rec->vx, vy = rec->vy, vz = rec->vz;
+            double tin = 0.0;
+            if (vx > 0.0 && x < d.box_k[0]) tin = fmax(tin, (d.box_k[0] - x) / vx);
+            if (vx < 0.0 && x > -d.box_k[1]) tin = fmax(tin, (-d.box_k[1] - x) / vx);
+            if (vy > 0.0 && y < d.box_k[2]) tin = fmax(tin, (d.box_k[2] - y) / vy);
+            if (vy < 0.0 && y > -d.box_k[3]) tin = fmax(tin, (-d.box_k[3] - y) / vy);
+            if (vz > 0.0 && z < d.box_k[4]) tin = fmax(tin, (d.box_k[4] - z) / vz);
+            if (vz < 0.0 && z > -d.box_k[5]) tin = fmax(tin, (-d.box_k[5] - z) / vz);
+            if (tin > 0.0) { x += vx * tin; y += vy * tin; z += vz * tin; }
+            double tc; int fc;
+            NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, x, y, z, vx, vy, vz, tc, fc);
+            nts_out[i] = (tc + tin) / d.dt;
+            facet_out[i] = fc;
         }
     }
 }
@@ -1594,7 +1654,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_init_particles(NkDe
         const int slot = atomicAdd(d.seg_count + seg, 1);
         if (slot < d.segcap) {
             const int64_t o = (int64_t)seg * d.segcap + slot;
-            d.x[o] = x; d.y[o] = y; d.z[o] = z; d.occ[o] = occ; d.nts[o] = 0.0; d.w0[o] = (uint32_t)idx;
+            d.x[o] = x; d.y[o] = y; d.z[o] = z; d.occ[o] = occ; if (d.nts) d.nts[o] = 0.0; d.w0[o] = (uint32_t)idx;
             if (d.pid) d.pid[o] = pid;
         } else atomicOr(d.overflow, 2);
     }
@@ -1653,8 +1713,9 @@ __global__ __launch_bounds__(NK_WG) void k_contains(NkDev d, uint32_t step) {
             const NkMode *rec = sm.rec + idx;
             double tc; int fc;
             NK_RAY(GEOM, d, L, NK_TREE_NO_SKIP, x, y, z, rec->vx, rec->vy, rec->vz, tc, fc);
-            d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = tc / d.dt;
-            d.w0[i] = ((uint32_t)(fc + 1) << d.lb) | idx;
+            d.x[i] = x; d.y[i] = y; d.z[i] = z;
+            if (d.box) d.w0[i] = (fc < 0 ? NK_LOST : 0u) | idx;
+            else { d.nts[i] = tc / d.dt; d.w0[i] = ((uint32_t)(fc + 1) << d.lb) | idx; }
         }
     }
 }

@@ -40,7 +40,7 @@ def build(cfg, total, comm=None):
     return pop, geo, ph
 
 
-@pytest.mark.parametrize('cfg,total', [('c2', 10000000), ('c5', 12500000)])
+@pytest.mark.parametrize('cfg,total', [('c2', 10000000), ('c3', 10000000), ('c5', 12500000)])
 def test_full_size_properties(cfg, total, monkeypatch):
     nsteps = 12
     pop, geo, ph = build(cfg, total)

@@ -244,3 +244,65 @@ def test_mesh_crossings_on_the_device_equal_the_host_count(monkeypatch):
     monkeypatch.setattr(M, '_DEVICE_HELPER', False)
     ref = wire_mesh()
     assert np.array_equal(ref.faces, mesh.faces) and np.array_equal(ref.simplices, mesh.simplices) and ref.volume == mesh.volume
+
+
+@pytest.mark.gpu
+def test_engine_from_a_file_loaded_material_vs_oracle_on_reference_tables(tmp_path, monkeypatch):
+    """SURVEY 8 row f2 on the GPU: `Phonon(args)` reads the phono3py datasets of tests/golden/kappa-m999.hdf5 (their .npz
+    twin: h5py is not installed for the system interpreter) + POSCAR through THIS package's IBZ -> FBZ loader (reference
+    Phonon.load_base_properties Phonon.py:66-149, expand_FBZ :515-564) -> `Population` -> 25 steps of the engine; the oracle
+    runs the same ensemble on the tables the REFERENCE's loader produced from the same file (tests/golden/fbz.npz, written by
+    tests/golden/make_fbz.py).  Particle by particle (as multisets: this configuration stores no ids)."""
+    import shutil
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    sys.path.insert(0, golden_dir)
+    import make_hdf5_material_data as M
+    import ref_harness_args as A
+    from util import golden
+    from nanokappa_amd import crystal, setup_tables as ST
+    from nanokappa_amd.argument_parser import initialise_parser
+    from nanokappa_amd.geometry import Geometry
+    from nanokappa_amd.phonon import Phonon
+    from nanokappa_amd.population import Population
+    np.savez(tmp_path / 'kappa.npz', **M.datasets())
+    shutil.copy(os.path.join(golden_dir, 'POSCAR_Si'), tmp_path / 'POSCAR')
+    monkeypatch.setenv('NK_HOST_INIT', '1')                  # particles made on the host and uploaded: the oracle gets the same ones
+    argv = A.argv_for('ttp', 30000)
+    argv[argv.index('--hdf_file') + 1] = 'kappa.npz'
+    i = argv.index('--bound_values')
+    argv[i + 1:i + 3] = ['305', '295']                       # the file's temperature grid is 250 / 300 / 350 K
+    args = initialise_parser().parse_args(argv + ['--mat_folder', str(tmp_path), '--seed', '17', '--isotope_scat', '0'])
+    args.results_folder = ''
+    geo = Geometry(args)
+    ph = Phonon(args, 0)                                     # the loader: irreducible wedge -> full zone
+    assert ph.omega.shape == (729, 6)
+    pop = Population(args, geo, ph)
+    eng = pop.engine
+    p0 = eng.download()
+    assert p0['mode'].shape[0] == 30000 and not p0['pid'].any()
+    # ---- the oracle on the REFERENCE's expansion of the same file
+    g = golden('fbz')
+    cell = crystal.read_poscar(os.path.join(golden_dir, 'POSCAR_Si'))
+    rec = np.around(np.linalg.inv(cell['lattice']) * 2 * np.pi, decimals=6)
+    gam = np.where(g['gamma_with_isotope'] > 0, g['gamma_with_isotope'], -1)
+    ph_ref = Phonon(None, 0, material=dict(data_mesh=g['data_mesh'], q_points=g['q_points'], omega=g['omega'], frequency=g['frequency'],
+                                           group_vel=g['group_vel'], temperature=g['temperature'], gamma=gam,
+                                           reciprocal_lattice=rec, volume_unitcell=abs(np.linalg.det(cell['lattice']))))
+    Q, J = ph_ref.omega.shape
+    Mm = Q * J
+    density = 30000 / geo.volume
+    ct = dict(ph=ph_ref, J=J, M=Mm, mesh=geo.tables(), tables=ph_ref.tables(), centers=geo.subvol_center, volumes=geo.subvol_volume,
+              axis=geo.slice_axis, kind=0, res_facets=geo.res_facets, res_T=np.asarray(geo.res_values, dtype=float),
+              enter_prob=ST.enter_probability(geo, ph_ref, geo.res_facets, density, 1.0).reshape(-1, Mm),
+              particle_density=density, rough=None)
+    assert rel_err(pop.enter_prob.reshape(-1, Mm), ct['enter_prob']) < 1e-12
+    sim = make_oracle_sim(ct, p0['positions'], p0['mode'], p0['occupation'], pop.res_counter.reshape(-1, Mm), seed=17,
+                          T0=float(pop.subvol_temperature[0]), ids_from_state=True)
+    assert np.all(pop.subvol_temperature == pop.subvol_temperature[0])
+    t = eng.step(25)
+    for s in range(25):
+        sim.run_timestep()
+        assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
+        assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+    assert t['N_emitted'].sum() > 0 and t['N_leaving'].sum() > 0
+    compare_by_state(eng.download(), sim)
