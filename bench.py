@@ -90,7 +90,7 @@ def _oracle_run(geo, ph, n, seed, seconds_target, max_steps, start=None, rough=N
     occ = ph.calculate_occupation(298.0, ph.omega.ravel()[mode])
     store = O.ParticleStore(int(1.3 * n) + 4096)
     store.load(pos, mode, occ)
-    sim = O.OracleSim(mat, mesh, sv, res, rgh, par, store, np.full(geo.n_of_subvols, 298.0))
+    sim = O.OracleSim(mat, mesh, sv, res, rgh, par, store, np.full(geo.n_of_subvols, 298.0), box='auto')   # the engine's event rule
     sim.init_boundaries()
     sim.run_timestep()                       # warm-up step
     if start is not None:

@@ -168,6 +168,8 @@ typedef struct {
                               * timed): where a store lies in memory decides between two speeds of the sweep, 15 % apart */
     double place_gbps;       /* GB/s of an in-place copy pass over the store that was kept ... */
     double place_worst_gbps; /* ... and over the slowest candidate */
+    int64_t box_store;       /* 1: the particle store holds no cached next hit (axis-aligned box meshes: the hit is read off the
+                                position, the reference's expression of Mesh.py:818 at event time); 36 B per particle, else 44 */
 } nk_timing;
 
 /* lifetime: `Population.__init__` / end of run */

@@ -636,23 +636,27 @@ __device__ __forceinline__ bool nk_box_out(const NkDev &d, double x, double y, d
 // v.n = +-v_a exactly), the earliest wins, the lowest face index among equals (:846-848).  What the reference holds in
 // n_timesteps / collision_facets at this point is the same hit, cast from where the particle's free flight began and
 // decremented once per step (Population.py:795): equal up to the rounding of the drift.
+// one axis of nk_box_first_hit: the wall with normal -e_a (constants klo, ...) or +e_a (khi, ...)
+__device__ __forceinline__ void nk_box_axis(double xa, double va, double klo, double khi, int flo, int fhi, int f0lo, int f0hi,
+                                            double &tb, int &fb, int &f0b) {
+#pragma clang fp contract(off)
+    double num, den;
+    int f, f0;
+    if (va > 0.0 && xa > -khi) { num = xa + khi; den = va; f = fhi; f0 = f0hi; }
+    else if (va < 0.0 && xa < klo) { num = -xa + klo; den = -va; f = flo; f0 = f0lo; }
+    else return;
+    const double t = -num / den;
+    if (t < tb || (t == tb && f0 < f0b)) { tb = t; fb = f; f0b = f0; }
+}
 __device__ __forceinline__ void nk_box_first_hit(const NkDev &d, double x, double y, double z, double vx, double vy, double vz,
                                                  double &nts, int &facet) {
-#pragma clang fp contract(off)
+    // (the walls' constants by constant index: a loop over the axes makes the compiler keep the whole parameter block in
+    // scratch memory)
     double tb = __builtin_inf();
     int fb = -1, f0b = 0x7fffffff;
-    const double xs[3] = {x, y, z}, vs[3] = {vx, vy, vz};
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-        const double xa = xs[a], va = vs[a];
-        double num, den;
-        int w;
-        if (va > 0.0 && xa > -d.box_k[2 * a + 1]) { num = xa + d.box_k[2 * a + 1]; den = va; w = 2 * a + 1; }
-        else if (va < 0.0 && xa < d.box_k[2 * a]) { num = -xa + d.box_k[2 * a]; den = -va; w = 2 * a; }
-        else continue;
-        const double t = -num / den;
-        if (t < tb || (t == tb && d.box_face0[w] < f0b)) { tb = t; fb = d.box_facet[w]; f0b = d.box_face0[w]; }
-    }
+    nk_box_axis(x, vx, d.box_k[0], d.box_k[1], d.box_facet[0], d.box_facet[1], d.box_face0[0], d.box_face0[1], tb, fb, f0b);
+    nk_box_axis(y, vy, d.box_k[2], d.box_k[3], d.box_facet[2], d.box_facet[3], d.box_face0[2], d.box_face0[3], tb, fb, f0b);
+    nk_box_axis(z, vz, d.box_k[4], d.box_k[5], d.box_facet[4], d.box_facet[5], d.box_face0[4], d.box_face0[5], tb, fb, f0b);
     nts = tb / d.dt;
     facet = fb;
 }

@@ -24,6 +24,10 @@ extern template __global__ void k_sweep<1, false, false, false, false, true, 1>(
 extern template __global__ void k_sweep<1, false, false, false, false, true, 2>(NkDev, uint32_t, int, int);
 extern template __global__ void k_sweep<1, false, false, false, false, false, 1>(NkDev, uint32_t, int, int);
 extern template __global__ void k_sweep<1, false, false, false, false, false, 2>(NkDev, uint32_t, int, int);
+extern template __global__ void k_sweep<1, false, false, false, false, true, 1, true>(NkDev, uint32_t, int, int);
+extern template __global__ void k_sweep<1, false, false, false, false, true, 2, true>(NkDev, uint32_t, int, int);
+extern template __global__ void k_sweep<1, false, false, false, false, false, 1, true>(NkDev, uint32_t, int, int);
+extern template __global__ void k_sweep<1, false, false, false, false, false, 2, true>(NkDev, uint32_t, int, int);
 #endif
 
 struct NkRccl {      // symbols resolved lazily with dlopen: a single-GPU run never loads librccl
@@ -48,6 +52,10 @@ struct nk_ctx {
     void *store_buf = nullptr;     // the one among them that holds the particle fields (nk_alloc_fields)
     size_t store_pad = 0;
     bool store_pid = false;
+    bool store_nts = true;         // false: box store (no cached next hit, NkDev::box)
+    bool mesh_box = false;         // nk_set_mesh: the mesh is an axis-aligned box whose six sides are its six facets
+    bool box_forbidden = false;    // this context met particles a box store cannot express (nk_init_boundaries): cached layout from then on
+    int32_t *anomalies = nullptr;  // device word of k_init_boundaries
     bool have_material = false, have_mesh = false, have_sv = false, have_params = false;
     int64_t step = 0;
     bool pending_relax = false;
@@ -142,37 +150,45 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
 // x | y | z | occ | nts | [pid] | w0 (NkField, nk_device.h).  NK_LAYOUT=soa (developer comparison): one plain array per
 // field, as in round 2.  The allocation is registered in ctx->pallocs.
 static inline bool nk_layout_soa() { return getenv("NK_LAYOUT") && !strcmp(getenv("NK_LAYOUT"), "soa"); }
-static inline size_t nk_store_bytes(int64_t cap, bool with_pid) {
+// bytes of one particle in the store: x y z occ (+ nts unless it is a box store) (+ pid) + the packed word
+static inline int nk_particle_bytes(bool with_pid, bool with_nts) { return 36 + (with_nts ? 8 : 0) + (with_pid ? 8 : 0); }
+static inline size_t nk_store_bytes(int64_t cap, bool with_pid, bool with_nts) {
     const int64_t nblk = (cap + 63) / 64;
-    const int bd = with_pid ? 6 * 64 + 32 : 5 * 64 + 32;          // doubles per block (the 64 packed words take 32)
-    const size_t bytes = nk_layout_soa() ? (size_t)nblk * 64 * (with_pid ? 52 : 44) : (size_t)nblk * bd * 8;
+    const int nf = 4 + (with_nts ? 1 : 0) + (with_pid ? 1 : 0);   // 8-byte fields per particle
+    const int bd = nf * 64 + 32;                                  // doubles per block (the 64 packed words take 32)
+    const size_t bytes = nk_layout_soa() ? (size_t)nblk * 64 * (nf * 8 + 4) : (size_t)nblk * bd * 8;
     return bytes ? bytes : 64;
 }
 // the fields of a store of `cap` slots that starts at b
-static void nk_point_fields(NkDev &d, double *b, int64_t cap, bool with_pid) {
+static void nk_point_fields(NkDev &d, double *b, int64_t cap, bool with_pid, bool with_nts) {
     const int64_t nblk = (cap + 63) / 64;
-    const int bd = with_pid ? 6 * 64 + 32 : 5 * 64 + 32;
+    const int nf = 4 + (with_nts ? 1 : 0) + (with_pid ? 1 : 0);
+    const int bd = nf * 64 + 32;
     if (nk_layout_soa()) {
         const int64_t n = nblk * 64;
-        d.x = {b, 64}; d.y = {b + n, 64}; d.z = {b + 2 * n, 64}; d.occ = {b + 3 * n, 64}; d.nts = {b + 4 * n, 64};
-        d.pid = {with_pid ? (uint64_t *)(b + 5 * n) : nullptr, 64};
-        d.w0 = {(uint32_t *)(b + (with_pid ? 6 : 5) * n), 64};
+        int k = 4;
+        d.x = {b, 64}; d.y = {b + n, 64}; d.z = {b + 2 * n, 64}; d.occ = {b + 3 * n, 64};
+        d.nts = {with_nts ? b + (k++) * n : nullptr, 64};
+        d.pid = {with_pid ? (uint64_t *)(b + (k++) * n) : nullptr, 64};
+        d.w0 = {(uint32_t *)(b + k * n), 64};
     } else {
-        d.x = {b, bd}; d.y = {b + 64, bd}; d.z = {b + 128, bd}; d.occ = {b + 192, bd}; d.nts = {b + 256, bd};
-        d.pid = {with_pid ? (uint64_t *)(b + 320) : nullptr, bd};
-        d.w0 = {(uint32_t *)(b + (with_pid ? 384 : 320)), 2 * bd};
+        int k = 4;
+        d.x = {b, bd}; d.y = {b + 64, bd}; d.z = {b + 128, bd}; d.occ = {b + 192, bd};
+        d.nts = {with_nts ? b + 64 * (k++) : nullptr, bd};
+        d.pid = {with_pid ? (uint64_t *)(b + 64 * (k++)) : nullptr, bd};
+        d.w0 = {(uint32_t *)(b + 64 * k), 2 * bd};
     }
 }
-static int nk_alloc_fields(nk_ctx *ctx, NkDev &d, int64_t cap, bool with_pid) {
-    const size_t bytes = nk_store_bytes(cap, with_pid);
+static int nk_alloc_fields(nk_ctx *ctx, NkDev &d, int64_t cap, bool with_pid, bool with_nts) {
+    const size_t bytes = nk_store_bytes(cap, with_pid, with_nts);
     void *buf = nullptr;
     // developer probe (scripts/placement_probe.py): NK_STORE_PAD_KB shifts the store inside a larger allocation
     const size_t pad = getenv("NK_STORE_PAD_KB") ? (size_t)atol(getenv("NK_STORE_PAD_KB")) * 1024 : 0;
     NK_HIP(hipMalloc(&buf, bytes + pad));
     ctx->pallocs.push_back(buf);
     NK_HIP(hipMemsetAsync(buf, 0, bytes + pad, ctx->stream));
-    ctx->store_buf = buf; ctx->store_pad = pad; ctx->store_pid = with_pid;
-    nk_point_fields(d, (double *)((char *)buf + pad), cap, with_pid);
+    ctx->store_buf = buf; ctx->store_pad = pad; ctx->store_pid = with_pid; ctx->store_nts = with_nts;
+    nk_point_fields(d, (double *)((char *)buf + pad), cap, with_pid, with_nts);
     return NK_OK;
 }
 // Host copy of a whole field (slot order) and back.
@@ -207,6 +223,13 @@ static inline size_t nk_lds(const nk_ctx *ctx, bool geom, int kind = 0) {
         if (nk_geom_mode(ctx) == 1) kernel<1><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);         \
         else kernel<2><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);                                \
     } while (0)
+// k_emit / k_tail: the same, plus the box store's variant (no first ray cast)
+#define NK_EMIT_LAUNCH(kernel, grid, lds, ...)                                                        \
+    do {                                                                                               \
+        if (ctx->d.box) kernel<1, true><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);               \
+        else if (nk_geom_mode(ctx) == 1) kernel<1, false><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);   \
+        else kernel<2, false><<<grid, NK_WG, lds, ctx->stream>>>(__VA_ARGS__);                         \
+    } while (0)
 static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
 // The sweep is instantiated per (table placement, rough facets, RBF temperatures, particle ids, split): run STMT with
 // KERNEL bound to the one that matches.  Rough facets draw random numbers per particle, so they imply ids.  The last
@@ -219,9 +242,21 @@ static inline int nk_sweep_grid(const nk_ctx *ctx) { return ctx->num_cu * 8; }
 #define NK_SWEEP_CASE_S(G, R, B, P, split, lrec, STMT) { if (split) NK_SWEEP_CASE(G, R, B, P, true, lrec, STMT) else NK_SWEEP_CASE(G, R, B, P, false, lrec, STMT) }
 #define NK_SWEEP_CASE_RP(G, B, rough, pid, split, lrec, STMT)                                         \
     { if (rough) NK_SWEEP_CASE_S(G, true, B, true, split, lrec, STMT) else if (pid) NK_SWEEP_CASE_S(G, false, B, true, split, lrec, STMT) else NK_SWEEP_CASE_S(G, false, B, false, split, lrec, STMT) }
+// ... and every sweep of a small mesh exists for the box store (k_sweep's BOX; ctx->d.box decides)
+#define NK_SWEEP_CASE_BOX(R, B, P, lrec, STMT) { if (lrec) { auto KERNEL = k_sweep<1, R, B, P, false, true, 0, true>; STMT; } else { auto KERNEL = k_sweep<1, R, B, P, false, false, 0, true>; STMT; } }
+#define NK_SWEEP_CASE_BOX_RP(B, rough, pid, lrec, STMT)                                               \
+    { if (rough) NK_SWEEP_CASE_BOX(true, B, true, lrec, STMT) else if (pid) NK_SWEEP_CASE_BOX(false, B, true, lrec, STMT) else NK_SWEEP_CASE_BOX(false, B, false, lrec, STMT) }
+#define NK_SWEEP_CASE_FAST_BOX(lrec, fast, STMT)                                                                               \
+    { if (lrec) { if ((fast) == 1) { auto KERNEL = k_sweep<1, false, false, false, false, true, 1, true>; STMT; } else { auto KERNEL = k_sweep<1, false, false, false, false, true, 2, true>; STMT; } } \
+      else { if ((fast) == 1) { auto KERNEL = k_sweep<1, false, false, false, false, false, 1, true>; STMT; } else { auto KERNEL = k_sweep<1, false, false, false, false, false, 2, true>; STMT; } } }
 #define NK_SWEEP_DISPATCH(gm, rough, rbf, pid, split, lrec, STMT)                                     \
     do {                                                                                               \
         const int fast_ = ((gm) == 1 && !(rough) && !(rbf) && !(pid) && !(split)) ? nk_sweep_fast(ctx) : 0;   \
+        if (ctx->d.box && (gm) == 1 && !(split)) {                                                     \
+            if (fast_) { NK_SWEEP_CASE_FAST_BOX(lrec, fast_, STMT) break; }                            \
+            if (rbf) NK_SWEEP_CASE_BOX_RP(true, rough, pid, lrec, STMT) else NK_SWEEP_CASE_BOX_RP(false, rough, pid, lrec, STMT)   \
+            break;                                                                                     \
+        }                                                                                              \
         if (fast_) { NK_SWEEP_CASE_FAST(lrec, fast_, STMT) break; }                                    \
         if ((gm) == 1) { if (rbf) NK_SWEEP_CASE_RP(1, true, rough, pid, split, lrec, STMT) else NK_SWEEP_CASE_RP(1, false, rough, pid, split, lrec, STMT) }   \
         else { if (rbf) NK_SWEEP_CASE_RP(2, true, rough, pid, split, lrec, STMT) else NK_SWEEP_CASE_RP(2, false, rough, pid, split, lrec, STMT) }             \
@@ -356,6 +391,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.overflow = (int32_t *)p32 + 4;
     ctx->d.ticket = (int32_t *)p32 + 5;
     ctx->d.ev_ticket = (int32_t *)p32 + 6;
+    ctx->anomalies = (int32_t *)p32 + 7;
     *out = ctx;
     return NK_OK;
 }
@@ -750,8 +786,65 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         for (int s = 0; s < m->nS; ++s) sc[s] /= sc[m->nS - 1];
         NK_UP(sc.data(), sc.size(), &d.simplex_cdf);
     }
+    // Box store (nk_device.h, NkDev::box): six planes with exact unit axis normals, one facet each, whose faces are the whole
+    // side of the bounding box (two triangles over its four corners).  Then "which wall does a particle meet next, and when"
+    // follows from its position alone, with the reference's own expression (nk_box_first_hit), and need not be stored.
+    ctx->mesh_box = false;
+    if (d.cap == 0) d.box = 0;                       // (an existing store keeps its layout until nk_check_ready re-deals it)
+    if (m->F == 12 && m->Fc == 6 && d.NP == 6) {
+        bool ok = true;
+        int seen = 0;
+        for (int pl = 0; pl < 6 && ok; ++pl) {
+            const double *pn = &planes[(size_t)pl * NK_PLANE_DOUBLES];
+            int a = -1, sgn = 0;
+            for (int k = 0; k < 3; ++k) {
+                if (pn[k] == 1.0 || pn[k] == -1.0) { if (a >= 0) ok = false; a = k; sgn = pn[k] > 0 ? 1 : 0; }
+                else if (pn[k] != 0.0) ok = false;
+            }
+            if (!ok || a < 0) { ok = false; break; }
+            const int w = 2 * a + sgn;
+            if (seen & (1 << w)) { ok = false; break; }
+            seen |= 1 << w;
+            const double wall = sgn ? -pn[3] : pn[3];              // n.x + k = 0  ->  x_a = -k (normal +e_a) or k (-e_a)
+            if (!(fabs(wall - m->bbox[(sgn ? 3 : 0) + a]) <= 1e-9 * (1.0 + fabs(wall)))) { ok = false; break; }
+            if (members[pl].size() != 2) { ok = false; break; }
+            int fct0 = -1, face0 = 0x7fffffff;
+            double area = 0.0;
+            for (int f : members[pl]) {
+                if (fct0 < 0) fct0 = m->face_facet[f]; else if (m->face_facet[f] != fct0) ok = false;
+                face0 = std::min(face0, f);
+                area += m->face_area[f];
+                const double *V = m->vertices + 9 * (size_t)f;
+                for (int c = 0; c < 3 && ok; ++c)
+                    for (int k = 0; k < 3; ++k) {
+                        const double v = V[3 * c + k], lo = m->bbox[k], hi = m->bbox[3 + k];
+                        const double e = 1e-9 * (1.0 + fabs(lo) + fabs(hi));
+                        if (k == a) { if (fabs(v - wall) > e) ok = false; }
+                        else if (fabs(v - lo) > e && fabs(v - hi) > e) ok = false;      // a corner of the side
+                    }
+            }
+            const int b = (a + 1) % 3, c = (a + 2) % 3;
+            const double side = (m->bbox[3 + b] - m->bbox[b]) * (m->bbox[3 + c] - m->bbox[c]);
+            if (!(fabs(area - side) <= 1e-9 * side) || fct0 < 0 || fct0 >= m->Fc) ok = false;
+            if (!ok) break;
+            d.box_k[w] = pn[3]; d.box_facet[w] = fct0; d.box_face0[w] = face0;
+        }
+        if (ok && seen == 63) {
+            // one facet per wall
+            int fm = 0;
+            for (int w = 0; w < 6; ++w) fm |= 1 << d.box_facet[w];
+            ctx->mesh_box = fm == 63;
+        }
+    }
     ctx->have_mesh = true;
     return NK_OK;
+}
+
+// The box store is used when the mesh allows it, the tables sit in LDS, and nothing in this context spoke against it
+// (NK_NO_BOX=1: developer switch / tests of the cached layout on boxes).
+static inline bool nk_want_box(const nk_ctx *ctx) {
+    return ctx->have_mesh && ctx->mesh_box && !ctx->box_forbidden && !getenv("NK_NO_BOX") && !getenv("NK_SPLIT") && !nk_layout_soa() &&
+           ctx->d.F <= NK_LDS_FACES && ctx->d.Fc <= NK_LDS_FACES;
 }
 
 static int nk_patch_facets(nk_ctx *ctx) {
@@ -1025,7 +1118,25 @@ static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
     if ((rc = nk_field_download(ctx, d, d.y, bd))) return rc; keep(bd, h.y.data());
     if ((rc = nk_field_download(ctx, d, d.z, bd))) return rc; keep(bd, h.z.data());
     if ((rc = nk_field_download(ctx, d, d.occ, bd))) return rc; keep(bd, h.occ.data());
-    if ((rc = nk_field_download(ctx, d, d.nts, bd))) return rc; keep(bd, h.nts.data());
+    std::vector<int32_t> bfc;
+    if (d.nts) { if ((rc = nk_field_download(ctx, d, d.nts, bd))) return rc; keep(bd, h.nts.data()); }
+    else {
+        // box store: the next hit is not kept -- cast it where the particles stand (k_next_hit; needs the tables)
+        if (ctx->have_material && ctx->have_mesh && ctx->have_sv && d.modetab) {
+            double *dn = nullptr; int32_t *df = nullptr;
+            NK_HIP(hipMalloc((void **)&dn, (size_t)d.cap * 8));
+            if (hipMalloc((void **)&df, (size_t)d.cap * 4) != hipSuccess) { hipFree(dn); ctx->err = "nk_gather_live: out of memory"; return NK_ERR_HIP; }
+            hipMemsetAsync(dn, 0, (size_t)d.cap * 8, ctx->stream); hipMemsetAsync(df, 0xff, (size_t)d.cap * 4, ctx->stream);
+            k_next_hit<1><<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, true), ctx->stream>>>(d, dn, df);
+            bd.resize((size_t)d.cap); bfc.resize((size_t)d.cap);
+            hipError_t e1 = hipGetLastError();
+            if (e1 == hipSuccess) e1 = hipMemcpy(bd.data(), dn, (size_t)d.cap * 8, hipMemcpyDeviceToHost);
+            if (e1 == hipSuccess) e1 = hipMemcpy(bfc.data(), df, (size_t)d.cap * 4, hipMemcpyDeviceToHost);
+            hipFree(dn); hipFree(df);
+            if (e1 != hipSuccess) { ctx->err = std::string("nk_gather_live: ") + hipGetErrorString(e1); return NK_ERR_HIP; }
+            keep(bd, h.nts.data());
+        } else { std::fill(h.nts.begin(), h.nts.end(), 0.0); }
+    }
     if ((rc = nk_field_download(ctx, d, d.w0, bw))) return rc; keep(bw, w0.data());
     if (d.pid) { if ((rc = nk_field_download(ctx, d, d.pid, bu))) return rc; keep(bu, h.pid.data()); }
     // packed word -> (mode, facet): mode = idx * nseg + segment when the modes are partitioned
@@ -1035,7 +1146,8 @@ static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
         for (int j = 0; j < cnt[sgm]; ++j, ++k) {
             const uint32_t idx = w0[(size_t)k] & lbmask;
             h.mode[(size_t)k] = d.part ? ctx->h_s2m[(size_t)sgm * d.nlmax + idx] : (int32_t)idx;
-            h.facet[(size_t)k] = (int32_t)(w0[(size_t)k] >> d.lb) - 1;
+            if (d.nts) h.facet[(size_t)k] = (int32_t)(w0[(size_t)k] >> d.lb) - 1;
+            else h.facet[(size_t)k] = (w0[(size_t)k] & NK_LOST) ? -1 : (bfc.empty() ? 0 : bfc[(size_t)sgm * d.segcap + j]);
         }
     return NK_OK;
 }
@@ -1083,14 +1195,15 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
     };
     int rc;
     if ((rc = put(x, d.x)) || (rc = put(y, d.y)) || (rc = put(z, d.z)) || (rc = put(occ, d.occ))) return rc;
-    if (n_ts && (rc = put(n_ts, d.nts))) return rc;
+    if (n_ts && d.nts && (rc = put(n_ts, d.nts))) return rc;
     {
         std::vector<uint32_t> w0((size_t)N);
         for (int64_t i = 0; i < N; ++i) {
             const int32_t fc = facet ? facet[i] : -1;
             NK_ARG(fc >= -1 && fc < d.Fc, "nk_upload_particles: facet index out of range");
             const uint32_t idx = d.part ? (uint32_t)(ctx->h_m2s[(size_t)mode[i]] / d.nseg) : (uint32_t)mode[i];
-            w0[(size_t)i] = ((uint32_t)(fc + 1) << d.lb) | idx;
+            // (box store: the facet is not kept, only whether the last cast missed)
+            w0[(size_t)i] = d.nts ? (((uint32_t)(fc + 1) << d.lb) | idx) : (((facet && fc < 0) ? NK_LOST : 0u) | idx);
         }
         if ((rc = put((const uint32_t *)w0.data(), d.w0))) return rc;
     }
@@ -1125,7 +1238,7 @@ static int nk_sweep_blocks(nk_ctx *ctx) {
     const int gm_ = nk_geom_mode(ctx);
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = nk_want_pid(ctx), split_ = nk_want_split(ctx);
     const bool lrec_ = nk_want_lrec(ctx);
-    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4) | (split_ << 5) | (lrec_ << 6) | (nk_sweep_fast(ctx) << 7);
+    const int key = gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4) | (split_ << 5) | (lrec_ << 6) | (nk_sweep_fast(ctx) << 7) | ((d.box ? 1 : 0) << 9);
     const size_t lds_w = nk_lds(ctx, true, pid_ ? 3 : 2);
     if (ctx->g_sweep == 0 || ctx->g_sweep_key != key || ctx->g_sweep_lds != lds_w) {
         int per_cu = 0;
@@ -1268,7 +1381,8 @@ static int nk_place_store(nk_ctx *ctx) {
     NkDev &d = ctx->d;
     ctx->timing.place_tries = 0; ctx->timing.place_gbps = 0.0; ctx->timing.place_worst_gbps = 0.0;
     const int tries = getenv("NK_PLACE_TRIES") ? atoi(getenv("NK_PLACE_TRIES")) : 96;
-    const size_t bytes = nk_store_bytes(d.cap, ctx->store_pid);
+    const size_t bytes = nk_store_bytes(d.cap, ctx->store_pid, ctx->store_nts);
+    const int pbytes = nk_particle_bytes(ctx->store_pid, ctx->store_nts);
     // test hooks: NK_PLACE_MIN_MB (stores below it are not timed; default 64), NK_PLACE_FORCE=1 (always move into the last candidate)
     const size_t min_mb = getenv("NK_PLACE_MIN_MB") ? (size_t)atol(getenv("NK_PLACE_MIN_MB")) : 64;
     const bool force = getenv("NK_PLACE_FORCE") != nullptr;
@@ -1282,7 +1396,7 @@ static int nk_place_store(nk_ctx *ctx) {
     NK_HIP(hipEventCreate(&e0)); NK_HIP(hipEventCreate(&e1));
     auto probe = [&](void *buf, double &ms) -> int {
         NkDev t = d;
-        nk_point_fields(t, (double *)buf, d.cap, ctx->store_pid);
+        nk_point_fields(t, (double *)buf, d.cap, ctx->store_pid, ctx->store_nts);
         k_probe_place<<<g, NK_WG, 0, ctx->stream>>>(t, tiles);           // untimed: page tables, caches
         NK_HIP(hipEventRecord(e0, ctx->stream));
         for (int k = 0; k < 3; ++k) k_probe_place<<<g, NK_WG, 0, ctx->stream>>>(t, tiles);
@@ -1302,7 +1416,7 @@ static int nk_place_store(nk_ctx *ctx) {
         for (double v : ms) { lo = std::min(lo, v); hi = std::max(hi, v); }
         // the fast speed has been seen: 12 % above the slowest candidate AND at the level the fast memory of an MI355X gives this
         // copy (5.6-5.9 TB/s; the level in between, 5.2, does not end the search)
-        const double gb_ = 2.0 * (double)d.nseg * tiles * 64 * 44 / 1e9;
+        const double gb_ = 2.0 * (double)d.nseg * tiles * 64 * (pbytes - (ctx->store_pid ? 8 : 0)) / 1e9;
         if (hi > 1.12 * lo && gb_ / (lo * 1e-3) >= 5500.0 && !force) break;
         if (bytes * cand.size() > free_b / 3) break;                     // the extra ones: never more than a third of what is free
         if (std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count() > 1000.0) break;   // ... nor more than a second (large stores: 0.1 s per allocation)
@@ -1322,12 +1436,12 @@ static int nk_place_store(nk_ctx *ctx) {
         else {
             for (void *&p : ctx->pallocs) if (p == cand[0]) p = cand[best];
             ctx->store_buf = cand[best];
-            nk_point_fields(d, (double *)cand[best], d.cap, ctx->store_pid);
+            nk_point_fields(d, (double *)cand[best], d.cap, ctx->store_pid, ctx->store_nts);
             std::swap(cand[0], cand[best]);                              // cand[0] stays, the rest goes
         }
     } else best = 0;
     for (size_t k = 1; k < cand.size(); ++k) hipFree(cand[k]);
-    const double gb = 2.0 * (double)d.nseg * tiles * 64 * 44 / 1e9;      // read + written by one probe launch
+    const double gb = 2.0 * (double)d.nseg * tiles * 64 * (pbytes - (ctx->store_pid ? 8 : 0)) / 1e9;      // read + written by one probe launch (it leaves the ids alone)
     ctx->timing.place_tries = (int64_t)cand.size();
     ctx->timing.place_gbps = ms[best] > 0.0 ? gb / (ms[best] * 1e-3) : 0.0;
     ctx->timing.place_worst_gbps = ms[worst] > 0.0 ? gb / (ms[worst] * 1e-3) : 0.0;
@@ -1359,6 +1473,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     // every resident wave has one -- a wave's serial chain (tiles, event passes, entering particles) is what a small
     // sweep waits for.
     d.part = nk_want_part(ctx) ? 1 : 0;
+    d.box = nk_want_box(ctx) ? 1 : 0;
     d.nlrec = 0;
     int64_t nseg = 0;
     // the sweep's LDS (hence its residency, hence the segment count) depends on the record area, which depends on the segment
@@ -1390,7 +1505,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         const int64_t maxidx = d.part ? d.nlmax - 1 : (d.M > 0 ? d.M - 1 : 0);
         int lb = 1;
         while ((1ll << lb) <= maxidx) ++lb;
-        NK_ARG(lb < 31 && (int64_t)d.Fc + 1 < (1ll << (32 - lb)), "mesh has too many facets for the packed particle word (facets x modes)");
+        NK_ARG(lb < 30 && (int64_t)d.Fc + 1 < (1ll << (31 - lb)), "mesh has too many facets for the packed particle word (facets x modes)");
         d.lb = lb;
     }
     int64_t segcap = (capacity + nseg - 1) / nseg;
@@ -1413,7 +1528,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     const double *pd; const uint32_t *pw; const int32_t *pi; const uint64_t *pu;
 #define NK_PALLOC(T, field, ptr, count)                                                                \
     do { int rc_ = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (rc_) return rc_; d.field = (T *)ptr; } while (0)
-    { int rcf = nk_alloc_fields(ctx, d, d.cap, nk_want_pid(ctx)); if (rcf) return rcf; }
+    { int rcf = nk_alloc_fields(ctx, d, d.cap, nk_want_pid(ctx), !d.box); if (rcf) return rcf; }
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
@@ -1429,7 +1544,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     { const unsigned long long *ps; int rc_ = nk_upload<unsigned long long>(ctx, nullptr, (size_t)d.nseg * 16, &ps, true); if (rc_) return rc_; d.stamps = (unsigned long long *)ps; }
 #endif
 #undef NK_PALLOC
-    ctx->layout_key = (d.part ? 1 : 0) | (d.pid ? 2 : 0) | (d.qx ? 4 : 0);
+    ctx->layout_key = (d.part ? 1 : 0) | (d.pid ? 2 : 0) | (d.qx ? 4 : 0) | (d.box ? 8 : 0);
     // tables that follow the segmentation: permuted mode records, 'one_to_one' inboxes
     if (ctx->have_material) { int rc = nk_update_tau_window(ctx, true); if (rc) return rc; }
     if (ctx->inbox) { hipFree(ctx->inbox); ctx->inbox = nullptr; }
@@ -1487,7 +1602,7 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     int rc = NK_OK;
 #define NK_PALLOC(T, field, ptr, count)                                                                \
     do { if (!rc) { rc = nk_upload<T>(ctx, nullptr, (size_t)(count), &ptr, true); if (!rc) d.field = (T *)ptr; } } while (0)
-    if (!rc) rc = nk_alloc_fields(ctx, d, d.cap, (bool)old.pid);
+    if (!rc) rc = nk_alloc_fields(ctx, d, d.cap, (bool)old.pid, (bool)old.nts);
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
@@ -1549,7 +1664,14 @@ int nk_upload_particles(nk_ctx *ctx, int64_t N, const double *x, const double *y
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
     NK_HIP(hipStreamSynchronize(ctx->stream));
-    bool fits = d.cap > 0 && ctx->layout_key == ((nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0) | (nk_want_split(ctx) ? 4 : 0)) && N + N / 5 + 1024 <= d.cap;
+    if (n_ts && facet && ctx->mesh_box && !ctx->box_forbidden) {
+        // a state handed over WITH its cached hits: a box store re-derives them from the positions, which is the same thing
+        // only for particles inside the box (nk_init_boundaries has the other half of this rule)
+        const double *k = d.box_k;
+        for (int64_t i = 0; i < N && !ctx->box_forbidden; ++i)
+            if (facet[i] >= 0 && !(x[i] >= k[0] && x[i] <= -k[1] && y[i] >= k[2] && y[i] <= -k[3] && z[i] >= k[4] && z[i] <= -k[5])) ctx->box_forbidden = true;
+    }
+    bool fits = d.cap > 0 && ctx->layout_key == ((nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0) | (nk_want_split(ctx) ? 4 : 0) | (nk_want_box(ctx) ? 8 : 0)) && N + N / 5 + 1024 <= d.cap;
     if (fits && d.part) {                              // every segment must hold its modes' particles with head room
         std::vector<int64_t> per((size_t)d.nseg, 0);
         for (int64_t i = 0; i < N; ++i) if (mode[i] >= 0 && mode[i] < d.M) per[(size_t)nk_mode_seg(ctx, mode[i], d.nseg)] += 1;
@@ -1582,7 +1704,7 @@ static int nk_check_ready(nk_ctx *ctx) {
     NK_ARG(d.cap > 0, "no particle storage: call nk_reserve / nk_upload_particles");
     NK_ARG(nk_lds(ctx, true, 3) <= 160 * 1024 && nk_lds(ctx, true, 1) <= 160 * 1024, "tables do not fit the 160 KiB LDS");
     // the store's layout follows the configuration (ids, partitioned modes): tables set after the upload re-deal it
-    const int want = (nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0) | (nk_want_split(ctx) ? 4 : 0);
+    const int want = (nk_want_part(ctx) ? 1 : 0) | (nk_want_pid(ctx) ? 2 : 0) | (nk_want_split(ctx) ? 4 : 0) | (nk_want_box(ctx) ? 8 : 0);
     if (ctx->layout_key != want) {
         NkHostParticles h;
         int rc = nk_gather_live(ctx, h, true);
@@ -1627,9 +1749,20 @@ int nk_init_boundaries(nk_ctx *ctx) {
     int rc = nk_check_ready(ctx);
     if (rc) return rc;
     NK_HIP(hipSetDevice(ctx->device));
-    NK_GEOM_LAUNCH(k_init_boundaries, nk_sweep_grid(ctx), nk_lds(ctx, true), ctx->d);
-    NK_HIP(hipGetLastError());
-    NK_HIP(hipStreamSynchronize(ctx->stream));
+    for (int pass = 0; pass < 2; ++pass) {
+        NK_HIP(hipMemsetAsync(ctx->anomalies, 0, 4, ctx->stream));
+        NK_GEOM_LAUNCH(k_init_boundaries, nk_sweep_grid(ctx), nk_lds(ctx, true), ctx->d, ctx->anomalies);
+        NK_HIP(hipGetLastError());
+        int32_t bad = 0;
+        NK_HIP(hipMemcpyAsync(&bad, ctx->anomalies, 4, hipMemcpyDeviceToHost, ctx->stream));
+        NK_HIP(hipStreamSynchronize(ctx->stream));
+        if (!(ctx->d.box && bad > 0)) break;
+        // Particles that start OUTSIDE the box and would meet a wall from behind (a resumed state with particles behind their
+        // reservoir face, test ensembles planted outside): the reference runs their event when they reach that wall, a store
+        // without cached hits would let them fly in.  This context keeps the cached layout from here on.
+        ctx->box_forbidden = true;
+        if ((rc = nk_check_ready(ctx))) return rc;       // re-deals the store (layout key changed)
+    }
     return NK_OK;
 }
 
@@ -1701,7 +1834,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         const int do_flux = (fe > 0 && ((stepno + 1) % fe) == 0) ? 1 : 0;
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s], ctx->stream));
         if (R > 0 && d.res_gen == 2) k_emit_one_to_one<<<ctx->num_cu * 4, NK_WG, 0, ctx->stream>>>(d, step);
-        if (R > 0 && !emitted_ahead) NK_GEOM_LAUNCH(k_emit, g_emit, lds_e, d, step);
+        if (R > 0 && !emitted_ahead) NK_EMIT_LAUNCH(k_emit, g_emit, lds_e, d, step);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
         {
             const int rl = pending ? 1 : 0;
@@ -1716,15 +1849,13 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         double *hrow = ctx->hist + (size_t)s * HROW;
         const bool ahead = tail_emit && s + 1 < nsteps;        // the next step's emission beside this step's tail
         if (ctx->comm) {
-            if (ahead) { if (gm_ == 1) k_tail<1><<<NB + g_emit, NK_WG, lds_t, ctx->stream>>>(d, step + 1u, rows, ctx->acc, hrow, do_flux, 0, NB);
-                         else k_tail<2><<<NB + g_emit, NK_WG, lds_t, ctx->stream>>>(d, step + 1u, rows, ctx->acc, hrow, do_flux, 0, NB); }
+            if (ahead) NK_EMIT_LAUNCH(k_tail, NB + g_emit, lds_t, d, step + 1u, rows, ctx->acc, hrow, do_flux, 0, NB);
             else k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 0);
             ncclResult_t nrc = ctx->rccl.AllReduce(ctx->acc, ctx->acc, (size_t)NB + 2, ncclDouble, ncclSum, ctx->comm, ctx->stream);
             if (nrc != ncclSuccess) { ctx->err = "ncclAllReduce failed"; return NK_ERR_COMM; }
             k_update<<<1, NK_WG, 0, ctx->stream>>>(d, ctx->acc, hrow, do_flux);
         } else if (ahead) {
-            if (gm_ == 1) k_tail<1><<<NB + g_emit, NK_WG, lds_t, ctx->stream>>>(d, step + 1u, rows, ctx->acc, hrow, do_flux, 1, NB);
-            else k_tail<2><<<NB + g_emit, NK_WG, lds_t, ctx->stream>>>(d, step + 1u, rows, ctx->acc, hrow, do_flux, 1, NB);
+            NK_EMIT_LAUNCH(k_tail, NB + g_emit, lds_t, d, step + 1u, rows, ctx->acc, hrow, do_flux, 1, NB);
         } else {
             k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 1);
         }
@@ -2018,6 +2149,7 @@ int nk_get_step(nk_ctx *ctx, int64_t *step) {
 int nk_get_timing(nk_ctx *ctx, nk_timing *t) {
     NK_ARG(ctx && t, "nk_get_timing: NULL argument");
     *t = ctx->timing;
+    t->box_store = (ctx->d.cap > 0 && ctx->d.box) ? 1 : 0;
     return NK_OK;
 }
 
@@ -2280,13 +2412,13 @@ int nk_calibrate_stream(nk_ctx *ctx, int32_t launches, int64_t *bytes_read, int6
                 float ms = 0.f;
                 hipEventElapsedTime(&ms, e0, e1);
                 fprintf(stderr, "[nanokappa_hip] copy probe, %d-byte accesses: %.1f us per pass over %lld particles (%.2f TB/s)\n", w, 100.0 * ms,
-                        (long long)ns, 88.0 * ns / (ms * 1e-4) / 1e12);
+                        (long long)ns, (ctx->d.nts ? 88.0 : 72.0) * ns / (ms * 1e-4) / 1e12);
             }
         }
         hipEventDestroy(e0); hipEventDestroy(e1);
     }
-    if (bytes_read) *bytes_read = ns * 44;
-    if (bytes_written) *bytes_written = ns * 32;
+    if (bytes_read) *bytes_read = ns * (ctx->d.nts ? 44 : 36);
+    if (bytes_written) *bytes_written = ns * (ctx->d.nts ? 32 : 24);
     return NK_OK;
 }
 int nk_uniform2(uint64_t seed, uint64_t pid, uint32_t step, uint32_t tag, double *u0, double *u1) {

@@ -1275,7 +1275,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkD
         const int64_t a = (int64_t)seg * o.segcap, b = (int64_t)seg * n.segcap;
         for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
             n.x[b + i] = o.x[a + i]; n.y[b + i] = o.y[a + i]; n.z[b + i] = o.z[a + i];
-            n.occ[b + i] = o.occ[a + i]; n.nts[b + i] = o.nts[a + i];
+            n.occ[b + i] = o.occ[a + i]; if (o.nts && n.nts) n.nts[b + i] = o.nts[a + i];
             n.w0[b + i] = o.w0[a + i];
             if (o.pid && n.pid) n.pid[b + i] = o.pid[a + i];
         }
@@ -1807,12 +1807,12 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d)
         for (int k = threadIdx.x; k < count; k += NK_WG) {
             const int64_t i = base + k;
             uint32_t w0 = d.w0[i];
-            double x = d.x[i], y = d.y[i], z = d.z[i], occ = d.occ[i], nts = d.nts[i];
+            double x = d.x[i], y = d.y[i], z = d.z[i], occ = d.occ[i], nts = d.nts ? d.nts[i] : 0.0;
             // every one of the six loads must really be issued: a load whose only use sits behind a never-taken branch is sunk
             // into that branch by the compiler (round 2's version lost its occ load that way: 36 B read, not the 44 B the
             // calibration assumed -- its "read factor" 2.44 was 2.0 x 44 / 36)
             asm volatile("" : "+v"(w0), "+v"(occ));
-            d.x[i] = x; d.y[i] = y; d.z[i] = z; d.nts[i] = nts;
+            d.x[i] = x; d.y[i] = y; d.z[i] = z; if (d.nts) d.nts[i] = nts;     // (box store: 36 B read + 24 B written per particle)
         }
     }
 }
@@ -1820,18 +1820,19 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_cal_stream(NkDev d)
 // copying the particle state in place -- the bandwidth floor of that structure (8-byte accesses, one particle per lane).
 template <int W>
 __global__ __launch_bounds__(NK_WG, 3) void k_probe_copy(NkDev d) {
+    const bool hn = (bool)d.nts;                         // (a box store has no nts field)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg] & ~63;        // whole tiles only (a probe)
         double xN = 0, yN = 0, zN = 0, oN = 0, nN = 0; uint32_t wN = 0;
-        if (count > 0) { const int64_t i0 = base; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
+        if (count > 0) { const int64_t i0 = base; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); if (hn) nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
         for (int r = 0; r < count; r += 64) {
             const double x = xN, y = yN, z = zN, o = oN, n = nN; const uint32_t w = wN;
-            if (r + 64 < count) { const int64_t i0 = base + r + 64; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
+            if (r + 64 < count) { const int64_t i0 = base + r + 64; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); if (hn) nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
             const int64_t i0 = base + r;
-            *d.x.tile(i0, lane) = x + 1e-300; *d.y.tile(i0, lane) = y; *d.z.tile(i0, lane) = z; *d.occ.tile(i0, lane) = o; *d.nts.tile(i0, lane) = n; *d.w0.tile(i0, lane) = w;
+            *d.x.tile(i0, lane) = x + 1e-300; *d.y.tile(i0, lane) = y; *d.z.tile(i0, lane) = z; *d.occ.tile(i0, lane) = o; if (hn) *d.nts.tile(i0, lane) = n; *d.w0.tile(i0, lane) = w;
         }
     }
 }
@@ -1840,6 +1841,7 @@ __global__ __launch_bounds__(NK_WG, 3) void k_probe_copy(NkDev d) {
 // tells the two speeds apart that one and the same store shows depending on where its allocation lies in memory
 // (profiles/r03_notes.txt (9), (17)).
 NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG, 3) void k_probe_place(NkDev d, int tiles) {
+    const bool hn = (bool)d.nts;                         // (a box store has no nts field)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
@@ -1847,13 +1849,13 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG, 3) void k_probe_place(NkDe
         const int64_t step = 64;
         const int count = tiles;
         double xN = 0, yN = 0, zN = 0, oN = 0, nN = 0; uint32_t wN = 0;
-        if (count > 0) { const int64_t i0 = base; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
+        if (count > 0) { const int64_t i0 = base; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); if (hn) nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
         for (int r = 0; r < count; ++r) {
             double x = xN, y = yN, z = zN, o = oN, n = nN; uint32_t w = wN;
-            if (r + 1 < count) { const int64_t i0 = base + (r + 1) * step; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
+            if (r + 1 < count) { const int64_t i0 = base + (r + 1) * step; xN = *d.x.tile(i0, lane); yN = *d.y.tile(i0, lane); zN = *d.z.tile(i0, lane); oN = *d.occ.tile(i0, lane); if (hn) nN = *d.nts.tile(i0, lane); wN = *d.w0.tile(i0, lane); }
             asm volatile("" : "+v"(x), "+v"(y), "+v"(z), "+v"(o), "+v"(n), "+v"(w));     // (a store of the value just loaded would be dropped)
             const int64_t i0 = base + r * step;
-            *d.x.tile(i0, lane) = x; *d.y.tile(i0, lane) = y; *d.z.tile(i0, lane) = z; *d.occ.tile(i0, lane) = o; *d.nts.tile(i0, lane) = n; *d.w0.tile(i0, lane) = w;
+            *d.x.tile(i0, lane) = x; *d.y.tile(i0, lane) = y; *d.z.tile(i0, lane) = z; *d.occ.tile(i0, lane) = o; if (hn) *d.nts.tile(i0, lane) = n; *d.w0.tile(i0, lane) = w;
         }
     }
 }

@@ -15,3 +15,8 @@ template __global__ void k_sweep<1, false, false, false, false, true, 1>(NkDev, 
 template __global__ void k_sweep<1, false, false, false, false, true, 2>(NkDev, uint32_t, int, int);
 template __global__ void k_sweep<1, false, false, false, false, false, 1>(NkDev, uint32_t, int, int);
 template __global__ void k_sweep<1, false, false, false, false, false, 2>(NkDev, uint32_t, int, int);
+// ... and the same four for the box store (BOX: no cached next hit in the particle state, nk_kernels.h)
+template __global__ void k_sweep<1, false, false, false, false, true, 1, true>(NkDev, uint32_t, int, int);
+template __global__ void k_sweep<1, false, false, false, false, true, 2, true>(NkDev, uint32_t, int, int);
+template __global__ void k_sweep<1, false, false, false, false, false, 1, true>(NkDev, uint32_t, int, int);
+template __global__ void k_sweep<1, false, false, false, false, false, 2, true>(NkDev, uint32_t, int, int);

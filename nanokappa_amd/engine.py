@@ -71,7 +71,8 @@ class nk_timing(C.Structure):
                 ('total_ms', C.c_double),
                 ('slots', C.c_int64), ('live', C.c_int64),
                 ('regrows', C.c_int64), ('halts', C.c_int64), ('tau_rebuilds', C.c_int64), ('batches', C.c_int64),
-                ('emit_fused', C.c_int64), ('place_tries', C.c_int64), ('place_gbps', C.c_double), ('place_worst_gbps', C.c_double)]
+                ('emit_fused', C.c_int64), ('place_tries', C.c_int64), ('place_gbps', C.c_double), ('place_worst_gbps', C.c_double),
+                ('box_store', C.c_int64)]
 
 
 class nk_comm_report(C.Structure):
@@ -415,7 +416,8 @@ class Engine(object):
                     total_ms=t.total_ms,
                     slots=int(t.slots), live=int(t.live), regrows=int(t.regrows), halts=int(t.halts),
                     tau_rebuilds=int(t.tau_rebuilds), batches=int(t.batches), emit_fused=int(t.emit_fused),
-                    place_tries=int(t.place_tries), place_gbps=t.place_gbps, place_worst_gbps=t.place_worst_gbps)
+                    place_tries=int(t.place_tries), place_gbps=t.place_gbps, place_worst_gbps=t.place_worst_gbps,
+                    box_store=int(t.box_store))
 
     # ---- set-up table builder (find_specular_correspondences 'velocity', Population.py:1241-1454)
     def specular_begin(self, group_vel, omega, delta_omega):

@@ -275,13 +275,85 @@ void nko_reflect(const nko_material *mat, const nko_mesh *mesh, const nko_subvol
 
 /* --------------------------------------------------------------- stages ---- */
 /* timesteps_to_boundary, Population.py:797-830 (first call :310-314) */
-void nko_init_boundaries(const nko_mesh *mesh, const nko_material *mat, const nko_params *p, nko_particles *P) {
+/* ---- box rule (nk_oracle.h nko_params::box; engine: nk_device.h nk_box_out / nk_box_first_hit) ---- */
+int32_t nko_box_detect(const nko_mesh *m, nko_params *p) {
+    if (m->F != 12 || m->Fc != 6) return 0;
+    int seen = 0, fm = 0;
+    double area[6] = {0, 0, 0, 0, 0, 0};
+    int cnt[6] = {0, 0, 0, 0, 0, 0};
+    for (int w = 0; w < 6; ++w) p->box_face0[w] = 0x7fffffff;
+    for (int32_t f = 0; f < m->F; ++f) {
+        const double *n = m->normals + 3 * f;
+        int a = -1, sgn = 0;
+        for (int k = 0; k < 3; ++k) {
+            if (n[k] == 1.0 || n[k] == -1.0) { if (a >= 0) return 0; a = k; sgn = n[k] > 0 ? 1 : 0; }
+            else if (n[k] != 0.0) return 0;
+        }
+        if (a < 0) return 0;
+        const int w = 2 * a + sgn;
+        const double wall = sgn ? -m->k[f] : m->k[f];
+        if (!(fabs(wall - m->bbox[(sgn ? 3 : 0) + a]) <= 1e-9 * (1.0 + fabs(wall)))) return 0;
+        if (seen & (1 << w)) { if (p->box_k[w] != m->k[f] || p->box_facet[w] != m->face_facet[f]) return 0; }
+        else { seen |= 1 << w; p->box_k[w] = m->k[f]; p->box_facet[w] = m->face_facet[f]; }
+        if (f < p->box_face0[w]) p->box_face0[w] = f;
+        area[w] += m->face_area[f];
+        cnt[w] += 1;
+        for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 3; ++k) {
+                const double v = m->vertices[9 * (int64_t)f + 3 * c + k], lo = m->bbox[k], hi = m->bbox[3 + k];
+                const double e = 1e-9 * (1.0 + fabs(lo) + fabs(hi));
+                if (k == a) { if (fabs(v - wall) > e) return 0; }
+                else if (fabs(v - lo) > e && fabs(v - hi) > e) return 0;
+            }
+    }
+    if (seen != 63) return 0;
+    for (int w = 0; w < 6; ++w) {
+        const int a = w / 2, b = (a + 1) % 3, c = (a + 2) % 3;
+        const double side = (m->bbox[3 + b] - m->bbox[b]) * (m->bbox[3 + c] - m->bbox[c]);
+        if (cnt[w] != 2 || !(fabs(area[w] - side) <= 1e-9 * side)) return 0;
+        if (p->box_facet[w] < 0 || p->box_facet[w] >= 6) return 0;
+        fm |= 1 << p->box_facet[w];
+    }
+    return fm == 63;
+}
+/* does the particle lie beyond a wall it flies towards?  (nk_box_out) */
+static int box_out(const nko_params *p, const double x[3], const double v[3]) {
+    for (int a = 0; a < 3; ++a) {
+        if (v[a] > 0.0 && x[a] > -p->box_k[2 * a + 1]) return 1;
+        if (v[a] < 0.0 && x[a] < p->box_k[2 * a]) return 1;
+    }
+    return 0;
+}
+/* the wall it crossed first, Mesh.py:816-818 on the walls it lies beyond; timesteps from the end of the step (nk_box_first_hit) */
+static void box_first_hit(const nko_params *p, const double x[3], const double v[3], double *nts, int32_t *facet) {
+    double tb = INFINITY;
+    int32_t fb = -1, f0b = 0x7fffffff;
+    for (int a = 0; a < 3; ++a) {
+        double num, den;
+        int w;
+        if (v[a] > 0.0 && x[a] > -p->box_k[2 * a + 1]) { num = x[a] + p->box_k[2 * a + 1]; den = v[a]; w = 2 * a + 1; }
+        else if (v[a] < 0.0 && x[a] < p->box_k[2 * a]) { num = -x[a] + p->box_k[2 * a]; den = -v[a]; w = 2 * a; }
+        else continue;
+        const double t = -num / den;
+        if (t < tb || (t == tb && p->box_face0[w] < f0b)) { tb = t; fb = p->box_facet[w]; f0b = p->box_face0[w]; }
+    }
+    *nts = tb / p->dt;
+    *facet = fb;
+}
+
+int64_t nko_init_boundaries(const nko_mesh *mesh, const nko_material *mat, const nko_params *p, nko_particles *P) {
+    int64_t bad = 0;
     for (int64_t i = 0; i < P->N; ++i) {
         double xc[3], tc; int32_t fc;
         find_boundary_one(mesh, P->pos + 3 * i, mat->group_vel + 3 * (int64_t)P->mode[i], xc, &tc, &fc);
         P->n_ts[i] = tc / p->dt;
         P->facet[i] = fc;
+        if (p->box && fc >= 0) {
+            const double *x = P->pos + 3 * i;
+            for (int a = 0; a < 3; ++a) if (!(x[a] >= p->box_k[2 * a] && x[a] <= -p->box_k[2 * a + 1])) { ++bad; break; }
+        }
     }
+    return bad;
 }
 /* Population.drift, Population.py:790-795 */
 void nko_drift(const nko_material *mat, const nko_params *p, nko_particles *P) {
@@ -437,7 +509,14 @@ void nko_boundary_scattering(const nko_material *mat, const nko_mesh *mesh, cons
         double occ = P->occ[i], nts = P->n_ts[i];
         int32_t fct = P->facet[i];
         int alive = 1;
-        if (nts < 0) {                                                        /* :1551-1556 */
+        int has_event = nts < 0;                                              /* :1551-1556 */
+        if (p->box) {
+            /* box rule: read off the position; a particle whose last cast missed (the reference's n_timesteps = inf) never has one */
+            const double *v0 = mat->group_vel + 3 * (int64_t)mode;
+            has_event = fct >= 0 && box_out(p, x, v0);
+            if (has_event) box_first_hit(p, x, v0, &nts, &fct);
+        }
+        if (has_event) {
             double cts = 0.0;
             double omega = mat->omega[mode];
             uint32_t ev = 0;

@@ -113,6 +113,16 @@ typedef struct {
     uint64_t seed;
     int32_t ids_from_state;  /* 1: the resampling draws of contains_check are keyed on the particle's state (mode and the bits
                               * of its position) instead of its id -- the engine's rule when it does not track ids */
+    /* Box rule (round 4; the engine's "box store", nk_device.h NkDev::box): on an axis-aligned box whose six sides are its six
+     * facets the engine keeps no cached next hit.  Whether a particle meets a wall inside the step is read off its end-of-step
+     * position (beyond a wall it flies towards), and that hit -- time and facet -- is evaluated then, with Mesh.find_boundary's
+     * expression t = -(x.n + k) / (v.n) (Mesh.py:818).  The reference decides on the cached n_timesteps it decremented
+     * (Population.py:795, :1551): the same hit up to the rounding of the drift.  box = 1 makes the oracle decide the engine's
+     * way (nko_box_detect fills the rest); n_ts / facet are still carried the reference's way, for comparison. */
+    int32_t box;
+    double box_k[6];         /* plane constants of the walls: [2a] normal -e_a, [2a+1] normal +e_a */
+    int32_t box_facet[6];
+    int32_t box_face0[6];    /* lowest face index of each wall (ties, Mesh.py:846-848) */
 } nko_params;
 
 /* Particle arrays in the reference's own layout (Population.py:199-321). */
@@ -146,7 +156,11 @@ void nko_reflect(const nko_material *mat, const nko_mesh *mesh, const nko_subvol
                  int32_t *mode_out, double *n_out, double *omega_out);
 
 /* ---- stages of run_timestep (Population.py:1724-1769) ---- */
-void nko_init_boundaries(const nko_mesh *mesh, const nko_material *mat, const nko_params *p, nko_particles *P);
+/* returns the number of particles the box rule cannot express: outside the box with a wall ahead of them (the caller then
+ * clears p->box, as the engine goes back to its cached layout) */
+int64_t nko_init_boundaries(const nko_mesh *mesh, const nko_material *mat, const nko_params *p, nko_particles *P);
+/* 1 and p->box_* filled if the mesh is such a box (the engine's rule, nk_engine.hip nk_set_mesh), else 0; p->box is left alone */
+int32_t nko_box_detect(const nko_mesh *mesh, nko_params *p);
 void nko_drift(const nko_material *mat, const nko_params *p, nko_particles *P);
 /* emission: appends to P; returns number emitted or -1 on capacity overflow */
 int64_t nko_emit(const nko_material *mat, const nko_mesh *mesh, nko_reservoirs *res, const nko_params *p,

@@ -57,7 +57,8 @@ class Rough(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [('dt', C.c_double), ('norm_fixed', C.c_int32), ('particle_density', C.c_double),
-                ('T_ref_local', C.c_int32), ('T_ref', C.c_double), ('seed', C.c_uint64), ('ids_from_state', C.c_int32)]
+                ('T_ref_local', C.c_int32), ('T_ref', C.c_double), ('seed', C.c_uint64), ('ids_from_state', C.c_int32),
+                ('box', C.c_int32), ('box_k', C.c_double * 6), ('box_facet', C.c_int32 * 6), ('box_face0', C.c_int32 * 6)]
 
 
 class Particles(C.Structure):
@@ -81,6 +82,8 @@ def lib():
         L = _LIB
         L.nko_emit.restype = C.c_int64
         L.nko_contains_check.restype = C.c_int64
+        L.nko_init_boundaries.restype = C.c_int64
+        L.nko_box_detect.restype = C.c_int32
     return _LIB
 
 
@@ -291,9 +294,16 @@ class ParticleStore(object):
 class OracleSim(object):
     """Runs Population.run_timestep's stage order (Population.py:1724-1769) on the oracle."""
 
-    def __init__(self, mat, mesh, sv, res, rough, params, store, T_sv):
+    def __init__(self, mat, mesh, sv, res, rough, params, store, T_sv, box=False):
+        """box: False = the reference's rule (events decided on the cached, decremented n_timesteps: what the goldens pin);
+        'auto' = the engine's rule: on an axis-aligned box whose sides are its facets the hit is read off the position
+        (nk_oracle.h nko_params::box), unless NK_NO_BOX / NK_SPLIT / NK_LAYOUT=soa switch the engine's box store off."""
         self.L = lib()
         self.mat, self.mesh, self.sv, self.res, self.rough, self.p, self.P = mat, mesh, sv, res, rough, params, store
+        self.p.box = 0
+        off = os.environ.get('NK_NO_BOX') or os.environ.get('NK_SPLIT') or os.environ.get('NK_LAYOUT') == 'soa'
+        if box and not off and self.L.nko_box_detect(C.byref(self.mesh), C.byref(self.p)):
+            self.p.box = 1
         self.S = sv.S
         self.R = res.R
         self.T_sv = np.array(T_sv, dtype=np.float64)
@@ -311,7 +321,9 @@ class OracleSim(object):
         return C.byref(x)
 
     def init_boundaries(self):
-        self.L.nko_init_boundaries(self.ref(self.mesh), self.ref(self.mat), self.ref(self.p), self.ref(self.P.s))
+        bad = self.L.nko_init_boundaries(self.ref(self.mesh), self.ref(self.mat), self.ref(self.p), self.ref(self.P.s))
+        if self.p.box and bad > 0:        # particles outside the box with a wall ahead: the engine goes back to cached hits
+            self.p.box = 0
 
     def run_timestep_sharded(self, allreduce, emit=True, contains_every=100, halt_requests=(0, 0)):
         """run_timestep for one rank of a particle-sharded ensemble: `allreduce(vec)` sums a float64 vector over the

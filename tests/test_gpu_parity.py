@@ -6,7 +6,7 @@ import sys
 import numpy as np
 import pytest
 
-from util import golden, sub, golden_phonon, rel_err, case_tables, random_population, make_oracle_sim, make_engine, allclose
+from util import golden, sub, golden_phonon, rel_err, case_tables, random_population, make_oracle_sim, make_engine, allclose, same_event_rule
 
 pytestmark = pytest.mark.gpu
 
@@ -214,15 +214,20 @@ def test_frozen_step_vs_reference(variant):
     assert rel_err(p['occupation'][o], gs['post_occupation']) < 1e-9
 
 
+@pytest.mark.parametrize('store', ['box', 'cached'])
 @pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
-def test_multistep_vs_oracle(case):
+def test_multistep_vs_oracle(case, store, monkeypatch):
     """Same seed, same counter-based RNG: engine and oracle must make the same decisions; compare the
-    per-step tallies and the final particle set (matched by particle id)."""
+    per-step tallies and the final particle set (matched by particle id).  Both layouts of the particle store: the box store
+    (no cached next hit; these meshes are axis-aligned boxes) and, with NK_NO_BOX, the cached one that every other mesh uses."""
+    if store == 'cached':
+        monkeypatch.setenv('NK_NO_BOX', '1')
     ct = case_tables(case)
     pos, mode, occ, counter = random_population(ct, 30000, seed=5)
     nsteps = 25
     sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=42)
     eng = make_engine(ct, pos, mode, occ, counter, seed=42)
+    assert same_event_rule(eng, sim) == (1 if store == 'box' else 0)
     t = eng.step(nsteps)
     for s in range(nsteps):
         sim.run_timestep()

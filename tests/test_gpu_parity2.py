@@ -9,7 +9,7 @@ import tempfile
 import numpy as np
 import pytest
 
-from util import rel_err, case_tables, random_population, make_oracle_sim, make_engine, allclose
+from util import rel_err, case_tables, random_population, make_oracle_sim, make_engine, allclose, same_event_rule
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
@@ -41,6 +41,7 @@ def compare_by_state(p, sim):
 
 
 def steps_agree(eng, sim, nsteps, chunk=50):
+    same_event_rule(eng, sim)
     done = 0
     while done < nsteps:
         k = min(chunk, nsteps - done)

@@ -138,7 +138,9 @@ def random_population(ct, n, seed, T0=298.0):
 
 
 def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=298.0, emit_scale=1.0, gen=0,
-                    ids_from_state=False, res_T=None):
+                    ids_from_state=False, res_T=None, box='auto'):
+    """box='auto': the oracle decides events the way the engine does on this mesh (box rule on axis-aligned boxes, see
+    oracle/nk_oracle.h nko_params::box); box=False: the reference's cached rule."""
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'oracle'))
     import nk_oracle as O
@@ -161,9 +163,16 @@ def make_oracle_sim(ct, pos, mode, occ, counter, seed, cap=None, interp=1, T0=29
     n = pos.shape[0]
     store = O.ParticleStore(cap or (2 * n + 4096))
     store.load(pos, mode, occ)
-    sim = O.OracleSim(mat, mesh, sv, res, rough, par, store, np.full(ct['centers'].shape[0], T0))
+    sim = O.OracleSim(mat, mesh, sv, res, rough, par, store, np.full(ct['centers'].shape[0], T0), box=box)
     sim.init_boundaries()
     return sim
+
+
+def same_event_rule(eng, sim):
+    """Engine and oracle must decide events the same way: both on cached next hits, or both by the box rule (engine: box store,
+    nk_timing.box_store; oracle: nko_params.box)."""
+    assert int(eng.timing()['box_store']) == int(sim.p.box), 'engine box_store %d, oracle box rule %d' % (eng.timing()['box_store'], sim.p.box)
+    return int(sim.p.box)
 
 
 def sv_interp_of(ct, kind, interp):
