@@ -64,6 +64,21 @@ struct NkField {
     __host__ __device__ __forceinline__ explicit operator bool() const { return p != nullptr; }
 };
 
+// The same geometry for code that knows at compile time which fields the store has (the sweep): every field of slot i is a
+// fixed distance from the slot's x, so a tile's loads and stores share ONE address and differ by immediate offsets -- one
+// 64-bit address computation per tile instead of one per field, and one base pointer in scalar registers instead of six.
+template <bool NTS, bool PID>
+struct NkBlock {
+    static constexpr int NF = 4 + (NTS ? 1 : 0) + (PID ? 1 : 0);     // 8-byte fields per particle
+    static constexpr int BD = NF * 64 + 32;                           // doubles per block (nk_engine.hip nk_store_bytes)
+    static constexpr int O_Y = 64, O_Z = 128, O_OCC = 192, O_NTS = 256, O_PID = 64 * (NTS ? 5 : 4), O_W0 = 64 * NF;   // in doubles
+    // x of slot i (any slot) / of lane `lane` in the tile that starts at slot i0 (a multiple of 64)
+    static __device__ __forceinline__ double *slot(double *s0, int64_t i) { return s0 + (i >> 6) * (int64_t)BD + (i & 63); }
+    static __device__ __forceinline__ double *tile(double *s0, int64_t i0, int lane) { return s0 + (i0 >> 6) * (int64_t)BD + lane; }
+    // the packed word that belongs to the slot whose x is at q
+    static __device__ __forceinline__ uint32_t *word(double *s0, int64_t i) { return reinterpret_cast<uint32_t *>(s0 + (i >> 6) * (int64_t)BD + O_W0) + (i & 63); }
+};
+
 struct __attribute__((aligned(16))) NkFacet {   // 96 bytes
     double cx, cy, cz;    // centroid
     double nx, ny, nz;    // outward normal
@@ -124,8 +139,9 @@ struct NkDev {
     // normals the two dot products are exact, x.n + k is one rounding).  36 B per particle instead of 44.
     int32_t box;                      // 1: box store
     double box_k[6];                  // plane constants k (n.x + k = 0) of the walls: [2 a] the wall with normal -e_a, [2 a + 1] +e_a
-    int32_t box_facet[6];             // their facets
-    int32_t box_face0[6];             // lowest face index of each wall (Mesh.find_boundary: the lowest face index wins a tie)
+    uint64_t box_ids;                 // per wall w, bits [8 w, 8 w + 4): its facet, bits [8 w + 4, 8 w + 8): its lowest face index
+                                      // (Mesh.find_boundary: the lowest face index wins a tie); one scalar pair instead of twelve
+    double inv_dt;                    // 1 / dt
     const double *face_verts;         // [F*9] original face order
     const int32_t *facet_face_off;    // [Fc+1]
     const int32_t *facet_face_idx;
@@ -625,40 +641,57 @@ __device__ __forceinline__ void nk_find_boundary(const double *planes, const dou
 // resampling; a particle behind its reservoir face with a negative entry time flies INWARDS and is not caught here, like in
 // the reference, whose cached next hit is the far wall).  x_a > -k exactly when the reference's numerator x.n + k rounds above
 // zero, so this is the sign of the very t the event pass then computes.
-__device__ __forceinline__ bool nk_box_out(const NkDev &d, double x, double y, double z, double vx, double vy, double vz) {
-    const bool ox = vx > 0.0 ? x > -d.box_k[1] : (vx < 0.0 ? x < d.box_k[0] : false);
-    const bool oy = vy > 0.0 ? y > -d.box_k[3] : (vy < 0.0 ? y < d.box_k[2] : false);
-    const bool oz = vz > 0.0 ? z > -d.box_k[5] : (vz < 0.0 ? z < d.box_k[4] : false);
+// The six walls, held in VECTOR registers for the whole kernel (NkBoxWalls::load launders them through an empty asm): as kernel
+// arguments they are scalar values, of which the sweep has more than scalar registers -- the compiler parks the surplus in
+// vector lanes and fetches every use back with v_readlane, per basic block (+134 of those in the tile loop for the twelve
+// dwords of the walls; a vector instruction each, as dear as an FMA).  Twelve vector registers are free (144 of 168 in use).
+struct NkBoxWalls {
+    double lx, hx, ly, hy, lz, hz;      // lo = k of the wall with normal -e_a, hi = -k of the wall with normal +e_a
+    uint32_t ids_lo, ids_hi;            // NkDev::box_ids
+    __device__ __forceinline__ void load(const NkDev &d) {
+        lx = d.box_k[0]; hx = -d.box_k[1]; ly = d.box_k[2]; hy = -d.box_k[3]; lz = d.box_k[4]; hz = -d.box_k[5];
+        ids_lo = (uint32_t)d.box_ids; ids_hi = (uint32_t)(d.box_ids >> 32);
+        asm volatile("" : "+v"(lx), "+v"(hx), "+v"(ly), "+v"(hy), "+v"(lz), "+v"(hz), "+v"(ids_lo), "+v"(ids_hi));
+    }
+};
+__device__ __forceinline__ bool nk_box_out(const NkBoxWalls &b, double x, double y, double z, double vx, double vy, double vz) {
+    const bool ox = ((x > b.hx) & (vx > 0.0)) | ((x < b.lx) & (vx < 0.0));
+    const bool oy = ((y > b.hy) & (vy > 0.0)) | ((y < b.ly) & (vy < 0.0));
+    const bool oz = ((z > b.hz) & (vz > 0.0)) | ((z < b.lz) & (vz < 0.0));
     return ox | oy | oz;
 }
 // The wall such a particle crossed FIRST and when, in timesteps counted from the end of the step (negative): for every wall it
 // lies beyond, t = -(x.n + k) / (v.n) as Mesh.find_boundary evaluates it (Mesh.py:816-818; unit axis normal: x.n = +-x_a and
-// v.n = +-v_a exactly), the earliest wins, the lowest face index among equals (:846-848).  What the reference holds in
-// n_timesteps / collision_facets at this point is the same hit, cast from where the particle's free flight began and
-// decremented once per step (Population.py:795): equal up to the rounding of the drift.
-// one axis of nk_box_first_hit: the wall with normal -e_a (constants klo, ...) or +e_a (khi, ...)
-__device__ __forceinline__ void nk_box_axis(double xa, double va, double klo, double khi, int flo, int fhi, int f0lo, int f0hi,
-                                            double &tb, int &fb, int &f0b) {
+// v.n = +-v_a exactly, so num = x.n + k is one rounding -- x_a - hi resp. lo - x_a -- and den = |v_a| none), the earliest wins,
+// the lowest face index among equals (:846-848).  What the reference holds in n_timesteps / collision_facets at this point is
+// the same hit, cast from where the particle's free flight began and decremented once per step (Population.py:795): equal up
+// to the rounding of the drift.
+// num and den are positive for a wall the particle lies beyond (num <= 0 for the others), so "earliest" = largest num / den
+// is decided on the cross products -- no division per wall -- and only the winner is divided (v_rcp_f64 + Newton: the quotient
+// places the hit point, it decides nothing).  The oracle's box rule selects the same way (oracle/nk_oracle.c box_first_hit).
+// one axis: the wall with normal -e_a (w = 2 a) or +e_a (w = 2 a + 1) against the best so far (nb / db, wall wb)
+__device__ __forceinline__ void nk_box_axis(double xa, double va, double lo, double hi, int wlo, uint64_t ids,
+                                            double &nb, double &db, int &wb) {
 #pragma clang fp contract(off)
-    double num, den;
-    int f, f0;
-    if (va > 0.0 && xa > -khi) { num = xa + khi; den = va; f = fhi; f0 = f0hi; }
-    else if (va < 0.0 && xa < klo) { num = -xa + klo; den = -va; f = flo; f0 = f0lo; }
-    else return;
-    const double t = -num / den;
-    if (t < tb || (t == tb && f0 < f0b)) { tb = t; fb = f; f0b = f0; }
+    const bool fwd = va > 0.0;
+    const double num = fwd ? xa - hi : lo - xa;          // x.n + k of the wall the particle flies towards
+    const double den = fabs(va);                          // v.n of that wall
+    const int w = wlo + (fwd ? 1 : 0);
+    const double l = num * db, r = nb * den;
+    // (a tie between two walls: the lower face index wins; wb < 0: nothing chosen yet)
+    const unsigned f0w = (unsigned)(ids >> (8 * w + 4)) & 15u, f0b = wb < 0 ? 16u : ((unsigned)(ids >> (8 * wb + 4)) & 15u);
+    if ((num > 0.0) & (den > 0.0) & ((l > r) | ((l == r) & (f0w < f0b)))) { nb = num; db = den; wb = w; }
 }
-__device__ __forceinline__ void nk_box_first_hit(const NkDev &d, double x, double y, double z, double vx, double vy, double vz,
-                                                 double &nts, int &facet) {
-    // (the walls' constants by constant index: a loop over the axes makes the compiler keep the whole parameter block in
-    // scratch memory)
-    double tb = __builtin_inf();
-    int fb = -1, f0b = 0x7fffffff;
-    nk_box_axis(x, vx, d.box_k[0], d.box_k[1], d.box_facet[0], d.box_facet[1], d.box_face0[0], d.box_face0[1], tb, fb, f0b);
-    nk_box_axis(y, vy, d.box_k[2], d.box_k[3], d.box_facet[2], d.box_facet[3], d.box_face0[2], d.box_face0[3], tb, fb, f0b);
-    nk_box_axis(z, vz, d.box_k[4], d.box_k[5], d.box_facet[4], d.box_facet[5], d.box_face0[4], d.box_face0[5], tb, fb, f0b);
-    nts = tb / d.dt;
-    facet = fb;
+__device__ __forceinline__ void nk_box_first_hit(const NkBoxWalls &b, double inv_dt, double x, double y, double z, double vx, double vy,
+                                                 double vz, double &nts, int &facet) {
+    const uint64_t ids = ((uint64_t)b.ids_hi << 32) | b.ids_lo;
+    double nb = -1.0, db = 1.0;
+    int wb = -1;
+    nk_box_axis(x, vx, b.lx, b.hx, 0, ids, nb, db, wb);
+    nk_box_axis(y, vy, b.ly, b.hy, 2, ids, nb, db, wb);
+    nk_box_axis(z, vz, b.lz, b.hz, 4, ids, nb, db, wb);
+    nts = -(nb * nk_rcp(db)) * inv_dt;
+    facet = wb < 0 ? -1 : (int)((ids >> (8 * wb)) & 15u);
 }
 // Large meshes (tables in global memory): a 4-ary tree of bounding boxes over the FACES, walked by every lane on its own.
 // The faces are sorted along a space-filling curve; a leaf is 4 consecutive faces, node i of level l + 1 the union of

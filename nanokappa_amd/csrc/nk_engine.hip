@@ -147,9 +147,10 @@ static int nk_upload(nk_ctx *ctx, const T *src, size_t n, const T **dst, bool pa
     do { int rc_ = nk_upload(ctx, src, n, dst); if (rc_) return rc_; } while (0)
 
 // The particle fields of a store of `cap` slots (a multiple of 64): ONE allocation cut into blocks of 64 slots, every block
-// x | y | z | occ | nts | [pid] | w0 (NkField, nk_device.h).  NK_LAYOUT=soa (developer comparison): one plain array per
-// field, as in round 2.  The allocation is registered in ctx->pallocs.
-static inline bool nk_layout_soa() { return getenv("NK_LAYOUT") && !strcmp(getenv("NK_LAYOUT"), "soa"); }
+// x | y | z | occ | [nts] | [pid] | w0 (NkField, nk_device.h; the sweep addresses a block's fields from ONE base pointer at
+// compile-time distances, NkBlock).  (Round 3 also had one plain array per field as a developer layout, NK_LAYOUT=soa: measured
+// equal, removed with the single-base addressing.)  The allocation is registered in ctx->pallocs.
+static inline bool nk_layout_soa() { return false; }
 // bytes of one particle in the store: x y z occ (+ nts unless it is a box store) (+ pid) + the packed word
 static inline int nk_particle_bytes(bool with_pid, bool with_nts) { return 36 + (with_nts ? 8 : 0) + (with_pid ? 8 : 0); }
 static inline size_t nk_store_bytes(int64_t cap, bool with_pid, bool with_nts) {
@@ -378,7 +379,7 @@ int nk_create(nk_ctx **out, int device_id, uint64_t seed) {
     ctx->d.tau_row0 = -1;
     ctx->d.stamps = nullptr;
     ctx->params.dt = 1.0; ctx->params.T_ref_local = 1; ctx->params.flux_every = 10; ctx->params.contains_every = 100;
-    ctx->d.dt = 1.0; ctx->d.T_ref_local = 1;
+    ctx->d.dt = 1.0; ctx->d.inv_dt = 1.0; ctx->d.T_ref_local = 1;
     // bookkeeping words in device memory: halt[4], overflow, ticket, ev_ticket
     const int32_t *p32 = nullptr;
     int rc;
@@ -794,6 +795,8 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
     if (m->F == 12 && m->Fc == 6 && d.NP == 6) {
         bool ok = true;
         int seen = 0;
+        int box_facet[6] = {0, 0, 0, 0, 0, 0};
+        d.box_ids = 0;
         for (int pl = 0; pl < 6 && ok; ++pl) {
             const double *pn = &planes[(size_t)pl * NK_PLANE_DOUBLES];
             int a = -1, sgn = 0;
@@ -827,12 +830,14 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
             const double side = (m->bbox[3 + b] - m->bbox[b]) * (m->bbox[3 + c] - m->bbox[c]);
             if (!(fabs(area - side) <= 1e-9 * side) || fct0 < 0 || fct0 >= m->Fc) ok = false;
             if (!ok) break;
-            d.box_k[w] = pn[3]; d.box_facet[w] = fct0; d.box_face0[w] = face0;
+            d.box_k[w] = pn[3];
+            box_facet[w] = fct0;
+            d.box_ids = (d.box_ids & ~(0xFFull << (8 * w))) | ((uint64_t)(fct0 & 15) << (8 * w)) | ((uint64_t)(face0 & 15) << (8 * w + 4));
         }
         if (ok && seen == 63) {
             // one facet per wall
             int fm = 0;
-            for (int w = 0; w < 6; ++w) fm |= 1 << d.box_facet[w];
+            for (int w = 0; w < 6; ++w) fm |= 1 << box_facet[w];
             ctx->mesh_box = fm == 63;
         }
     }
@@ -1078,7 +1083,7 @@ int nk_set_params(nk_ctx *ctx, const nk_params *p) {
     NK_ARG(p->dt > 0, "nk_set_params: dt must be positive");
     ctx->params = *p;
     NkDev &d = ctx->d;
-    d.dt = p->dt; d.norm_fixed = p->norm_fixed; d.particle_density = p->particle_density;
+    d.dt = p->dt; d.inv_dt = 1.0 / p->dt; d.norm_fixed = p->norm_fixed; d.particle_density = p->particle_density;
     d.T_ref_local = p->T_ref_local; d.T_ref = p->T_ref;
     ctx->have_params = true;
     return NK_OK;

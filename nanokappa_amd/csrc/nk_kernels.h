@@ -586,15 +586,23 @@ struct NkOut {
     }
     // the same in two halves (plain cursor only): the slots are taken now, the stores are issued later (the sweep's tile commit)
     __device__ __forceinline__ int reserve(int rank, int n) { const int o = wout + rank; wout += n; return o; }
+    // one slot's fields from ONE address (NkBlock): the stores differ by immediate offsets
+    template <bool BOX>
+    static __device__ __forceinline__ void put_slot(const NkDev &d, int64_t i, double px, double py, double pz, double pocc, double pnts,
+                                                    uint32_t pw0, unsigned long long ppid) {
+        typedef NkBlock<!BOX, PID> B;
+        double *q = B::slot(d.x.p, i);
+        NK_ST(q, px); NK_ST(q + B::O_Y, py); NK_ST(q + B::O_Z, pz); NK_ST(q + B::O_OCC, pocc);
+        if (!BOX) NK_ST(q + B::O_NTS, pnts);
+        if (PID) NK_ST(reinterpret_cast<unsigned long long *>(q + B::O_PID), ppid);
+        NK_ST(B::word(d.x.p, i), pw0);
+    }
     template <bool BOX = false>
     __device__ __forceinline__ void store(const NkDev &d, int64_t base, bool put, int o, double px, double py, double pz, double pocc,
                                           double pnts, uint32_t pw0, unsigned long long ppid) {
         if (put) {
-            if (o < d.segcap) {
-                const NkSlot q = nk_slot(d, base + o);
-                NK_ST(d.x.p + q.od, px); NK_ST(d.y.p + q.od, py); NK_ST(d.z.p + q.od, pz); NK_ST(d.occ.p + q.od, pocc); if (!BOX) NK_ST(d.nts.p + q.od, pnts); NK_ST(d.w0.p + q.ow, pw0);
-                if (PID) NK_ST(d.pid.p + q.od, ppid);
-            } else atomicOr(d.overflow, 2);     // segment full
+            if (o < d.segcap) put_slot<BOX>(d, base + o, px, py, pz, pocc, pnts, pw0, ppid);
+            else atomicOr(d.overflow, 2);     // segment full
         }
     }
     // lanes with `put` append their particle (rank = position among them, n = how many); a full tile leaves at once
@@ -604,11 +612,8 @@ struct NkOut {
         if (!NK_OUT_RING) {                           // straight to the write cursor
             if (put) {
                 const int o = wout + rank;
-                if (o < d.segcap) {
-                    const NkSlot q = nk_slot(d, base + o);
-                    NK_ST(d.x.p + q.od, px); NK_ST(d.y.p + q.od, py); NK_ST(d.z.p + q.od, pz); NK_ST(d.occ.p + q.od, pocc); if (!BOX) NK_ST(d.nts.p + q.od, pnts); NK_ST(d.w0.p + q.ow, pw0);
-                    if (PID) NK_ST(d.pid.p + q.od, ppid);
-                } else atomicOr(d.overflow, 2);     // segment full
+                if (o < d.segcap) put_slot<BOX>(d, base + o, px, py, pz, pocc, pnts, pw0, ppid);
+                else atomicOr(d.overflow, 2);     // segment full
             }
             wout += n;
             return;
@@ -708,6 +713,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: segment bookkeeping lives in scalar registers
     const int rep = lane & (NK_NREP - 1);
     const uint32_t lbmask = (1u << d.lb) - 1u;
+    NkBoxWalls bw;
+    if (BOX) bw.load(d);
     double2 *lrec = reinterpret_cast<double2 *>(L.lrec) + wave * d.nlrec * NK_LREC_STRIDE;
     // the wave's carry in LDS: x y z occ nts cts [64] each, then (ids) pid [64], then the words w0, evc and (ids) gm [64] each
     double *const cX = L.carry ? L.carry + wave * NK_CARRY_DOUBLES(PID ? 3 : 2) : nullptr;
@@ -771,21 +778,24 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 // (the counter retires in order), and it never touches a set between its loads and the wait: the set is live, and
                 // only `arrived` reads it (tests/test_isa_inflight.py walks the assembly for any instruction that does; a copy of a
                 // set in flight would also be garbage in every GPU parity test).
-                const uint32_t *pw = d.w0.tile(i0, lane);
-                const double *px = d.x.tile(i0, lane), *py = d.y.tile(i0, lane), *pz = d.z.tile(i0, lane), *po = d.occ.tile(i0, lane), *pn = d.nts.tile(i0, lane);
+                typedef NkBlock<!BOX, PID> B;
+                const double *px = B::tile(d.x.p, i0, lane), *py = px + B::O_Y, *pz = px + B::O_Z, *po = px + B::O_OCC, *pn = px + B::O_NTS;
+                const uint32_t *pw = B::word(d.x.p, i0) + lane;
                 asm volatile("global_load_dword %0, %1, off" : "=v"(b.w0) : "v"(pw) : "memory");
                 asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.x) : "v"(px) : "memory");
                 asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.y) : "v"(py) : "memory");
                 asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.z) : "v"(pz) : "memory");
                 asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.occ) : "v"(po) : "memory");
                 asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.nts) : "v"(pn) : "memory");
-                if (PID) { const uint64_t *pp = d.pid.tile(i0, lane); asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.pid) : "v"(pp) : "memory"); }
+                if (PID) { const double *pp = px + B::O_PID; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.pid) : "v"(pp) : "memory"); }
                 return;
             }
             if (r + lane < count) {                       // (one tile ahead, the compiler's own counting: only what will be used)
-                b.w0 = NK_LD(d.w0.tile(i0, lane)); b.x = NK_LD(d.x.tile(i0, lane)); b.y = NK_LD(d.y.tile(i0, lane)); b.z = NK_LD(d.z.tile(i0, lane)); b.occ = NK_LD(d.occ.tile(i0, lane));
-                if (!BOX) b.nts = NK_LD(d.nts.tile(i0, lane));
-                if (PID) b.pid = NK_LD(d.pid.tile(i0, lane));
+                typedef NkBlock<!BOX, PID> B;
+                const double *q = B::tile(d.x.p, i0, lane);     // ONE address; the fields at immediate offsets
+                b.w0 = NK_LD(B::word(d.x.p, i0) + lane); b.x = NK_LD(q); b.y = NK_LD(q + B::O_Y); b.z = NK_LD(q + B::O_Z); b.occ = NK_LD(q + B::O_OCC);
+                if (!BOX) b.nts = NK_LD(q + B::O_NTS);
+                if (PID) b.pid = NK_LD(reinterpret_cast<const unsigned long long *>(q + B::O_PID));
             }
         };
         // the set's tile is there: everything but the loads issued last -- the other set's -- has retired
@@ -881,7 +891,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
             // ---- commit: final particles -> tally + compacted store; boundary particles -> the carry
             // (box store: the reference's "n_timesteps < 0" read off the position; a particle whose last cast missed -- the
             // reference's n_timesteps = inf -- never has an event)
-            const bool ev = BOX ? (act && (w0 & NK_LOST) == 0u && nk_box_out(d, x, y, z, vx, vy, vz)) : (act && nts < 0.0);
+            const bool ev = BOX ? (act && (w0 & NK_LOST) == 0u && nk_box_out(bw, x, y, z, vx, vy, vz)) : (act && nts < 0.0);
             const bool done = act && !ev;
             const unsigned long long mD = __ballot(done), mE = __ballot(ev);
             if (done) nk_tally_one(d, L.tb, L.bins, x, y, z, occ, omega, E0, vx, vy, vz, do_flux, rep);
@@ -959,7 +969,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
                 }
                 p.facet = (int)(cw0 >> d.lb) - 1;
                 // box store: a particle's FIRST event of the step is the wall it lies beyond (the carry holds no hit for it yet)
-                if (BOX && eact && evc == 0u) nk_box_first_hit(d, p.x, p.y, p.z, p.vx, p.vy, p.vz, p.nts, p.facet);
+                if (BOX && eact && evc == 0u) nk_box_first_hit(bw, d.inv_dt, p.x, p.y, p.z, p.vx, p.vy, p.vz, p.nts, p.facet);
                 if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, cpid, step);
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
 #ifdef NK_STAMPS

@@ -324,20 +324,21 @@ static int box_out(const nko_params *p, const double x[3], const double v[3]) {
     }
     return 0;
 }
-/* the wall it crossed first, Mesh.py:816-818 on the walls it lies beyond; timesteps from the end of the step (nk_box_first_hit) */
+/* the wall it crossed first, Mesh.py:816-818 on the walls it lies beyond; timesteps from the end of the step.  num = x.n + k and
+ * den = v.n are both positive for such a wall; the earliest crossing = the largest num / den is picked on the cross products
+ * (the engine's nk_box_first_hit selects the same way: no division per wall), the lowest face index among equals (:846-848) */
 static void box_first_hit(const nko_params *p, const double x[3], const double v[3], double *nts, int32_t *facet) {
-    double tb = INFINITY;
+    double nb = -1.0, db = 1.0;
     int32_t fb = -1, f0b = 0x7fffffff;
     for (int a = 0; a < 3; ++a) {
-        double num, den;
-        int w;
-        if (v[a] > 0.0 && x[a] > -p->box_k[2 * a + 1]) { num = x[a] + p->box_k[2 * a + 1]; den = v[a]; w = 2 * a + 1; }
-        else if (v[a] < 0.0 && x[a] < p->box_k[2 * a]) { num = -x[a] + p->box_k[2 * a]; den = -v[a]; w = 2 * a; }
-        else continue;
-        const double t = -num / den;
-        if (t < tb || (t == tb && p->box_face0[w] < f0b)) { tb = t; fb = p->box_facet[w]; f0b = p->box_face0[w]; }
+        const int fwd = v[a] > 0.0;
+        const double num = fwd ? x[a] - (-p->box_k[2 * a + 1]) : p->box_k[2 * a] - x[a];   /* x.n + k of the wall it flies towards */
+        const double den = fabs(v[a]);                                                     /* v.n of that wall */
+        const int w = 2 * a + fwd;
+        const double l = num * db, r = nb * den;
+        if (num > 0.0 && den > 0.0 && (l > r || (l == r && p->box_face0[w] < f0b))) { nb = num; db = den; fb = p->box_facet[w]; f0b = p->box_face0[w]; }
     }
-    *nts = tb / p->dt;
+    *nts = -(nb / db) / p->dt;                                            /* t = -num / den (:818), n_timesteps = t / dt */
     *facet = fb;
 }
 
