@@ -409,14 +409,24 @@ __device__ __forceinline__ double nk_E_of_T(const NkDev &d, double T) {
 // lifetime_function = RegularGridInterpolator((T,q,j), tau) at integer (q,j): linear in tau along T (Phonon.py:336).
 // Out-of-table T gives NaN (the reference raises ValueError there).  ta, tb, tc are the three rows packed into the
 // particle's mode record (two grid intervals around the live temperature range); anything else reads the full table.
+// The packed window's grid values and reciprocal widths.  park = true (the sweep) keeps them in VECTOR registers: as kernel
+// arguments they are scalars, the sweep has more scalars than scalar registers, and every use of a parked one costs a
+// v_readlane per dword and basic block (see NkBoxWalls).
+struct NkTauWin {
+    double g0, g1, g2, i0, i1;
+    __device__ __forceinline__ void load(const NkDev &d, bool park) {
+        g0 = d.tau_g[0]; g1 = d.tau_g[1]; g2 = d.tau_g[2]; i0 = d.tau_ig[0]; i1 = d.tau_ig[1];
+        if (park) asm volatile("" : "+v"(g0), "+v"(g1), "+v"(g2), "+v"(i0), "+v"(i1));
+    }
+};
 template <class SegModes>
-__device__ __forceinline__ double nk_lifetime(const NkDev &d, double ta, double tb, double tc, double T, const SegModes &sm, int idx) {
+__device__ __forceinline__ double nk_lifetime(const NkDev &d, const NkTauWin &w, double ta, double tb, double tc, double T, const SegModes &sm, int idx) {
     // Fast path: T inside the packed window (g0, g2].  searchsorted-left - 1 puts T in (g_k, g_k+1] at interval k; grid
-    // values and reciprocal widths come from scalar registers, lifetimes from the mode record.
-    if (T > d.tau_g[0] && T <= d.tau_g[2]) {
-        const bool b = T > d.tau_g[1];
-        const double glo = b ? d.tau_g[1] : d.tau_g[0];
-        const double ig = b ? d.tau_ig[1] : d.tau_ig[0];
+    // values and reciprocal widths come from registers, lifetimes from the mode record.
+    if (T > w.g0 && T <= w.g2) {
+        const bool b = T > w.g1;
+        const double glo = b ? w.g1 : w.g0;
+        const double ig = b ? w.i1 : w.i0;
         const double t0 = b ? tb : ta, t1 = b ? tc : tb;
         const double y = (T - glo) * ig;
         return t0 * (1.0 - y) + t1 * y;

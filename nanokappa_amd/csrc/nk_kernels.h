@@ -288,11 +288,11 @@ __device__ __forceinline__ NkSegModes nk_seg_modes(const NkDev &d, int seg) {
 // Deferred lifetime_scattering (Population.py:1701-1710) for one particle.
 // The mode record is passed as two 32-byte halves {omega, vx, vy, vz} {E0, tau0..tau2} (two dwordx4 pairs, no struct copy).
 template <bool RBF = true>
-__device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const double4 &ra, const double4 &rb, double x,
+__device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const NkTauWin &tw, const double4 &ra, const double4 &rb, double x,
                                            double y, double z, double occ, const NkSegModes &sm, int idx) {
     double invT;
     const double T = nk_interp_T<RBF>(d, L.tb, x, y, z, invT);
-    const double tau = nk_lifetime(d, rb.y, rb.z, rb.w, T, sm, idx);
+    const double tau = nk_lifetime(d, tw, rb.y, rb.z, rb.w, T, sm, idx);
     const double n0 = (T > 0.0) ? nk_be(ra.x * d.c_hk, rb.x, invT, d.invT0) : 0.0;
     return (tau > 0.0) ? n0 + (occ - n0) * nk_exp(-d.dt * nk_rcp(tau)) : n0;
 }
@@ -675,6 +675,9 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 #ifndef NK_PREFETCH2
 #define NK_PREFETCH2 0
 #endif
+#ifndef NK_PARK_TAU
+#define NK_PARK_TAU 1           // the sweep keeps the lifetime window's five doubles in vector registers (NkTauWin)
+#endif
 #ifndef NK_PRIO_ROT
 #define NK_PRIO_ROT 0           // log2 of the tiles between two steps of the sweep's issue-priority rotation (0 = off)
 #endif
@@ -715,6 +718,8 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
     const uint32_t lbmask = (1u << d.lb) - 1u;
     NkBoxWalls bw;
     if (BOX) bw.load(d);
+    NkTauWin tw;
+    tw.load(d, NK_PARK_TAU != 0);
     double2 *lrec = reinterpret_cast<double2 *>(L.lrec) + wave * d.nlrec * NK_LREC_STRIDE;
     // the wave's carry in LDS: x y z occ nts cts [64] each, then (ids) pid [64], then the words w0, evc and (ids) gm [64] each
     double *const cX = L.carry ? L.carry + wave * NK_CARRY_DOUBLES(PID ? 3 : 2) : nullptr;
@@ -879,7 +884,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
 #endif
                 NK_STAMP(0);
                 if (act && !newborn) {
-                    if (do_relax) occ = nk_relax<RBF>(d, L, ra, rb, x, y, z, occ, sm, idx);
+                    if (do_relax) occ = nk_relax<RBF>(d, L, tw, ra, rb, x, y, z, occ, sm, idx);
                     x += vx * d.dt; y += vy * d.dt; z += vz * d.dt;                 // drift, Population.py:793
                     if (!BOX) nts -= 1.0;                                           // :795
                 }
@@ -1478,6 +1483,8 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d, int 
     NkLds L;
     nk_lds_setup<0, 0>(d, smem, L);
     const uint32_t lbmask = (1u << d.lb) - 1u;
+    NkTauWin tw;
+    tw.load(d, false);
     for (int seg = blockIdx.x; seg < d.nseg; seg += gridDim.x) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int count = d.seg_count[seg];
@@ -1487,7 +1494,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_relax(NkDev d, int 
             const int idx = (int)(d.w0[i] & lbmask);
             const double4 *mrec = reinterpret_cast<const double4 *>(sm.rec + idx);
             const double4 ra = mrec[0], rb = mrec[1];
-            d.occ[i] = nk_relax(d, L, ra, rb, d.x[i], d.y[i], d.z[i], d.occ[i], sm, idx);
+            d.occ[i] = nk_relax(d, L, tw, ra, rb, d.x[i], d.y[i], d.z[i], d.occ[i], sm, idx);
         }
     }
 }
@@ -1786,7 +1793,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_tap_eval(NkDev d, i
     if (i >= n) return;
     switch (what) {
         case 0: out[i] = nk_occupation(d, a[i], d.modetab[mode[i]].omega, d.modetab[mode[i]].E0); break;
-        case 1: { const NkMode *rec = d.modetab + mode[i]; out[i] = nk_lifetime(d, rec->tau[0], rec->tau[1], rec->tau[2], a[i], NkPlainModes(), mode[i]); break; }
+        case 1: { const NkMode *rec = d.modetab + mode[i]; NkTauWin tw; tw.load(d, false); out[i] = nk_lifetime(d, tw, rec->tau[0], rec->tau[1], rec->tau[2], a[i], NkPlainModes(), mode[i]); break; }
         case 2: out[i] = nk_T_of_E(d, a[i]); break;
         case 3: out[i] = nk_E_of_T(d, a[i]); break;
         case 5: out[i] = nk_exp(a[i]); break;
