@@ -678,7 +678,7 @@ __device__ __forceinline__ bool nk_box_out(const NkBoxWalls &b, double x, double
 // to the rounding of the drift.
 // num and den are positive for a wall the particle lies beyond (num <= 0 for the others), so "earliest" = largest num / den
 // is decided on the cross products -- no division per wall -- and only the winner is divided (v_rcp_f64 + Newton: the quotient
-// places the hit point, it decides nothing).  The oracle's box rule selects the same way (oracle/nk_oracle.c box_first_hit).
+// places the hit point, it decides nothing).  The tests' CPU checker selects the same way.
 // one axis: the wall with normal -e_a (w = 2 a) or +e_a (w = 2 a + 1) against the best so far (nb / db, wall wb)
 __device__ __forceinline__ void nk_box_axis(double xa, double va, double lo, double hi, int wlo, uint64_t ids,
                                             double &nb, double &db, int &wb) {

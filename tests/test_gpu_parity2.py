@@ -9,22 +9,22 @@ import tempfile
 import numpy as np
 import pytest
 
-from util import rel_err, case_tables, random_population, make_oracle_sim, make_engine, allclose, same_event_rule
+from util import rel_err, case_tables, random_population, make_oracle_sim, make_engine, allclose, same_event_rule, TOL_T, TOL_X, TOL_X_LONG, TOL_NTS, TOL_OCC
 
 pytestmark = pytest.mark.gpu
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
 
 
-def compare_by_pid(p, sim, pos_atol=1e-8):
+def compare_by_pid(p, sim, pos_atol=TOL_X_LONG):
     n = sim.P.N
     assert p['pid'].shape[0] == n
     o1, o2 = np.argsort(p['pid']), np.argsort(sim.P.pid[:n])
     assert np.array_equal(p['pid'][o1], sim.P.pid[:n][o2])
     assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
     assert np.array_equal(p['facet'][o1], sim.P.facet[:n][o2])
-    assert allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=1e-10, atol=pos_atol)
-    assert allclose(p['n_timesteps'][o1], sim.P.n_ts[:n][o2], rtol=1e-9, atol=1e-9)
-    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+    assert allclose(p['positions'][o1], sim.P.pos[:n][o2], rtol=0, atol=pos_atol)
+    assert allclose(p['n_timesteps'][o1], sim.P.n_ts[:n][o2], rtol=0, atol=TOL_NTS)
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < TOL_OCC
 
 
 def compare_by_state(p, sim):
@@ -36,8 +36,8 @@ def compare_by_state(p, sim):
     o2 = np.lexsort((q[:, 2], q[:, 1], q[:, 0], sim.P.mode[:n]))
     assert np.array_equal(p['mode'][o1], sim.P.mode[:n][o2])
     assert np.array_equal(p['facet'][o1], sim.P.facet[:n][o2])
-    assert allclose(p['positions'][o1], q[o2], rtol=1e-10, atol=1e-8)
-    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < 1e-8
+    assert allclose(p['positions'][o1], q[o2], rtol=0, atol=TOL_X)
+    assert rel_err(p['occupation'][o1], sim.P.occ[:n][o2]) < TOL_OCC
 
 
 def steps_agree(eng, sim, nsteps, chunk=50):
@@ -49,7 +49,7 @@ def steps_agree(eng, sim, nsteps, chunk=50):
         for s in range(k):
             sim.run_timestep()
             assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % (done + s)
-            assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % (done + s)
+            assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=TOL_T), 'step %d' % (done + s)
         done += k
 
 
@@ -161,7 +161,7 @@ def test_other_generators_on_a_large_mesh(gen):
     for s in range(nsteps):
         sim.run_timestep()
         assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
-        assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+        assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=TOL_T), 'step %d' % s
         if gen == 2 and s > 0:
             assert t['N_emitted'][s] == t['N_leaving'][s - 1].sum()
     assert t['N_emitted'].sum() > 0
@@ -304,6 +304,6 @@ def test_engine_from_a_file_loaded_material_vs_oracle_on_reference_tables(tmp_pa
     for s in range(25):
         sim.run_timestep()
         assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
-        assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=1e-8), 'step %d' % s
+        assert allclose(t['T_sv'][s], sim.T_sv, rtol=0, atol=TOL_T), 'step %d' % s
     assert t['N_emitted'].sum() > 0 and t['N_leaving'].sum() > 0
     compare_by_state(eng.download(), sim)

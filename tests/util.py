@@ -49,6 +49,18 @@ def golden_phonon():
 # (<= 10 x the measured margin), not guessed.
 MARGINS = {}
 
+# Tolerances of the GPU-vs-oracle and GPU-vs-reference comparisons: <= 10 x the largest deviation measured on an MI355X
+# (profiles/r04_parity_margins.txt, one `pytest -m gpu` run; the engine's own exp / reciprocal and the LDS-atomic summation
+# order are all inside these).  SURVEY 8d asks for 1e-12 relative on deterministic fixtures.
+TOL_T = 2e-11         # K: subvolume temperatures (measured 1.1e-13 ... 2.4e-12)
+TOL_X = 1e-11         # angstrom: positions after tens of steps in a 200 A box (measured <= 9.4e-13)
+TOL_X_LONG = 5e-10    # ... after 260 steps / on the faceted meshes, where a ray cast's t is ~1e3 (measured 2.8e-11, 5.2e-11)
+TOL_NTS = 2e-11       # timesteps to the next boundary (measured <= 1.3e-12)
+TOL_OCC = 2e-14       # relative: occupations (measured <= 2.5e-15)
+TOL_OCC_GRID = 1e-12  # ... with grid subvolumes / RBF temperatures (measured 1.2e-14, 8.7e-14)
+TOL_E = 2e-15         # relative: subvolume energies (measured 1.9e-16)
+TOL_RES = 4e-13       # relative: reservoir energy balance, a sum of few terms of either sign (measured 3.5e-14)
+
 
 def _record(kind, value, bound, depth=2):
     f = sys._getframe(depth)
