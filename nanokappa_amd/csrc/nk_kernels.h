@@ -387,8 +387,11 @@ __device__ __forceinline__ void nk_newborn_place(const NkDev &d, double x0, doub
 // :440-443; add_reservoir_particles :525-552) and appends them BEHIND the segment's live particles, marked newborn; the
 // sweep of the same step takes them in (tally, boundary events) without relaxing or drifting them.
 // BOX (box store): no first ray cast -- the sweep reads a newborn particle's first event off its position like anyone's.
+// ahead: the emission runs in the tail launch of the step before (k_tail), i.e. before that step's update has decided on a
+// halt.  If that step's sweep has asked for one (halt[1]), this emission will be run again after the store has grown: a
+// segment it cannot fit into now is not a loss and must not raise the (sticky) overflow word.
 template <int GEOM, bool BOX = false>
-__device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsigned char *smem, int bid, int nblocks) {
+__device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsigned char *smem, int bid, int nblocks, bool ahead = false) {
 #ifdef NK_STAMPS
     const unsigned long long em_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -520,7 +523,7 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
                         d.qx[i] = x0; d.qy[i] = y0; d.qz[i] = z0; d.qocc[i] = occ; d.qnts[i] = dt_in;
                         d.qw0[i] = NK_NEWBORN | ((uint32_t)((skip == rf ? rf : -1) + 1) << d.lb) | (uint32_t)idx;
                         if (d.qpid) d.qpid[i] = pid;
-                    } else atomicOr(d.overflow, 1);
+                    } else if (!(ahead && d.halt[1])) atomicOr(d.overflow, 1);
                     continue;
                 }
                 double tc = 0.0;
@@ -543,7 +546,7 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
                     if (!BOX) d.nts.p[q.od] = na;
                     d.w0.p[q.ow] = BOX ? (NK_NEWBORN | (uint32_t)idx) : (NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx);
                     if (d.pid) d.pid.p[q.od] = pid;
-                } else atomicOr(d.overflow, 1);         // more entering particles than free slots
+                } else if (!(ahead && d.halt[1])) atomicOr(d.overflow, 1);         // more entering particles than free slots
             }
             made += spn;
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // the next chunk overwrites the scratch
@@ -1466,7 +1469,7 @@ __global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int
         int &last = *reinterpret_cast<int *>(smem + NK_WG * sizeof(double));
         nk_reduce_body(d, rows, acc, hist_row, do_flux, fuse, (int)blockIdx.x, n_reduce, sh, last);
     } else {
-        nk_emit_body<GEOM, BOX>(d, step_next, smem, (int)blockIdx.x - n_reduce, (int)gridDim.x - n_reduce);
+        nk_emit_body<GEOM, BOX>(d, step_next, smem, (int)blockIdx.x - n_reduce, (int)gridDim.x - n_reduce, true);
     }
 }
 

@@ -122,6 +122,25 @@ def test_store_grows_by_itself(case, monkeypatch):
     compare_by_pid(eng.download(), sim)
 
 
+def test_dense_emission_into_a_tight_store(monkeypatch):
+    """enter_prob >> 1 per (reservoir, mode) entry -- every entry emits dozens of particles per step -- into a store
+    with hardly any head room.  The next step's emission runs ahead in the tail launch (k_tail); when the step before it asks
+    for a halt, the segment may not hold the ahead emission: that is no loss (it is run again after the store has grown) and
+    must not surface as 'particles were dropped'.  Equal to the oracle throughout."""
+    monkeypatch.setenv('NK_TIGHT_STORE', '1')
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 20000, seed=9)
+    scale = 25.0 / float(np.max(ct['enter_prob']))                 # the largest entry emits 25 particles per step
+    assert scale > 10.0
+    sim = make_oracle_sim(ct, pos, mode, occ, counter, seed=4, cap=3000000, emit_scale=scale)
+    eng = make_engine(ct, pos, mode, occ, counter, seed=4, emit_scale=scale)
+    slots0 = eng.timing()['slots']
+    steps_agree(eng, sim, 24, chunk=8)
+    tm = eng.timing()
+    assert tm['live'] > 5 * 20000 and tm['slots'] > slots0 and tm['halts'] > 0
+    compare_by_pid(eng.download(), sim)
+
+
 @pytest.mark.parametrize('case', ['ttp', 'ttrrp'])
 def test_store_placement_choice_moves_the_store(case, monkeypatch):
     """nk_place_store (the store's allocation is timed against further candidates, the particles move into the fastest):
