@@ -43,15 +43,14 @@ def _worker(rank, world, port, out_dir, gen=0):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('gen', [0, 2])
-def test_two_rank_union_equals_single_run(tmp_path, gen):
-    """gen 0: 'constant' reservoirs (every rank advances all counters, keeps its share); gen 2: 'one_to_one' (the
-    all-reduced N_leaving of a step drives the next step's emission on every rank)."""
+@pytest.mark.parametrize('world,gen', [(2, 0), (2, 2), (4, 0), (4, 2)])
+def test_shard_union_equals_single_run(tmp_path, world, gen):
+    """Two and four ranks.  gen 0: 'constant' reservoirs (every rank advances all counters, keeps its share); gen 2:
+    'one_to_one' (the all-reduced N_leaving of a step drives the next step's emission on every rank)."""
     import torch.multiprocessing as mp
-    port = 29500 + (os.getpid() % 2000) + 7 * gen
-    mp.spawn(_worker, args=(2, port, str(tmp_path), gen), nprocs=2, join=True)
-    r0 = np.load(tmp_path / 'rank0.npz')
-    r1 = np.load(tmp_path / 'rank1.npz')
+    port = 29500 + (os.getpid() % 2000) + 7 * gen + 13 * world
+    mp.spawn(_worker, args=(world, port, str(tmp_path), gen), nprocs=world, join=True)
+    rs = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
     # single-process reference
     ct = case_tables('ttrrp')
     pos, mode, occ, counter = random_population(ct, 12000, seed=3)
@@ -61,20 +60,22 @@ def test_two_rank_union_equals_single_run(tmp_path, gen):
         sim.run_timestep()
         T_hist.append(sim.T_sv.copy())
     n = sim.P.N
-    # both ranks saw the same (global) temperatures, equal to the single run up to summation order
-    assert np.array_equal(r0['T'], r1['T'])
-    assert np.allclose(r0['T'], np.array(T_hist), rtol=0, atol=1e-9)
-    assert np.array_equal(r0['N_sv'], sim.N_sv)
-    pid = np.concatenate((r0['pid'], r1['pid']))
+    # every rank saw the same (global) temperatures, equal to the single run up to summation order
+    for r in rs[1:]:
+        assert np.array_equal(rs[0]['T'], r['T'])
+    assert np.allclose(rs[0]['T'], np.array(T_hist), rtol=0, atol=1e-11)
+    assert np.array_equal(rs[0]['N_sv'], sim.N_sv)
+    pid = np.concatenate([r['pid'] for r in rs])
     assert pid.shape[0] == n and np.unique(pid).shape[0] == n          # disjoint shards, nothing lost
     o = np.argsort(pid)
     o1 = np.argsort(sim.P.pid[:n])
     assert np.array_equal(pid[o], sim.P.pid[:n][o1])
-    assert np.array_equal(np.concatenate((r0['mode'], r1['mode']))[o], sim.P.mode[:n][o1])
-    assert np.allclose(np.concatenate((r0['pos'], r1['pos']))[o], sim.P.pos[:n][o1], rtol=1e-10, atol=1e-8)
-    assert np.allclose(np.concatenate((r0['occ'], r1['occ']))[o], sim.P.occ[:n][o1], rtol=1e-8, atol=0)
+    assert np.array_equal(np.concatenate([r['mode'] for r in rs])[o], sim.P.mode[:n][o1])
+    assert np.allclose(np.concatenate([r['pos'] for r in rs])[o], sim.P.pos[:n][o1], rtol=0, atol=1e-10)
+    assert np.allclose(np.concatenate([r['occ'] for r in rs])[o], sim.P.occ[:n][o1], rtol=1e-12, atol=0)
     # load balance of the emission split
-    assert abs(r0['pid'].shape[0] - r1['pid'].shape[0]) < 0.05 * n
+    sizes = [r['pid'].shape[0] for r in rs]
+    assert max(sizes) - min(sizes) < 0.05 * n
 
 
 def _halt_worker(rank, world, port, out_dir):
