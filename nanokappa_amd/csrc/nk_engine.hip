@@ -102,6 +102,7 @@ struct nk_ctx {
     void *pin = nullptr;           // pinned host staging of the history rows + the halt words of a batch
     size_t pin_bytes = 0;
     int32_t halt_words[4] = {0, 0, 0, 0};
+    double *racc = nullptr;        // [3][384]: the resident kernel's rotating tally accumulators (k_resident)
     double *acc = nullptr;         // [NB + 2]: tally columns, then the two halt requests that travel with them
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -412,6 +413,7 @@ void nk_destroy(nk_ctx *ctx) {
     for (void *p : ctx->allocs) hipFree(p);
     for (void *p : ctx->pallocs) hipFree(p);
     if (ctx->acc) hipFree(ctx->acc);
+    if (ctx->racc) hipFree(ctx->racc);
     if (ctx->pin) hipHostFree(ctx->pin);
     if (ctx->hist) hipFree(ctx->hist);
     if (ctx->modetab_p) hipFree(ctx->modetab_p);
@@ -905,6 +907,8 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     ctx->hist_cap = 0;
     NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)(d.NB + 2) * sizeof(double)));
     NK_HIP(hipMemset(ctx->acc, 0, (size_t)(d.NB + 2) * sizeof(double)));
+    if (!ctx->racc) NK_HIP(hipMalloc((void **)&ctx->racc, 3 * 384 * sizeof(double)));
+    NK_HIP(hipMemset(ctx->racc, 0, 3 * 384 * sizeof(double)));
     const double *p;
     NK_UP((const double *)nullptr, (size_t)(ctx->num_cu * 16) * d.NB, &p);     // >= the sweep's and k_events' persistent grids
     d.partials = (double *)p;
@@ -2020,6 +2024,118 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     return NK_OK;
 }
 
+// Small ensembles: many steps per launch (k_resident, nk_kernels.h).  OPT-IN (NK_RESIDENT=1): measured SLOWER than the launches
+// it replaces -- 1e5 particles: 0.081 (9^3 x 6 modes) / 0.092 ms (31^3 x 6) per step against 0.032 / 0.037 ms; 1e6: 0.130-0.136
+// against 0.046-0.050 (profiles/r04_notes.txt (9)): a step's device-scope barrier and its FP64 atomics on 111 shared addresses
+// cost more than the two launches and the reduce chain they save.  One rank, no rough facets, tables in LDS, not 'one_to_one', no
+// RBF temperatures, at most NK_RESIDENT_MAX slots (default 1.2e6).  Kept, with its parity tests, as the measured record of
+// that design.
+static inline bool nk_want_resident(const nk_ctx *ctx) {
+    const NkDev &d = ctx->d;
+    if (!getenv("NK_RESIDENT") || getenv("NK_NO_RESIDENT") || ctx->comm || d.nranks != 1 || d.Fr > 0 || d.mig_buf || d.qx || nk_geom_mode(ctx) != 1) return false;
+    if (d.res_gen == 2 || d.sv_interp == 3 || d.NB > 384 || d.nseg <= 0) return false;
+    const int64_t lim = getenv("NK_RESIDENT_MAX") ? atoll(getenv("NK_RESIDENT_MAX")) : 1200000;
+    return d.cap <= lim && nk_lds(ctx, true, 5) <= 160 * 1024;
+}
+#define NK_RESIDENT_CASE(B, P, lrec, STMT) { if (lrec) { auto KERNEL = k_resident<B, P, true>; STMT; } else { auto KERNEL = k_resident<B, P, false>; STMT; } }
+#define NK_RESIDENT_DISPATCH(box, pid, lrec, STMT)                                                    \
+    do {                                                                                               \
+        if (box) { if (pid) NK_RESIDENT_CASE(true, true, lrec, STMT) else NK_RESIDENT_CASE(true, false, lrec, STMT) }   \
+        else { if (pid) NK_RESIDENT_CASE(false, true, lrec, STMT) else NK_RESIDENT_CASE(false, false, lrec, STMT) }      \
+    } while (0)
+static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, int32_t *done) {
+    NkDev &d = ctx->d;
+    const int S = d.S, NB = d.NB;
+    const int HROW = NB + 2 * S + 4;
+    if (nsteps > ctx->hist_cap) {
+        if (ctx->hist) hipFree(ctx->hist);
+        ctx->hist = nullptr;
+        const int rows_alloc = nsteps < 1024 ? 1024 : nsteps;
+        NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)rows_alloc * HROW * sizeof(double)));
+        ctx->hist_cap = rows_alloc;
+    }
+    ctx->timing.batches += 1;
+    NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));
+    (void)nk_sweep_blocks(ctx);
+    const bool pid_ = (bool)d.pid, lrec_ = nk_want_lrec(ctx), box_ = d.box != 0;
+    const size_t lds = nk_lds(ctx, true, pid_ ? 5 : 4);
+    // every workgroup must be resident for the grid barrier: no more than the device holds at once (occupancy query), and no
+    // more than there are segments
+    if (lds > 64 * 1024) {                                        // more dynamic LDS than the default limit of a launch
+        hipError_t ea = hipSuccess;
+        NK_RESIDENT_DISPATCH(box_, pid_, lrec_, (ea = hipFuncSetAttribute(reinterpret_cast<const void *>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)));
+        if (ea != hipSuccess) (void)hipGetLastError();            // (the launch itself will say if it does not fit)
+    }
+    int per_cu = 1;
+    {
+        hipError_t eo = hipSuccess;
+        NK_RESIDENT_DISPATCH(box_, pid_, lrec_, (eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, NK_WG, lds)));
+        if (eo != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+        if (per_cu > 2) per_cu = 2;
+    }
+    int G = std::min(ctx->num_cu * per_cu, (d.nseg + NK_WG / 64 - 1) / (NK_WG / 64));
+    if (const char *e = getenv("NK_RESIDENT_GRID")) { const int v = atoi(e); if (v >= 1 && v < G) G = v; }   // developer probe
+    G = std::max(1, G);
+    if (ctx->evpool.empty()) { ctx->evpool.resize(16 * 4 + 2); for (auto &e : ctx->evpool) NK_HIP(hipEventCreate(&e)); }
+    hipEvent_t t0 = ctx->evpool[64], t1 = ctx->evpool[65];
+    const bool relax0 = ctx->pending_relax;
+    bool pending = ctx->pending_relax, flushed_first = false;
+    ctx->timing.emit_fused = 2;                                   // (2: emission inside the resident kernel)
+    NK_HIP(hipMemsetAsync(ctx->racc, 0, 3 * 384 * sizeof(double), ctx->stream));     // (a halted launch leaves sums behind)
+    NK_HIP(hipEventRecord(t0, ctx->stream));
+    const int ce = ctx->params.contains_every;
+    int launches = 0;
+    for (int k = 0; k < nsteps;) {
+        const int64_t stepno = ctx->step + k;
+        if (ce > 0 && (stepno % ce) == 0 && d.nS > 0) {
+            if (pending) {
+                k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(d, 1);
+                pending = false;
+                if (k == 0) flushed_first = true;
+            }
+            NK_GEOM_LAUNCH(k_contains, nk_sweep_grid(ctx), nk_lds(ctx, true), d, (uint32_t)stepno);
+        }
+        int n = nsteps - k;
+        if (ce > 0 && d.nS > 0) n = std::min<int64_t>(n, ce - (stepno % ce));
+        NK_RESIDENT_DISPATCH(box_, pid_, lrec_, (KERNEL<<<G, NK_WG, lds, ctx->stream>>>(d, (uint32_t)stepno, n, pending ? 1 : 0, ctx->params.flux_every,
+                                                                                       ctx->hist + (size_t)k * HROW, HROW, (unsigned int *)ctx->anomalies + 1, ctx->racc)));
+        NK_HIP(hipGetLastError());
+        pending = true;
+        k += n;
+        ++launches;
+    }
+    NK_HIP(hipEventRecord(t1, ctx->stream));
+    const size_t hbytes = (size_t)nsteps * HROW * sizeof(double);
+    if (hbytes + 64 > ctx->pin_bytes) {
+        if (ctx->pin) hipHostFree(ctx->pin);
+        ctx->pin = nullptr; ctx->pin_bytes = 0;
+        const size_t want = ((size_t)(nsteps < 1024 ? 1024 : nsteps)) * HROW * sizeof(double) + 64;
+        NK_HIP(hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
+        ctx->pin_bytes = want;
+    }
+    NK_HIP(hipMemcpyAsync(ctx->pin, ctx->hist, hbytes, hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipMemcpyAsync((char *)ctx->pin + ctx->pin_bytes - 64, d.halt, 16, hipMemcpyDeviceToHost, ctx->stream));
+    NK_HIP(hipStreamSynchronize(ctx->stream));
+    h.resize((size_t)nsteps * HROW);
+    memcpy(h.data(), ctx->pin, hbytes);
+    memcpy(ctx->halt_words, (char *)ctx->pin + ctx->pin_bytes - 64, 16);
+    int32_t nd = 0;
+    while (nd < nsteps && h[(size_t)nd * HROW + NB + 2 * S + 1] != 0.0) ++nd;
+    *done = nd;
+    if (nd > 0) ctx->pending_relax = true;
+    else ctx->pending_relax = relax0 && !flushed_first;
+    float ms = 0.f;
+    NK_HIP(hipEventElapsedTime(&ms, t0, t1));
+    if (nd == nsteps && nd > 0) {
+        ctx->timing.step_kernel_ms = (double)ms / nd;              // the resident kernel IS the step
+        ctx->timing.emit_kernel_ms = 0.0;
+        ctx->timing.events_kernel_ms = 0.0;
+        ctx->timing.total_ms = ms;
+    }
+    (void)launches;
+    return NK_OK;
+}
+
 int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     NK_ARG(ctx && nsteps > 0, "nk_step: bad arguments");
     int rc = nk_check_ready(ctx);
@@ -2040,7 +2156,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     double last_T[2] = {0, 0};
     while (s_out < nsteps) {
         int32_t nd = 0;
-        if ((rc = nk_step_batch(ctx, nsteps - s_out, h, &nd))) return rc;
+        if ((rc = nk_want_resident(ctx) ? nk_step_resident(ctx, nsteps - s_out, h, &nd) : nk_step_batch(ctx, nsteps - s_out, h, &nd))) return rc;
         for (int s = 0; s < nd; ++s) {
             const double *row = &h[(size_t)s * HROW];
             if (row[NB + 2 * S + 3] != 0.0) overflow |= (int)row[NB + 2 * S + 3];
@@ -2106,6 +2222,14 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
         }
     }
     ctx->timing.slots = d.cap;
+    if (overflow & 256) {                                // k_resident: its grid barrier was not met (a workgroup was not resident?)
+        uint32_t z2[2] = {0u, 0u};
+        NK_HIP(hipMemcpy(ctx->anomalies + 1, z2, 8, hipMemcpyHostToDevice));
+        int32_t z = 0;
+        NK_HIP(hipMemcpy(d.overflow, &z, 4, hipMemcpyHostToDevice));
+        ctx->err = "nk_step: the resident kernel's grid barrier timed out; set NK_NO_RESIDENT=1";
+        return NK_ERR_HIP;
+    }
     if (overflow) {
         ctx->err = "particle capacity exceeded during nk_step (reason mask " + std::to_string(overflow) +
                    "): particles were dropped; call nk_reserve with a larger capacity";

@@ -92,11 +92,13 @@ struct NkLds {
     // output ring of the sweep, NK_ORING particles per wave: x y z occ nts [pid] (doubles), then w0
     double *oring;
     unsigned int *oring_w;
+    double *colsum;                      // k_resident: column sums of the tally rows
 };
 
 // geom: 0 = no ray-casting tables, 1 = planes/faces/facets staged in LDS, 2 = read from global memory (large meshes)
 // nrf: faces of the reservoir sampling tables staged in LDS (0 = not staged); kind: 0 plain, 1 + k_emit's scratch,
-// 2 + the sweep's mode records (nlrec per wave), carry (unless the sweep is split) and output ring, 3 the same with particle ids
+// 2 + the sweep's mode records (nlrec per wave), carry (unless the sweep is split) and output ring, 3 the same with particle ids,
+// 4 / 5 = 2 / 3 + k_emit's scratch + a column-sum area (the resident kernel of small ensembles, k_resident, does both)
 #ifndef NK_LREC_STRIDE
 #define NK_LREC_STRIDE 5     // 16-byte units between the LDS copies of two mode records: 4 = packed (64 B), 5 spreads the banks
 #endif
@@ -105,15 +107,17 @@ struct NkLds {
 #endif
 #define NK_ORING (NK_OUT_RING ? 128 : 0)
 // doubles of one wave's carry: x y z occ nts cts (64 each), w0 + evc (64 words each); with ids: + pid (64), gm and slot (64 words each)
-#define NK_CARRY_DOUBLES(kind) ((kind) == 3 ? 576 : 448)
+#define NK_CARRY_DOUBLES(kind) (((kind) == 3 || (kind) == 5) ? 576 : 448)
+#define NK_COLSUM_DOUBLES 768   // k_resident: column sums of the tally rows, two halves (NB <= 384)
 __host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, int kind, int nrf, int rbfP, int nlrec = 0, int carry = 0) {
-    const bool emit = kind == 1;
+    const bool emit = kind == 1 || kind >= 4;
     int Fl = geom == 1 ? F : 0;
     int Pl = Fl ? NP : 0;
     int Fcl = geom == 1 ? Fc : 0;
     size_t nd = (size_t)S + (size_t)((rbfP + 1) & ~1) + 3 * S + ((3 * S) & 1) + 4 * (size_t)S + NK_NREP * S + NK_NREP * 3 * S + 4 * R +
                 (size_t)Fl * NK_FACE_DOUBLES + (size_t)Pl * NK_PLANE_DOUBLES + 2 * (size_t)R + 10 * (size_t)nrf +
-                (emit ? 2 * (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (size_t)(NK_WG / 64) * ((size_t)nlrec * 2 * NK_LREC_STRIDE + (carry ? NK_CARRY_DOUBLES(kind) : 0) + NK_ORING * (kind == 3 ? 6 : 5)) : 0) + 4;
+                (emit ? 2 * (size_t)(NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (size_t)(NK_WG / 64) * ((size_t)nlrec * 2 * NK_LREC_STRIDE + (carry ? NK_CARRY_DOUBLES(kind) : 0) + NK_ORING * ((kind == 3 || kind == 5) ? 6 : 5)) : 0) +
+                (kind >= 4 ? NK_COLSUM_DOUBLES : 0) + 4;
     size_t bytes = nd * 8 + (size_t)Fcl * sizeof(NkFacet) +
                    (size_t)(NK_NREP * S + R + 1 + (R + 1) + (emit ? 3 * (NK_WG / 64) * NK_EMIT_CHUNK : 0) + (kind >= 2 ? (NK_WG / 64) * NK_ORING : 0)) * 4 + 32;
     return (bytes + 15) & ~(size_t)15;
@@ -123,7 +127,7 @@ __host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int 
 // are read with ds_read, not flat loads).  Plane, face, facet and subvolume records start on 16-byte boundaries.
 template <int GEOM, int KIND>
 __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem, NkLds &L) {
-    constexpr bool EMIT = KIND == 1;
+    constexpr bool EMIT = KIND == 1 || KIND >= 4;
     const int S = d.S, R = d.R;
     const int Fl = GEOM == 1 ? d.F : 0;
     const int Pl = Fl ? d.NP : 0;
@@ -148,8 +152,9 @@ __device__ __forceinline__ void nk_lds_carve(const NkDev &d, unsigned char *smem
     if (KIND >= 2) {
         L.lrec = p; p += (NK_WG / 64) * (size_t)d.nlrec * 2 * NK_LREC_STRIDE;
         L.carry = p; p += d.qx ? 0 : (NK_WG / 64) * NK_CARRY_DOUBLES(KIND);
-        L.oring = p; p += (NK_WG / 64) * NK_ORING * (KIND == 3 ? 6 : 5);
+        L.oring = p; p += (NK_WG / 64) * NK_ORING * ((KIND == 3 || KIND == 5) ? 6 : 5);
     } else { L.lrec = nullptr; L.carry = nullptr; L.oring = nullptr; }
+    if (KIND >= 4) { L.colsum = p; p += NK_COLSUM_DOUBLES; } else L.colsum = nullptr;
     NkFacet *facets = (NkFacet *)p;
     unsigned int *u = (unsigned int *)(facets + Fcl);
     L.bins.N = u; u += NK_NREP * S;
@@ -391,15 +396,12 @@ __device__ __forceinline__ void nk_newborn_place(const NkDev &d, double x0, doub
 // halt.  If that step's sweep has asked for one (halt[1]), this emission will be run again after the store has grown: a
 // segment it cannot fit into now is not a loss and must not raise the (sticky) overflow word.
 template <int GEOM, bool BOX = false>
-__device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsigned char *smem, int bid, int nblocks, bool ahead = false) {
+__device__ __forceinline__ void nk_emit_segments(const NkDev &d, NkLds L, uint32_t step, int bid, int nblocks, bool ahead
 #ifdef NK_STAMPS
-    const unsigned long long em_t0 = __builtin_amdgcn_s_memrealtime();
+                                                 , unsigned long long em_t0, unsigned long long em_t1
 #endif
-    if (d.halt[0]) return;
-    NkLds L;
-    nk_lds_setup<GEOM, 1>(d, smem, L);
+) {
 #ifdef NK_STAMPS
-    const unsigned long long em_t1 = __builtin_amdgcn_s_memrealtime();
     unsigned long long em_t2 = 0;
 #endif
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: segment bookkeeping lives in scalar registers
@@ -567,6 +569,21 @@ __device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsi
 }
 
 template <int GEOM, bool BOX = false>
+__device__ __forceinline__ void nk_emit_body(const NkDev &d, uint32_t step, unsigned char *smem, int bid, int nblocks, bool ahead = false) {
+#ifdef NK_STAMPS
+    const unsigned long long em_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
+    if (d.halt[0]) return;
+    NkLds L;
+    nk_lds_setup<GEOM, 1>(d, smem, L);
+#ifdef NK_STAMPS
+    nk_emit_segments<GEOM, BOX>(d, L, step, bid, nblocks, ahead, em_t0, __builtin_amdgcn_s_memrealtime());
+#else
+    nk_emit_segments<GEOM, BOX>(d, L, step, bid, nblocks, ahead);
+#endif
+}
+
+template <int GEOM, bool BOX = false>
 __global__ __launch_bounds__(NK_WG) void k_emit(NkDev d, uint32_t step) {
     extern __shared__ __align__(16) unsigned char smem[];
     nk_emit_body<GEOM, BOX>(d, step, smem, (int)blockIdx.x, (int)gridDim.x);
@@ -704,17 +721,15 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 // BOX (axis-aligned box meshes, NkDev::box): the store holds no cached next hit -- no nts field to stream, no facet bits; a
 // particle has an event when its end-of-step position lies beyond a wall it flies towards (nk_box_out), and the event pass
 // evaluates that hit itself (nk_box_first_hit) before it runs the event.  72 B moved per phonon-step instead of 88.
+// The body between the LDS set-up and the flush of the tally row, for workgroup `wg` of `nwg` (k_sweep: blockIdx.x of gridDim.x;
+// the resident kernel of small ensembles calls it once per step from its own loop, k_resident).
 template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC, int FAST = 0, bool BOX = false>
-__global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
-    static_assert(!BOX || (GEOM == 1 && !SPLIT && !NK_PREFETCH2 && !NK_OUT_RING), "the box store goes with the fused sweep over LDS tables");
-    extern __shared__ __align__(16) unsigned char smem[];
+__device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t step, int do_relax, int flags, int wg, int nwg
 #ifdef NK_STAMPS
-    const unsigned long long st_entry_r = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
+                                              , unsigned long long st_entry_r
 #endif
-    if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
-    if (FAST) { d.sv_kind = 0; d.sv_interp = FAST - 1; d.T_ref_local = 1; }
-    NkLds L;
-    nk_lds_setup<GEOM, PID ? 3 : 2>(d, smem, L);
+) {
+    static_assert(!BOX || (GEOM == 1 && !SPLIT && !NK_PREFETCH2 && !NK_OUT_RING), "the box store goes with the fused sweep over LDS tables");
     const bool do_flux = (flags & 1) != 0;          // flags: 1 = heat-flux step
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: segment bookkeeping lives in scalar registers
     const int rep = lane & (NK_NREP - 1);
@@ -728,11 +743,11 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
     double *const cX = L.carry ? L.carry + wave * NK_CARRY_DOUBLES(PID ? 3 : 2) : nullptr;
     double *const cP = cX + 6 * 64;
     uint32_t *const cW = reinterpret_cast<uint32_t *>(cX + (PID ? 7 : 6) * 64);
-    const int nwaves = gridDim.x * (NK_WG / 64);
+    const int nwaves = nwg * (NK_WG / 64);
 #if NK_PRIO_ROT
-    const int prio_phase = (int)(blockIdx.x / (gridDim.x > 3 ? (gridDim.x + 3) / 4 : 1));     // quarter of the grid = dispatch age
+    const int prio_phase = (int)(wg / (nwg > 3 ? (nwg + 3) / 4 : 1));     // quarter of the grid = dispatch age
 #endif
-    for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
+    for (int seg = wg * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
         const int64_t base = (int64_t)seg * d.segcap;
         const int nnew = d.R > 0 ? d.seg_new[seg] : 0;
         const int count = d.seg_count[seg] + nnew;
@@ -1049,10 +1064,26 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
             }
         }
     }
+}
+template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC, int FAST = 0, bool BOX = false>
+__global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) void k_sweep(NkDev d, uint32_t step, int do_relax, int flags) {
+    extern __shared__ __align__(16) unsigned char smem[];
+#ifdef NK_STAMPS
+    const unsigned long long st_entry_r = __builtin_amdgcn_s_memrealtime();   // 100 MHz, the same counter on every CU
+#endif
+    if (d.halt[0]) return;                          // an earlier step of this call asked for a larger store (nk_device.h)
+    if (FAST) { d.sv_kind = 0; d.sv_interp = FAST - 1; d.T_ref_local = 1; }
+    NkLds L;
+    nk_lds_setup<GEOM, PID ? 3 : 2>(d, smem, L);
+#ifdef NK_STAMPS
+    nk_sweep_body<GEOM, ROUGH, RBF, PID, SPLIT, LREC, FAST, BOX>(d, L, step, do_relax, flags, (int)blockIdx.x, (int)gridDim.x, st_entry_r);
+#else
+    nk_sweep_body<GEOM, ROUGH, RBF, PID, SPLIT, LREC, FAST, BOX>(d, L, step, do_relax, flags, (int)blockIdx.x, (int)gridDim.x);
+#endif
     nk_lds_flush(d, L, blockIdx.x);
 #ifdef NK_STAMPS
-    if (d.stamps && lane == 0) {
-        const int seg0 = blockIdx.x * (NK_WG / 64) + wave;
+    if (d.stamps && (threadIdx.x & 63) == 0) {
+        const int seg0 = blockIdx.x * (NK_WG / 64) + (threadIdx.x >> 6);
         if (seg0 < d.nseg) d.stamps[((int64_t)d.nseg + seg0) * 8 + 3] = __builtin_amdgcn_s_memrealtime();   // the wave is through
     }
 #endif
@@ -1336,22 +1367,11 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
     }
 }
 
-// Normalise, invert E(T), publish the new subvolume temperatures, history row: calculate_energy (Population.py:719-728)
-// + refresh_temperatures (:692), run by ONE workgroup.
-// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, row_valid, halt, overflow
-// acc[NB] / acc[NB + 1] (summed over the ranks like the tallies) > 0: some segment could overflow at the next step / cannot
-// take its migrants -> raise the halt word,
-// on every rank at the same step.
-__device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc, double *hist_row, int do_flux) {
-    // One workgroup, so everything here is a chain of memory latencies: the E(T) / T(E) tables are read as one 4-point
-    // window around the old temperature (T moves by a small fraction of the 0.1 K table step per timestep; the general
-    // search is the fallback).
-    const int tid = threadIdx.x, nth = blockDim.x;
-    const int S = d.S, NB = d.NB, n = d.nE;
-    const double Ta = d.Tarr[0], Tb = d.Tarr[1], Tz = d.Tarr[n - 1], Ea = d.Earr[0], Ez = d.Earr[n - 1];
-    for (int t = tid; t < S; t += nth) {
-        const double Eraw = acc[t], Ns = acc[S + t];
-        const double Told = d.T_ref_local ? d.T_sv[t] : d.T_ref;
+// One subvolume of the update: normalise the raw energy sum, add the reference E(T_old), invert to T (calculate_energy
+// Population.py:719-728, refresh_temperatures :692).  Ta, Tb, Tz, Ea, Ez: first two / last entries of the E(T) table.
+__device__ __forceinline__ void nk_update_sv(const NkDev &d, double Eraw, double Ns, double Told, int t, double Ta, double Tb, double Tz,
+                                             double Ea, double Ez, double &Tnew_out, double &E_out) {
+    const int n = d.nE;
         double norm;
         if (d.norm_fixed) norm = d.active_modes / (d.particle_density * d.sv_volume[t]);
         else { norm = d.active_modes / Ns; if (isnan(norm)) norm = 0.0; }
@@ -1384,6 +1404,25 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
             const double ylo = c == 0 ? wT[0] : (c == 1 ? wT[1] : wT[2]), yhi = c == 0 ? wT[1] : (c == 1 ? wT[2] : wT[3]);
             Tnew = (yhi - ylo) / (xhi - xlo) * (E - xlo) + ylo;
         } else { int io; Tnew = nk_interp_lin_hint(d.Earr, d.Tarr, n, E, it, io); }
+        Tnew_out = Tnew;
+        E_out = E;
+}
+// Normalise, invert E(T), publish the new subvolume temperatures, history row: calculate_energy (Population.py:719-728)
+// + refresh_temperatures (:692), run by ONE workgroup.
+// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, row_valid, halt, overflow
+// acc[NB] / acc[NB + 1] (summed over the ranks like the tallies) > 0: some segment could overflow at the next step / cannot
+// take its migrants -> raise the halt word,
+// on every rank at the same step.
+__device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc, double *hist_row, int do_flux) {
+    // One workgroup, so everything here is a chain of memory latencies: the E(T) / T(E) tables are read as one 4-point
+    // window around the old temperature (T moves by a small fraction of the 0.1 K table step per timestep; the general
+    // search is the fallback).
+    const int tid = threadIdx.x, nth = blockDim.x;
+    const int S = d.S, NB = d.NB, n = d.nE;
+    const double Ta = d.Tarr[0], Tb = d.Tarr[1], Tz = d.Tarr[n - 1], Ea = d.Earr[0], Ez = d.Earr[n - 1];
+    for (int t = tid; t < S; t += nth) {
+        double Tnew, E;
+        nk_update_sv(d, acc[t], acc[S + t], d.T_ref_local ? d.T_sv[t] : d.T_ref, t, Ta, Tb, Tz, Ea, Ez, Tnew, E);
         hist_row[NB + t] = Tnew;
         hist_row[NB + S + t] = E;
         d.T_sv[t] = Tnew;
@@ -1470,6 +1509,132 @@ __global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int
         nk_reduce_body(d, rows, acc, hist_row, do_flux, fuse, (int)blockIdx.x, n_reduce, sh, last);
     } else {
         nk_emit_body<GEOM, BOX>(d, step_next, smem, (int)blockIdx.x - n_reduce, (int)gridDim.x - n_reduce, true);
+    }
+}
+
+// =============================================================================== small ensembles: the resident kernel
+// Config 1's own size (1e5 particles: 3.6 MB of state) spends a step in launches and latency chains -- k_sweep 22 us + k_tail
+// 24 us for a few microseconds of arithmetic (round 3).  Here ONE launch runs many steps: the workgroups stay resident, the
+// read-only tables are staged in LDS once, and a step is  emission -> sweep -> the workgroup's tally sums added to a global
+// accumulator (FP64 atomics) -> grid barrier -> every workgroup reads the totals and inverts E -> T itself (redundantly: no
+// second barrier, no broadcast) -> next step.  (First version: every workgroup wrote its row and summed all G rows itself, in a
+// fixed order: G x G x NB coherent loads per step -- 0.100 ms per step at 1e5 particles, slower than the launches it replaced.)
+// The accumulator rotates over three copies: step s adds to copy s % 3, everybody reads it after the barrier, and workgroup 0
+// clears copy (s + 2) % 3, which nobody touches until step s + 2 has passed the next barrier.
+// The only data that crosses workgroups is the tally rows (the S-vector coupling of refresh_temperatures, Population.py:685-702);
+// a segment is swept by the same wave at every step.  Same device functions as the launch-per-step path (nk_emit_segments,
+// nk_sweep_body, nk_update_sv); only the order in which the workgroups' tally sums are added differs from the launch-per-step
+// path's -- and from run to run (atomics): subvolume energies agree to the last bits, not bit for bit.
+// Conditions (host, nk_step_resident): one rank, no rough facets (their migrants cross segments), small mesh, not 'one_to_one',
+// no RBF temperatures; contains_check steps start a new launch.
+// The barrier: arrival counter + generation word in device memory, agent-scope atomics; a release fence before and an acquire
+// fence after it make the rows visible across the XCDs' L2s.  Every workgroup must be resident: the grid is at most one
+// workgroup per CU.  A barrier that is not met within ~2 s gives up (overflow bit 256) instead of hanging the device.
+__device__ __forceinline__ bool nk_grid_barrier(unsigned int *bar, int G) {
+    __syncthreads();
+    int ok = 1;
+    if (threadIdx.x == 0) {
+        __threadfence();
+        const unsigned int gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)G - 1u) {
+            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            int spins = 0;
+            while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > 2000000) { ok = 0; break; }
+            }
+        }
+        __threadfence();
+    }
+    ok = __syncthreads_and(ok);
+    __threadfence();                                  // every wave: its own acquire
+    return ok != 0;
+}
+template <bool BOX, bool PID, bool LREC>
+__global__ __launch_bounds__(NK_WG, 2) void k_resident(NkDev d, uint32_t step0, int nsteps, int relax0, int flux_every, double *hist, int hrow,
+                                                       unsigned int *bar, double *racc) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    if (d.halt[0]) return;
+    NkLds L;
+    nk_lds_setup<1, PID ? 5 : 4>(d, smem, L);
+    const int tid = threadIdx.x, wg = (int)blockIdx.x, G = (int)gridDim.x;
+    const int S = d.S, R = d.R, NB = d.NB, a = d.sv_axis;
+    double *Tsv = const_cast<double *>(L.tb.Tsv);
+    NkSv *sv = const_cast<NkSv *>(L.tb.sv);
+    const int nE = d.nE;
+    const double Ta = d.Tarr[0], Tb = d.Tarr[1], Tz = d.Tarr[nE - 1], Ea = d.Earr[0], Ez = d.Earr[nE - 1];
+    for (int s = 0; s < nsteps; ++s) {
+        const uint32_t step = step0 + (uint32_t)s;
+        const int do_flux = (flux_every > 0 && ((step + 1u) % (uint32_t)flux_every) == 0u) ? 1 : 0;
+#ifdef NK_STAMPS
+        if (R > 0) nk_emit_segments<1, BOX>(d, L, step, wg, G, false, 0ull, 0ull);
+        nk_sweep_body<1, false, false, PID, false, LREC, 0, BOX>(d, L, step, s == 0 ? relax0 : 1, do_flux, wg, G, 0ull);
+#else
+        if (R > 0) nk_emit_segments<1, BOX>(d, L, step, wg, G, false);
+        nk_sweep_body<1, false, false, PID, false, LREC, 0, BOX>(d, L, step, s == 0 ? relax0 : 1, do_flux, wg, G);
+#endif
+        // this workgroup's tally sums (the row of nk_lds_flush) -> the step's accumulator
+        __syncthreads();
+        {
+            double *acc = racc + (size_t)(step % 3u) * 384;
+            for (int b = tid; b < NB; b += NK_WG) {
+                double v = 0.0;
+                if (b < S) { for (int r = 0; r < NK_NREP; ++r) v += L.bins.E[r * S + b]; }
+                else if (b < 2 * S) { unsigned int c = 0; for (int r = 0; r < NK_NREP; ++r) c += L.bins.N[r * S + (b - S)]; v = (double)c; }
+                else if (b < 5 * S) { const int k = b - 2 * S; for (int r = 0; r < NK_NREP; ++r) v += L.bins.flux[r * 3 * S + k]; }
+                else if (b < 5 * S + R) v = (double)L.bins.nleave[b - 5 * S];
+                else if (b < 5 * S + 2 * R) v = L.bins.resb[4 * (b - 5 * S - R)];
+                else if (b < 5 * S + 5 * R) { const int k = b - 5 * S - 2 * R; v = L.bins.resb[4 * (k / 3) + 1 + (k % 3)]; }
+                else v = (double)L.bins.misc[0];
+                if (v != 0.0) atomicAdd(acc + b, v);
+            }
+        }
+        if (!nk_grid_barrier(bar, G)) { if (tid == 0) atomicOr(d.overflow, 256); return; }
+        __builtin_amdgcn_s_dcache_inv();                      // (nothing uniform that this kernel writes should sit in the scalar cache; belt and braces)
+        {
+            const unsigned long long *acc = reinterpret_cast<const unsigned long long *>(racc + (size_t)(step % 3u) * 384);
+            for (int b = tid; b < NB; b += NK_WG) L.colsum[b] = __longlong_as_double((long long)__hip_atomic_load(acc + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (wg == 0) { double *z = racc + (size_t)((step + 2u) % 3u) * 384; for (int b = tid; b < NB; b += NK_WG) z[b] = 0.0; }
+        }
+        const int hreq = __hip_atomic_load(d.halt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a sweep of this step asked for head room
+        __syncthreads();
+        // ---- update (every workgroup, for its own LDS copy of the temperatures; workgroup 0 also publishes)
+        double *hrowp = hist + (size_t)s * hrow;
+        for (int t = tid; t < S; t += NK_WG) {
+            double Tnew, E;
+            nk_update_sv(d, L.colsum[t], L.colsum[S + t], d.T_ref_local ? Tsv[t] : d.T_ref, t, Ta, Tb, Tz, Ea, Ez, Tnew, E);
+            Tsv[t] = Tnew;
+            if (wg == 0) { hrowp[NB + t] = Tnew; hrowp[NB + S + t] = E; d.T_sv[t] = Tnew; }
+        }
+        if (wg == 0) {
+            for (int b = tid; b < NB; b += NK_WG) hrowp[b] = L.colsum[b];
+            if (tid == 0) {
+                hrowp[NB + 2 * S + 0] = (double)do_flux;
+                hrowp[NB + 2 * S + 1] = 1.0;
+                hrowp[NB + 2 * S + 2] = hreq ? 1.0 : 0.0;
+                hrowp[NB + 2 * S + 3] = (double)*d.overflow;
+                if (hreq) d.halt[0] = 1;
+            }
+        }
+        __syncthreads();
+        // per-subvolume records of the new temperatures, bins back to zero (what nk_lds_setup does at a launch's start)
+        for (int t = tid; t < S; t += NK_WG) {
+            const int jn = t + 1 < S ? t + 1 : t;
+            NkSv q;
+            q.c = L.tb.cen[3 * t + a]; q.T = Tsv[t];
+            q.slope = jn > t ? (Tsv[jn] - Tsv[t]) / (L.tb.cen[3 * jn + a] - L.tb.cen[3 * t + a]) : 0.0;
+            q.invT = 1.0 / Tsv[t];
+            sv[t] = q;
+        }
+        for (int i = tid; i < NK_NREP * S; i += NK_WG) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
+        for (int i = tid; i < NK_NREP * 3 * S; i += NK_WG) L.bins.flux[i] = 0.0;
+        for (int i = tid; i < 4 * R; i += NK_WG) L.bins.resb[i] = 0.0;
+        for (int i = tid; i < R; i += NK_WG) L.bins.nleave[i] = 0u;
+        if (tid == 0) L.bins.misc[0] = 0u;
+        __syncthreads();
+        if (hreq) return;                                     // the host grows the store and carries on
     }
 }
 
