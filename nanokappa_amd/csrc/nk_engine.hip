@@ -89,6 +89,10 @@ struct nk_ctx {
     std::vector<int32_t> rb_facet;
     int64_t o2o_first = 0;            // 'one_to_one': particles entering at the first step (sizes the spawn inboxes)
     bool stepped = false;             // a timestep has run (the emission ownership of a rank is fixed from then on)
+    int64_t emitted_for = -1;         // step whose emission already ran in the tail launch of the step before it (k_tail), also across
+                                      // nk_step calls: a driver that steps one by one (Population.run_timestep) then never launches k_emit;
+                                      // -1 after anything that changes the store or the tables (the emission is simply run again: its
+                                      // counters are double-buffered)
     std::vector<double> h_vg;         // host copy of the group velocities (the mode map deals the modes by their event rate)
     std::vector<int32_t> h_m2s, h_s2m;  // host copies of the mode map (NkDev::m2s / s2m), built with the segmentation
     int32_t *m2s_dev = nullptr, *s2m_dev = nullptr, *nl_dev = nullptr;
@@ -431,6 +435,7 @@ void nk_destroy(nk_ctx *ctx) {
 }
 
 int nk_set_material(nk_ctx *ctx, const nk_material *m) {
+    if (ctx) ctx->emitted_for = -1;
     NK_ARG(ctx && m, "nk_set_material: NULL argument");
     NK_ARG(m->Q > 0 && m->J > 0 && m->NT >= 2 && m->nE >= 2, "nk_set_material: bad sizes");
     NK_HIP(hipSetDevice(ctx->device));
@@ -507,6 +512,7 @@ static void nk_split_face(const double *V, int face, int max_depth, std::vector<
 }
 
 int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
+    if (ctx) ctx->emitted_for = -1;
     NK_ARG(ctx && m, "nk_set_mesh: NULL argument");
     NK_ARG(m->F > 0 && m->Fc > 0, "nk_set_mesh: empty mesh");
     NK_HIP(hipSetDevice(ctx->device));
@@ -927,6 +933,7 @@ static void nk_rbf_coefficients(nk_ctx *ctx, std::vector<double> &T) {
 }
 
 int nk_set_subvolumes(nk_ctx *ctx, const nk_subvols *s, const double *T_sv_init) {
+    if (ctx) ctx->emitted_for = -1;
     NK_ARG(ctx && s && T_sv_init, "nk_set_subvolumes: NULL argument");
     NK_ARG(s->S > 0 && s->S <= 512, "nk_set_subvolumes: S must be in [1, 512]");
     NK_ARG(ctx->have_material, "nk_set_subvolumes: call nk_set_material first");
@@ -970,6 +977,7 @@ int nk_set_subvolumes(nk_ctx *ctx, const nk_subvols *s, const double *T_sv_init)
 }
 
 int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
+    if (ctx) ctx->emitted_for = -1;
     NK_ARG(ctx && r, "nk_set_reservoirs: NULL argument");
     NK_ARG(ctx->have_material && ctx->have_mesh && ctx->have_sv, "nk_set_reservoirs: set material, mesh, subvolumes first");
     NK_ARG(r->R >= 0 && r->R <= 64, "nk_set_reservoirs: R must be in [0, 64]");
@@ -1044,6 +1052,7 @@ int nk_set_reservoirs(nk_ctx *ctx, const nk_reservoirs *r) {
 }
 
 int nk_set_rough(nk_ctx *ctx, const nk_rough *r) {
+    if (ctx) ctx->emitted_for = -1;
     NK_ARG(ctx && r, "nk_set_rough: NULL argument");
     NK_ARG(ctx->have_material && ctx->have_mesh, "nk_set_rough: set material and mesh first");
     NK_HIP(hipSetDevice(ctx->device));
@@ -1085,6 +1094,7 @@ int nk_set_rough(nk_ctx *ctx, const nk_rough *r) {
 }
 
 int nk_set_params(nk_ctx *ctx, const nk_params *p) {
+    if (ctx) ctx->emitted_for = -1;
     NK_ARG(ctx && p, "nk_set_params: NULL argument");
     NK_ARG(p->dt > 0, "nk_set_params: dt must be positive");
     ctx->params = *p;
@@ -1167,6 +1177,7 @@ static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
 // Global mode indices (rough facets): equal shares, sorted by mode (stable), so that a tile shares a few mode records.
 static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, const double *z, const int32_t *mode,
                       const double *occ, const double *n_ts, const int32_t *facet, const uint64_t *pid, uint64_t pid_offset) {
+    if (ctx) ctx->emitted_for = -1;
     NkDev &d = ctx->d;
     const int M = d.M;
     for (int64_t i = 0; i < N; ++i) NK_ARG(mode[i] >= 0 && mode[i] < M, "nk_upload_particles: mode index out of range");
@@ -1482,6 +1493,7 @@ static inline int64_t nk_tiled_count(int64_t u, int64_t nu, int64_t pid_lo, int6
 }
 static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode = nullptr, int64_t N = 0,
                               const int32_t *umodes = nullptr, int64_t nu = 0, int64_t pid_lo = 0) {
+    if (ctx) ctx->emitted_for = -1;
     NkDev &d = ctx->d;
     { int rc0 = nk_entry_tables_drop(ctx, true); if (rc0) return rc0; }
     for (void *p : ctx->pallocs) hipFree(p);
@@ -1607,6 +1619,7 @@ static int nk_ensure_inbox(nk_ctx *ctx) {
 
 // Grow every segment to `segcap_new` slots on the device (same segmentation: the particles keep their segments).
 static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
+    if (ctx) ctx->emitted_for = -1;
     NkDev &d = ctx->d;
     NK_HIP(hipStreamSynchronize(ctx->stream));
     const NkDev old = d;
@@ -1837,7 +1850,8 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     // than the 12 us they hid: 0.289 against 0.270 ms per step on config 2, profiles/r03_notes.txt (11).)
     const bool tail_emit = R > 0 && d.res_gen != 2 && !d.mig_buf && !getenv("NK_NO_TAIL_EMIT");
     const size_t lds_t = lds_e > (size_t)(NK_WG * 8 + 16) ? lds_e : (size_t)(NK_WG * 8 + 16);
-    bool emitted_ahead = false;                           // this step's emission already ran in the previous step's k_tail
+    bool emitted_ahead = tail_emit && ctx->emitted_for == ctx->step;   // this step's emission already ran in the previous step's k_tail (maybe of the call before)
+    ctx->emitted_for = -1;
     ctx->timing.emit_fused = tail_emit ? 1 : 0;
     for (int s = 0; s < nsteps; ++s) {
         const int64_t stepno = ctx->step + s;
@@ -1867,7 +1881,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         }
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
         double *hrow = ctx->hist + (size_t)s * HROW;
-        const bool ahead = tail_emit && s + 1 < nsteps;        // the next step's emission beside this step's tail
+        const bool ahead = tail_emit;                          // the next step's emission beside this step's tail (the last step's too: for the next call)
         if (ctx->comm) {
             if (ahead) NK_EMIT_LAUNCH(k_tail, NB + g_emit, lds_t, d, step + 1u, rows, ctx->acc, hrow, do_flux, 0, NB);
             else k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 0);
@@ -2002,6 +2016,11 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     int32_t nd = 0;
     while (nd < nsteps && h[(size_t)nd * HROW + NB + 2 * S + 1] != 0.0) ++nd;
     *done = nd;
+    {   // the emission that ran ahead in the last tail is good for the next call unless the batch halted (the store grows first)
+        int32_t hw_[4];
+        memcpy(hw_, ctx->halt_words, 16);
+        ctx->emitted_for = (tail_emit && nd == nsteps && !hw_[0] && !hw_[2] && !hw_[3]) ? ctx->step + nsteps : -1;
+    }
     // the deferred relaxation as the device left it: pending after any completed step; if none ran, whatever it was before,
     // unless a k_relax ahead of the first step flushed it (that kernel honours the halt word, which was clear then)
     if (nd > 0) ctx->pending_relax = true;
@@ -2055,6 +2074,7 @@ static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h,
         ctx->hist_cap = rows_alloc;
     }
     ctx->timing.batches += 1;
+    ctx->emitted_for = -1;
     NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));
     (void)nk_sweep_blocks(ctx);
     const bool pid_ = (bool)d.pid, lrec_ = nk_want_lrec(ctx), box_ = d.box != 0;
@@ -2321,6 +2341,7 @@ int nk_comm_unique_id(void *id128) {
     return NK_OK;
 }
 int nk_comm_init(nk_ctx *ctx, const void *id128, int rank, int nranks) {
+    if (ctx) ctx->emitted_for = -1;
     NK_ARG(ctx && id128 && nranks >= 1 && rank >= 0 && rank < nranks, "nk_comm_init: bad arguments");
     NK_ARG(!ctx->stepped, "nk_comm_init: must be called before the first nk_step (emission ownership is per rank)");
     NK_HIP(hipSetDevice(ctx->device));
@@ -2441,6 +2462,7 @@ extern "C" {
 // belongs to ('random_subvol': sv_first[S + 1], ascending, sv_first[0] = 0).  Replaces nk_reserve + nk_upload_particles.
 int nk_init_particles(nk_ctx *ctx, int64_t N, int64_t capacity, uint64_t pid_lo, const int32_t *unique_modes, int64_t n_unique,
                       const int64_t *sv_first) {
+    if (ctx) ctx->emitted_for = -1;
     NK_ARG(ctx && N >= 0 && unique_modes && n_unique > 0, "nk_init_particles: bad arguments");
     NK_ARG(ctx->have_material && ctx->have_mesh && ctx->have_sv, "nk_init_particles: set the material, the mesh and the subvolumes first");
     NkDev &d = ctx->d;

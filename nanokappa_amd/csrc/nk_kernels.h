@@ -299,7 +299,14 @@ __device__ __forceinline__ double nk_relax(const NkDev &d, const NkLds &L, const
     const double T = nk_interp_T<RBF>(d, L.tb, x, y, z, invT);
     const double tau = nk_lifetime(d, tw, rb.y, rb.z, rb.w, T, sm, idx);
     const double n0 = (T > 0.0) ? nk_be(ra.x * d.c_hk, rb.x, invT, d.invT0) : 0.0;
-    return (tau > 0.0) ? n0 + (occ - n0) * nk_exp(-d.dt * nk_rcp(tau)) : n0;
+    // exp(-dt / tau): where every lane of the wave has dt / tau < 1/8 (lifetimes of 8 timesteps and more -- all of the synthetic
+    // Si / Ge at dt = 1 ps, most modes of a real material) the short series of nk_exp_small does without the range reduction, the
+    // longer polynomial and the ldexp of nk_exp (truncation 3e-18 either way); a wave with one short-lived mode takes the general one
+    const double xr = -d.dt * nk_rcp(tau);
+    double er;
+    if (__builtin_expect(__ballot(tau > 0.0 && !(xr > -0.125)) == 0ull, 1)) er = nk_exp_small(xr);
+    else er = nk_exp(xr);
+    return (tau > 0.0) ? n0 + (occ - n0) * er : n0;
 }
 
 // Mesh.sample_surface on one reservoir facet (Mesh.py:923-951): face by area (np.random.choice, :937), then a uniform
