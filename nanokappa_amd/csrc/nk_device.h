@@ -719,33 +719,34 @@ __device__ __forceinline__ void nk_box_first_hit(const NkBoxWalls &b, double inv
 // of their rounding error, e = (|x| + B) 2^-20 |1 / v| per axis (B = largest box coordinate; the error proper is below
 // (|x| + B) 2^-21 |1 / v|: conversion of x and 1 / v, one subtraction, one product).  A box that is entered although the
 // exact ray misses it costs time, never a hit: the faces themselves are tested in FP64 as before.
-struct NkRayF { float x, y, z, ix, iy, iz, ex, ey, ez, cx, cy, cz; bool px, py, pz; };
+struct NkRayF { float x, y, z, ix, iy, iz, ex, ey, ez; };
+// A ray parallel to an axis (v_a == 0 exactly) gets a huge FINITE 1 / v_a instead of +-inf: the slab's entry / exit distances
+// (lo - x) 1e30 and (hi - x) 1e30 are then -huge / +huge when x lies strictly inside the slab, both > tmax when it lies outside by
+// more than the rounding margin c, and the widening e = c |1 / v| = c 1e30 makes every position in between pass -- the same
+// answers as the explicit "parallel and outside?" test of round 3 (six compares, six selects and a dozen mask operations per
+// box), with no special case.  |lo - x| < 1e5 keeps every product finite.  Conservative like before: a box that is entered
+// although the exact ray misses it costs time, never a hit.
+#define NK_RAY_BIG 1.0e30f
 __device__ __forceinline__ NkRayF nk_ray_f32(double x, double y, double z, double vx, double vy, double vz, double B) {
     NkRayF r;
     r.x = (float)x; r.y = (float)y; r.z = (float)z;
-    r.ix = (float)(1.0 / vx); r.iy = (float)(1.0 / vy); r.iz = (float)(1.0 / vz);     // +-inf for an axis-parallel ray: not used then
-    r.px = vx != 0.0; r.py = vy != 0.0; r.pz = vz != 0.0;
+    r.ix = vx != 0.0 ? (float)(1.0 / vx) : NK_RAY_BIG; r.iy = vy != 0.0 ? (float)(1.0 / vy) : NK_RAY_BIG; r.iz = vz != 0.0 ? (float)(1.0 / vz) : NK_RAY_BIG;
+    // (a component so small that 1 / v overflows a float is as good as parallel)
+    r.ix = fminf(fmaxf(r.ix, -NK_RAY_BIG), NK_RAY_BIG); r.iy = fminf(fmaxf(r.iy, -NK_RAY_BIG), NK_RAY_BIG); r.iz = fminf(fmaxf(r.iz, -NK_RAY_BIG), NK_RAY_BIG);
     const float k = 9.5367431640625e-07f;                                               // 2^-20
-    r.cx = ((float)fabs(x) + (float)B) * k; r.cy = ((float)fabs(y) + (float)B) * k; r.cz = ((float)fabs(z) + (float)B) * k;
-    r.ex = r.cx * fabsf(r.ix); r.ey = r.cy * fabsf(r.iy); r.ez = r.cz * fabsf(r.iz);
+    r.ex = ((float)fabs(x) + (float)B) * k * fabsf(r.ix); r.ey = ((float)fabs(y) + (float)B) * k * fabsf(r.iy); r.ez = ((float)fabs(z) + (float)B) * k * fabsf(r.iz);
     return r;
 }
-// Does the ray cross the box lo = (lx, ly, lz), hi = (hx, hy, hz) before tmax ?  Written without branches (four of these run
-// per visit, and a branch per axis costs more scalar bookkeeping than the arithmetic it skips): per axis both answers are
-// formed -- the slab's entry / exit distances, and for a ray parallel to the slab whether it lies outside -- and selected.
+// Does the ray cross the box lo = (lx, ly, lz), hi = (hx, hy, hz) before tmax ?  No branches, no special cases (see above).
 __device__ __forceinline__ bool nk_ray_box(float lx, float ly, float lz, float hx, float hy, float hz, const NkRayF &r, float tmax) {
-    const float inf = __builtin_inff();
     const float ax = (lx - r.x) * r.ix, bx = (hx - r.x) * r.ix;
     const float ay = (ly - r.y) * r.iy, by = (hy - r.y) * r.iy;
     const float az = (lz - r.z) * r.iz, bz = (hz - r.z) * r.iz;
-    const float nx = r.px ? fminf(ax, bx) - r.ex : -inf, fx = r.px ? fmaxf(ax, bx) + r.ex : inf;
-    const float ny = r.py ? fminf(ay, by) - r.ey : -inf, fy = r.py ? fmaxf(ay, by) + r.ey : inf;
-    const float nz = r.pz ? fminf(az, bz) - r.ez : -inf, fz = r.pz ? fmaxf(az, bz) + r.ez : inf;
+    const float nx = fminf(ax, bx) - r.ex, fx = fmaxf(ax, bx) + r.ex;
+    const float ny = fminf(ay, by) - r.ey, fy = fmaxf(ay, by) + r.ey;
+    const float nz = fminf(az, bz) - r.ez, fz = fmaxf(az, bz) + r.ez;
     const float t0 = fmaxf(fmaxf(0.0f, nx), fmaxf(ny, nz)), t1 = fminf(fminf(tmax, fx), fminf(fy, fz));
-    const int out = ((int)!r.px & ((int)(r.x < lx - r.cx) | (int)(r.x > hx + r.cx))) |
-                    ((int)!r.py & ((int)(r.y < ly - r.cy) | (int)(r.y > hy + r.cy))) |
-                    ((int)!r.pz & ((int)(r.z < lz - r.cz) | (int)(r.z > hz + r.cz)));
-    return (out == 0) & (t0 <= t1);
+    return t0 <= t1;
 }
 // The four faces of one leaf against one ray (same arithmetic and the same rounding as nk_fb_planes).
 __device__ __forceinline__ void nk_tree_leaf(const double *tree_faces, int leaf, double tol, double x, double y, double z,

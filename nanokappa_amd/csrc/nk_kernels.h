@@ -402,6 +402,177 @@ __device__ __forceinline__ void nk_newborn_place(const NkDev &d, double x0, doub
 // ahead: the emission runs in the tail launch of the step before (k_tail), i.e. before that step's update has decided on a
 // halt.  If that step's sweep has asked for one (halt[1]), this emission will be run again after the store has grown: a
 // segment it cannot fit into now is not a loss and must not raise the (sticky) overflow word.
+// One segment's emission, by the wave that owns it: evaluates the segment's (reservoir, mode) entries, builds the entering
+// particles behind the segment's live ones, writes seg_new / seg_bound; returns the number appended.  The five scratch arrays
+// hold NK_EMIT_CHUNK entries each and belong to the calling wave (k_emit: its slice of the emission scratch; a sweep that does
+// its own emission: the wave's carry, which is empty then).
+template <int GEOM, bool BOX>
+__device__ __forceinline__ int nk_emit_one(const NkDev &d, const NkLds &L, uint32_t step, int seg, int lane, unsigned int *sp_pref,
+                                           unsigned int *sp_cnt, unsigned int *sp_rm, double *sp_cv, double *sp_pr, bool ahead, bool to_queue,
+                                           int &bound_out
+#ifdef NK_STAMPS
+                                           , unsigned long long em_t0, unsigned long long em_t1, unsigned long long &em_t2
+#endif
+) {
+    const int64_t base = (int64_t)seg * d.segcap;
+    const int count = d.seg_count[seg];
+    const NkSegModes sm = nk_seg_modes(d, seg);
+    const int nent = d.res_gen != 2 ? d.R * sm.nl : 0;
+    int made = 0;                                 // particles appended so far
+    int sp_bound = 0;                             // per-lane partial sums of the entries' upper bounds
+    for (int e0 = 0; e0 < nent || (d.res_gen == 2 && e0 == 0); e0 += NK_EMIT_CHUNK) {
+        int spn = 0;
+        if (d.res_gen == 2) {
+            spn = d.sp_inbox_n[seg];
+            spn = spn < d.sp_icap ? spn : d.sp_icap;
+            sp_bound = lane == 0 ? 2 * spn + 64 : 0;
+        } else {
+            // ---- this chunk of the segment's (reservoir, mode) entries: entry e = r * nl + l, two per lane
+            unsigned int run = 0;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int e = e0 + k * 64 + lane;
+                int c = 0, cmine = 0;
+                double cv = 0.0, prob = 0.0;
+                unsigned int rm32 = 0, rl = 0;
+                if (e < nent) {
+                    const int r = e / sm.nl, l = e - r * sm.nl;
+                    rl = ((unsigned int)r << 12) | ((unsigned int)l << 18);      // c < 4096, R <= 64, l < 2^14
+                    const int64_t rm = (int64_t)r * d.M + sm.entry_mode(l);
+                    const int64_t at = ((int64_t)seg * d.R + r) * d.nlmax + l;
+                    prob = d.ep_p[at];
+                    nk_emit_entry(d, step, rm, at, prob, c, cmine, cv);
+                    rm32 = (unsigned int)rm;
+                    sp_bound += ((int)floor(prob) + 1 + d.nranks - 1) / d.nranks;
+                }
+                unsigned int v = (unsigned int)cmine;
+#pragma unroll
+                for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
+                sp_cnt[k * 64 + lane] = (unsigned int)c | rl;
+                sp_rm[k * 64 + lane] = rm32;
+                sp_cv[k * 64 + lane] = cv;
+                sp_pr[k * 64 + lane] = prob;
+                sp_pref[k * 64 + lane] = v + run - (unsigned int)cmine;
+                run += __shfl(v, 63, 64);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // LDS is in order per wave; keep the compiler honest
+            spn = (int)run;
+        }
+#ifdef NK_STAMPS
+        if (!em_t2) em_t2 = __builtin_amdgcn_s_memrealtime();     // the first chunk of entries is evaluated
+#endif
+        for (int spj = 0; spj < spn; spj += NK_TILE) {
+            const int j = spj + lane;
+            if (j >= spn) continue;
+            int64_t rm;
+            int level, r, idx;
+            double prob = 0.0, cval = 0.0;
+            uint64_t o2o = 0;
+            if (d.res_gen == 2) {
+                const uint64_t recd = d.sp_inbox[(int64_t)seg * d.sp_icap + j];
+                rm = (int64_t)((recd >> 12) & 0xFFFFFFFull);
+                level = 0;                              // 'one_to_one': entry time uniform in the step
+                o2o = recd >> 40;
+                r = (int)((uint32_t)rm / (uint32_t)d.M);                        // rm < 2^28
+                const int mode = (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
+                idx = d.part ? (int)((uint32_t)d.m2s[mode] / (uint32_t)d.nseg) : mode;
+            } else {
+                // the entry this particle belongs to: the last one whose exclusive prefix is <= j
+                int lo = 0, hi = NK_EMIT_CHUNK;
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)sp_pref[mid] <= j) lo = mid; else hi = mid; }
+                const unsigned int cw = sp_cnt[lo];
+                const int q = j - (int)sp_pref[lo], c = (int)(cw & 0xFFFu);
+                r = (int)((cw >> 12) & 0x3Fu);
+                rm = (int64_t)sp_rm[lo];
+                idx = d.part ? (int)(cw >> 18) : (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
+                cval = sp_cv[lo];
+                prob = sp_pr[lo];
+                // the q-th level this rank owns, counted down from c (nk_emit_entry's order)
+                if (d.nranks == 1) level = c - q;
+                else {
+                    const uint32_t n = (uint32_t)d.nranks;
+                    const uint32_t tq = ((uint32_t)d.rank + n - (((uint32_t)rm + step) % n)) % n;   // owned levels = tq mod n
+                    const uint32_t top = (uint32_t)c - (((uint32_t)c + n - tq) % n);                // largest owned level <= c
+                    level = (int)(top - (uint32_t)q * n);
+                }
+            }
+            const NkMode *rec = sm.rec + idx;
+            const double4 ra = *reinterpret_cast<const double4 *>(rec);
+            const double E0 = rec->E0;
+            const uint64_t pid = level > 0 ? ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level
+                                           : ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | o2o;
+            double uf, us, ur, ut;
+            nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
+            nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
+            const double iprob = level > 0 ? nk_rcp(prob) : 0.0;
+            const double dt_in = (level == 0) ? d.dt * ut                               // one_to_one :482
+                               : (level == 1) ? d.dt * (1.0 - cval * iprob)
+                                              : d.dt * (1.0 - ((double)(level - 1) + ut) * iprob);
+            double x0, y0, z0;
+            if (GEOM == 1 && d.res_lds) nk_sample_res_face(L.rf_off, L.rf_cdf, L.rf_verts, r, uf, us, ur, x0, y0, z0);
+            else nk_sample_res_face(d.res_face_off, d.res_face_cdf, d.res_face_verts, r, uf, us, ur, x0, y0, z0);
+            const double omega = ra.x, vx = ra.y, vy = ra.z, vz = ra.w;
+            const double occ = nk_be(omega * d.c_hk, E0, L.resT[2 * r + 1], d.invT0);   // Population.py:506
+            if (GEOM == 2 && to_queue) {
+                // split sweep over a face tree: the particle's first ray cast is a tree walk like any other, and k_events runs
+                // those with its lanes interleaved.  The particle goes into the segment's event queue as it stands on the
+                // reservoir -- position, entry time in the nts field, the reservoir's facet in the packed word -- and
+                // k_events finishes what follows here (nk_newborn_place)
+                const int o = made + j;
+                if (o < d.segcap) {
+                    const int64_t i = base + o;
+                    const int rf = d.res_facet[r];
+                    const NkFacet &fq = d.facets[rf];
+                    // the facet field: the reservoir's facet if the walk may skip the nodes that hold only its faces, else none
+                    const int skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
+                    d.qx[i] = x0; d.qy[i] = y0; d.qz[i] = z0; d.qocc[i] = occ; d.qnts[i] = dt_in;
+                    d.qw0[i] = NK_NEWBORN | ((uint32_t)((skip == rf ? rf : -1) + 1) << d.lb) | (uint32_t)idx;
+                    if (d.qpid) d.qpid[i] = pid;
+                } else if (!(ahead && d.halt[1])) atomicOr(d.overflow, 1);
+                continue;
+            }
+            double tc = 0.0;
+            int facet = -1;
+            int skip = NK_TREE_NO_SKIP;               // the particle starts on its reservoir's facet
+            if (GEOM == 2 && d.NG > 0) {
+                const int rf = d.res_facet[r];
+                const NkFacet &fq = d.facets[rf];
+                skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
+            }
+            if (!BOX) NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
+            const int o = count + made + j;
+            if (o < d.segcap) {
+                const int64_t i = base + o;
+                const NkSlot q = nk_slot(d, i);
+                double xa, ya, za, na;
+                nk_newborn_place(d, x0, y0, z0, vx, vy, vz, dt_in, tc, xa, ya, za, na);
+                d.x.p[q.od] = xa; d.y.p[q.od] = ya; d.z.p[q.od] = za;
+                d.occ.p[q.od] = occ;
+                if (!BOX) d.nts.p[q.od] = na;
+                d.w0.p[q.ow] = BOX ? (NK_NEWBORN | (uint32_t)idx) : (NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx);
+                if (d.pid) d.pid.p[q.od] = pid;
+            } else if (!(ahead && d.halt[1])) atomicOr(d.overflow, 1);         // more entering particles than free slots
+        }
+        made += spn;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // the next chunk overwrites the scratch
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sp_bound += __shfl_xor(sp_bound, o, 64);
+    const int room = d.segcap - count;
+    const int put = (GEOM == 2 && to_queue) ? 0 : (made < room ? made : (room > 0 ? room : 0));   // entering particles behind the segment's live ones
+    if (lane == 0) {
+        if (GEOM == 2 && to_queue) { d.seg_new[seg] = 0; d.seg_evq[seg] = made < d.segcap ? made : d.segcap; }
+        else d.seg_new[seg] = put;
+        d.seg_bound[seg] = sp_bound;
+        if (d.res_gen == 2) d.sp_inbox_n[seg] = 0;
+#ifdef NK_STAMPS
+        if (d.stamps) { unsigned long long *w = d.stamps + ((int64_t)d.nseg + seg) * 8 + 4; w[0] = em_t0; w[1] = em_t1; w[2] = em_t2; w[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+    }
+    bound_out = sp_bound;
+    return put;
+}
+
 template <int GEOM, bool BOX = false>
 __device__ __forceinline__ void nk_emit_segments(const NkDev &d, NkLds L, uint32_t step, int bid, int nblocks, bool ahead
 #ifdef NK_STAMPS
@@ -418,160 +589,12 @@ __device__ __forceinline__ void nk_emit_segments(const NkDev &d, NkLds L, uint32
     const int nwaves = nblocks * (NK_WG / 64);
     const bool to_queue = GEOM == 2 && d.NG > 0 && d.qx != nullptr;      // first casts by k_events (below)
     for (int seg = bid * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
-        const int64_t base = (int64_t)seg * d.segcap;
-        const int count = d.seg_count[seg];
-        const NkSegModes sm = nk_seg_modes(d, seg);
-        const int nent = d.res_gen != 2 ? d.R * sm.nl : 0;
-        int made = 0;                                 // particles appended so far
-        int sp_bound = 0;                             // per-lane partial sums of the entries' upper bounds
-        for (int e0 = 0; e0 < nent || (d.res_gen == 2 && e0 == 0); e0 += NK_EMIT_CHUNK) {
-            int spn = 0;
-            if (d.res_gen == 2) {
-                spn = d.sp_inbox_n[seg];
-                spn = spn < d.sp_icap ? spn : d.sp_icap;
-                sp_bound = lane == 0 ? 2 * spn + 64 : 0;
-            } else {
-                // ---- this chunk of the segment's (reservoir, mode) entries: entry e = r * nl + l, two per lane
-                unsigned int run = 0;
-#pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int e = e0 + k * 64 + lane;
-                    int c = 0, cmine = 0;
-                    double cv = 0.0, prob = 0.0;
-                    unsigned int rm32 = 0, rl = 0;
-                    if (e < nent) {
-                        const int r = e / sm.nl, l = e - r * sm.nl;
-                        rl = ((unsigned int)r << 12) | ((unsigned int)l << 18);      // c < 4096, R <= 64, l < 2^14
-                        const int64_t rm = (int64_t)r * d.M + sm.entry_mode(l);
-                        const int64_t at = ((int64_t)seg * d.R + r) * d.nlmax + l;
-                        prob = d.ep_p[at];
-                        nk_emit_entry(d, step, rm, at, prob, c, cmine, cv);
-                        rm32 = (unsigned int)rm;
-                        sp_bound += ((int)floor(prob) + 1 + d.nranks - 1) / d.nranks;
-                    }
-                    unsigned int v = (unsigned int)cmine;
-#pragma unroll
-                    for (int o = 1; o < 64; o <<= 1) { const unsigned int u = __shfl_up(v, o, 64); if (lane >= o) v += u; }
-                    sp_cnt[k * 64 + lane] = (unsigned int)c | rl;
-                    sp_rm[k * 64 + lane] = rm32;
-                    sp_cv[k * 64 + lane] = cv;
-                    sp_pr[k * 64 + lane] = prob;
-                    sp_pref[k * 64 + lane] = v + run - (unsigned int)cmine;
-                    run += __shfl(v, 63, 64);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");     // LDS is in order per wave; keep the compiler honest
-                spn = (int)run;
-            }
+        int bound_;
 #ifdef NK_STAMPS
-            if (!em_t2) em_t2 = __builtin_amdgcn_s_memrealtime();     // the first chunk of entries is evaluated
+        (void)nk_emit_one<GEOM, BOX>(d, L, step, seg, lane, sp_pref, sp_cnt, sp_rm, sp_cv, sp_pr, ahead, to_queue, bound_, em_t0, em_t1, em_t2);
+#else
+        (void)nk_emit_one<GEOM, BOX>(d, L, step, seg, lane, sp_pref, sp_cnt, sp_rm, sp_cv, sp_pr, ahead, to_queue, bound_);
 #endif
-            for (int spj = 0; spj < spn; spj += NK_TILE) {
-                const int j = spj + lane;
-                if (j >= spn) continue;
-                int64_t rm;
-                int level, r, idx;
-                double prob = 0.0, cval = 0.0;
-                uint64_t o2o = 0;
-                if (d.res_gen == 2) {
-                    const uint64_t recd = d.sp_inbox[(int64_t)seg * d.sp_icap + j];
-                    rm = (int64_t)((recd >> 12) & 0xFFFFFFFull);
-                    level = 0;                              // 'one_to_one': entry time uniform in the step
-                    o2o = recd >> 40;
-                    r = (int)((uint32_t)rm / (uint32_t)d.M);                        // rm < 2^28
-                    const int mode = (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
-                    idx = d.part ? (int)((uint32_t)d.m2s[mode] / (uint32_t)d.nseg) : mode;
-                } else {
-                    // the entry this particle belongs to: the last one whose exclusive prefix is <= j
-                    int lo = 0, hi = NK_EMIT_CHUNK;
-                    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int)sp_pref[mid] <= j) lo = mid; else hi = mid; }
-                    const unsigned int cw = sp_cnt[lo];
-                    const int q = j - (int)sp_pref[lo], c = (int)(cw & 0xFFFu);
-                    r = (int)((cw >> 12) & 0x3Fu);
-                    rm = (int64_t)sp_rm[lo];
-                    idx = d.part ? (int)(cw >> 18) : (int)((uint32_t)rm - (uint32_t)r * (uint32_t)d.M);
-                    cval = sp_cv[lo];
-                    prob = sp_pr[lo];
-                    // the q-th level this rank owns, counted down from c (nk_emit_entry's order)
-                    if (d.nranks == 1) level = c - q;
-                    else {
-                        const uint32_t n = (uint32_t)d.nranks;
-                        const uint32_t tq = ((uint32_t)d.rank + n - (((uint32_t)rm + step) % n)) % n;   // owned levels = tq mod n
-                        const uint32_t top = (uint32_t)c - (((uint32_t)c + n - tq) % n);                // largest owned level <= c
-                        level = (int)(top - (uint32_t)q * n);
-                    }
-                }
-                const NkMode *rec = sm.rec + idx;
-                const double4 ra = *reinterpret_cast<const double4 *>(rec);
-                const double E0 = rec->E0;
-                const uint64_t pid = level > 0 ? ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)rm << 12) | (uint64_t)level
-                                               : ((uint64_t)((step + 1u) & 0xFFFFFFu) << 40) | ((uint64_t)r << 32) | o2o;
-                double uf, us, ur, ut;
-                nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT, uf, us);
-                nk_uniform2_dev(d.seed, pid, step, NK_TAG_EMIT + 1, ur, ut);
-                const double iprob = level > 0 ? nk_rcp(prob) : 0.0;
-                const double dt_in = (level == 0) ? d.dt * ut                               // one_to_one :482
-                                   : (level == 1) ? d.dt * (1.0 - cval * iprob)
-                                                  : d.dt * (1.0 - ((double)(level - 1) + ut) * iprob);
-                double x0, y0, z0;
-                if (GEOM == 1 && d.res_lds) nk_sample_res_face(L.rf_off, L.rf_cdf, L.rf_verts, r, uf, us, ur, x0, y0, z0);
-                else nk_sample_res_face(d.res_face_off, d.res_face_cdf, d.res_face_verts, r, uf, us, ur, x0, y0, z0);
-                const double omega = ra.x, vx = ra.y, vy = ra.z, vz = ra.w;
-                const double occ = nk_be(omega * d.c_hk, E0, L.resT[2 * r + 1], d.invT0);   // Population.py:506
-                if (GEOM == 2 && to_queue) {
-                    // split sweep over a face tree: the particle's first ray cast is a tree walk like any other, and k_events runs
-                    // those with its lanes interleaved.  The particle goes into the segment's event queue as it stands on the
-                    // reservoir -- position, entry time in the nts field, the reservoir's facet in the packed word -- and
-                    // k_events finishes what follows here (nk_newborn_place)
-                    const int o = made + j;
-                    if (o < d.segcap) {
-                        const int64_t i = base + o;
-                        const int rf = d.res_facet[r];
-                        const NkFacet &fq = d.facets[rf];
-                        // the facet field: the reservoir's facet if the walk may skip the nodes that hold only its faces, else none
-                        const int skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
-                        d.qx[i] = x0; d.qy[i] = y0; d.qz[i] = z0; d.qocc[i] = occ; d.qnts[i] = dt_in;
-                        d.qw0[i] = NK_NEWBORN | ((uint32_t)((skip == rf ? rf : -1) + 1) << d.lb) | (uint32_t)idx;
-                        if (d.qpid) d.qpid[i] = pid;
-                    } else if (!(ahead && d.halt[1])) atomicOr(d.overflow, 1);
-                    continue;
-                }
-                double tc = 0.0;
-                int facet = -1;
-                int skip = NK_TREE_NO_SKIP;               // the particle starts on its reservoir's facet
-                if (GEOM == 2 && d.NG > 0) {
-                    const int rf = d.res_facet[r];
-                    const NkFacet &fq = d.facets[rf];
-                    skip = nk_tree_skip(d, rf, fq.cx, fq.cy, fq.cz, fq.nx, fq.ny, fq.nz, x0, y0, z0, vx, vy, vz);
-                }
-                if (!BOX) NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
-                const int o = count + made + j;
-                if (o < d.segcap) {
-                    const int64_t i = base + o;
-                    const NkSlot q = nk_slot(d, i);
-                    double xa, ya, za, na;
-                    nk_newborn_place(d, x0, y0, z0, vx, vy, vz, dt_in, tc, xa, ya, za, na);
-                    d.x.p[q.od] = xa; d.y.p[q.od] = ya; d.z.p[q.od] = za;
-                    d.occ.p[q.od] = occ;
-                    if (!BOX) d.nts.p[q.od] = na;
-                    d.w0.p[q.ow] = BOX ? (NK_NEWBORN | (uint32_t)idx) : (NK_NEWBORN | ((uint32_t)(facet + 1) << d.lb) | (uint32_t)idx);
-                    if (d.pid) d.pid.p[q.od] = pid;
-                } else if (!(ahead && d.halt[1])) atomicOr(d.overflow, 1);         // more entering particles than free slots
-            }
-            made += spn;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");         // the next chunk overwrites the scratch
-        }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) sp_bound += __shfl_xor(sp_bound, o, 64);
-        if (lane == 0) {
-            const int room = d.segcap - count;
-            if (GEOM == 2 && to_queue) { d.seg_new[seg] = 0; d.seg_evq[seg] = made < d.segcap ? made : d.segcap; }
-            else d.seg_new[seg] = made < room ? made : (room > 0 ? room : 0);
-            d.seg_bound[seg] = sp_bound;
-            if (d.res_gen == 2) d.sp_inbox_n[seg] = 0;
-#ifdef NK_STAMPS
-            if (d.stamps) { unsigned long long *w = d.stamps + ((int64_t)d.nseg + seg) * 8 + 4; w[0] = em_t0; w[1] = em_t1; w[2] = em_t2; w[3] = __builtin_amdgcn_s_memrealtime(); }
-#endif
-        }
     }
 }
 
@@ -730,6 +753,9 @@ __device__ __forceinline__ NkLdsRec nk_lds_rec(const double2 *q) { return (NkLds
 // evaluates that hit itself (nk_box_first_hit) before it runs the event.  72 B moved per phonon-step instead of 88.
 // The body between the LDS set-up and the flush of the tally row, for workgroup `wg` of `nwg` (k_sweep: blockIdx.x of gridDim.x;
 // the resident kernel of small ensembles calls it once per step from its own loop, k_resident).
+// (Tried in round 4 and dropped: the wave making its segment's entering particles itself before it sweeps the segment -- nk_emit_one
+// with the carry as scratch, no k_emit launch, a reduce-only tail.  The emission's scalars stay live across the tile loop: 229
+// instead of 91 scalar registers parked in vector lanes, v_readlane in the tile loop 42 -> 153, and vector registers in scratch.)
 template <int GEOM, bool ROUGH, bool RBF, bool PID, bool SPLIT, bool LREC, int FAST = 0, bool BOX = false>
 __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t step, int do_relax, int flags, int wg, int nwg
 #ifdef NK_STAMPS
