@@ -1848,7 +1848,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     // The next step's emission rides in the same launch as this step's reduce / update (k_tail) wherever it depends on neither
     // (no rough facets, not 'one_to_one').  (On a second stream instead, the two cross-stream event waits per step cost more
     // than the 12 us they hid: 0.289 against 0.270 ms per step on config 2, profiles/r03_notes.txt (11).)
-    const bool tail_emit = R > 0 && d.res_gen != 2 && !d.mig_buf && !getenv("NK_NO_TAIL_EMIT");
+    const bool tail_emit = R > 0 && d.res_gen != 2 && !getenv("NK_NO_TAIL_EMIT");
     const size_t lds_t = lds_e > (size_t)(NK_WG * 8 + 16) ? lds_e : (size_t)(NK_WG * 8 + 16);
     bool emitted_ahead = tail_emit && ctx->emitted_for == ctx->step;   // this step's emission already ran in the previous step's k_tail (maybe of the call before)
     ctx->emitted_for = -1;
@@ -1879,6 +1879,9 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
                 k_events_end<<<(d.nseg + 255) / 256, 256, 0, ctx->stream>>>(d);
             }
         }
+        // rough facets: the migrants of this step go to their segments before the tallies are reduced (and before the next step's
+        // emission, in the tail launch, appends behind them)
+        if (d.mig_buf) k_deliver<<<g_emit, NK_WG, 0, ctx->stream>>>(d, 1);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 2], ctx->stream));
         double *hrow = ctx->hist + (size_t)s * HROW;
         const bool ahead = tail_emit;                          // the next step's emission beside this step's tail (the last step's too: for the next call)
@@ -1894,7 +1897,6 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
             k_reduce<<<NB, NK_WG, 0, ctx->stream>>>(d, rows, ctx->acc, hrow, do_flux, 1);
         }
         emitted_ahead = ahead;
-        if (d.mig_buf) k_deliver<<<g_emit, NK_WG, 0, ctx->stream>>>(d);
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 3], ctx->stream));
         pending = true;
         if ((s & 63) == 0) NK_HIP(hipGetLastError());   // a bad launch configuration shows at the first step of a batch (every step launches the same)
@@ -2226,7 +2228,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
             // (hw[2] comes out of the all-reduced vector: with several ranks every one of them is here at the same step, has
             // grown its segments by the same amount, and delivers whatever waits in its own inboxes)
             if (hw[2]) {                                 // migrants that did not fit: they do now
-                k_deliver<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(d);
+                k_deliver<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(d, 0);
                 NK_HIP(hipGetLastError());
                 NK_HIP(hipStreamSynchronize(ctx->stream));
                 int32_t again[4];

@@ -1368,7 +1368,11 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_regrow(NkDev o, NkD
 // Rough facets: the particles whose reflection moved them to a mode of another segment wait in that segment's inbox; after
 // the step's update they are appended to the segment (one wave per segment, coalesced stores).  A segment that cannot
 // take its migrants keeps them in the inbox and raises the halt word: the host grows the store and delivers again.
-NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
+// in_step = 1: launched right behind the step's sweep, BEFORE its reduce / update (round 4; so that the next step's emission can ride
+// in the tail launch: it appends behind the delivered migrants): a segment that cannot take its migrants leaves them in the inbox,
+// k_reduce sees them there and the halt travels with the tally vector.  in_step = 0: launched by the host on its own, after the
+// store has grown: raises the halt words itself if something still does not fit.
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d, int in_step) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = gridDim.x * (NK_WG / 64);
     for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
@@ -1376,10 +1380,9 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
         if (n <= 0) continue;
         if (n > d.mig_cap) n = d.mig_cap;
         const int count = d.seg_count[seg];
-        // no room: the migrants stay in the inbox.  k_reduce saw that before the tallies were summed over the ranks, so halt[0]
-        // and halt[2] are already up on EVERY rank (nk_update_body) and all of them stop after this step; the atomics here only
-        // cover a k_deliver that the host launches on its own
-        if (count + n > d.segcap) { if (lane == 0) { atomicOr(d.halt + 2, 1); atomicOr(d.halt, 1); } continue; }
+        // no room: the migrants stay in the inbox.  In a step k_reduce sees that before the tallies are summed over the ranks, so
+        // halt[0] and halt[2] go up on EVERY rank (nk_update_body) and all of them stop after this step
+        if (count + n > d.segcap) { if (lane == 0 && !in_step) { atomicOr(d.halt + 2, 1); atomicOr(d.halt, 1); } continue; }
         const int64_t base = (int64_t)seg * d.segcap + count;
         for (int j = lane; j < n; j += 64) {
             const double2 *r = d.mig_buf + ((int64_t)seg * d.mig_cap + j) * 4;
@@ -1391,7 +1394,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d) {
         if (lane == 0) {
             d.seg_count[seg] = count + n;
             d.mig_n[seg] = 0;
-            // room for the next TWO steps (emission and about as many migrants again): the request travels with the next step's
+            // room for the next TWO steps (emission and about as many migrants again): the request travels with this step's
             // tally vector, so that every rank halts at the same step
             const int bound = d.R > 0 ? d.seg_bound[seg] : 0;
             if ((int64_t)count + n + 2 * (bound + 2 * n) + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
@@ -1530,8 +1533,8 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_reduce(NkDev d, int
 // the sweep has left -- and the reduce / update are latency chains of a hundred workgroups that leave the chip idle: side by
 // side they cost the longer of the two (and one launch less).  The update may raise the halt word while the emission of the
 // step that will then NOT run is under way: harmless, its counters are double-buffered (NkDev::rc_len) and it is simply run
-// again once the store has grown.  Not with rough facets (k_deliver, after the update, moves the segments' ends) nor
-// 'one_to_one' (emits what the update says left).
+// again once the store has grown.  Not 'one_to_one' (emits what the update says left).  With rough facets k_deliver runs between the
+// sweep and this launch (round 4: it used to run after the update and moved the segments' ends under the emission).
 template <int GEOM, bool BOX = false>
 __global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int rows, double *acc, double *hist_row, int do_flux, int fuse,
                                                 int n_reduce) {

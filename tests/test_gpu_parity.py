@@ -236,7 +236,7 @@ def test_multistep_vs_oracle(case, store, monkeypatch):
     eng = make_engine(ct, pos, mode, occ, counter, seed=42)
     assert same_event_rule(eng, sim) == (1 if store.startswith('box') else 0)
     t = eng.step(nsteps)
-    assert eng.timing()['emit_fused'] == (2 if store.endswith('resident') else (1 if case == 'ttp' else 0))   # which path ran
+    assert eng.timing()['emit_fused'] == (2 if store.endswith('resident') else 1)   # which path ran (1: the emission rides in the tail launch)
     for s in range(nsteps):
         sim.run_timestep()
         assert np.array_equal(t['N_sv'][s], sim.N_sv), 'step %d' % s
