@@ -1915,6 +1915,9 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     }
     NK_HIP(hipMemcpyAsync(ctx->pin, ctx->hist, hbytes, hipMemcpyDeviceToHost, ctx->stream));
     NK_HIP(hipMemcpyAsync((char *)ctx->pin + ctx->pin_bytes - 64, d.halt, 16, hipMemcpyDeviceToHost, ctx->stream));
+    // a call of a few steps (a driver that steps one by one) is over in a fraction of a millisecond: poll instead of sleeping on the
+    // stream -- the wake-up of a blocked wait is a tenth of such a call
+    if (nsteps <= 4) { hipError_t q_; while ((q_ = hipStreamQuery(ctx->stream)) == hipErrorNotReady) { } if (q_ != hipSuccess) { ctx->err = std::string("hipStreamQuery: ") + hipGetErrorString(q_); return NK_ERR_HIP; } }
     NK_HIP(hipStreamSynchronize(ctx->stream));
     h.resize((size_t)nsteps * HROW);
     memcpy(h.data(), ctx->pin, hbytes);

@@ -369,15 +369,20 @@ class Engine(object):
         return E, N, F
 
     def step(self, nsteps=1):
-        """Run nsteps timesteps; returns a dict of per-step arrays (see nk_tally in the header)."""
+        """Run nsteps timesteps; returns a dict of per-step arrays (see nk_tally in the header).  The arrays are views of ONE block
+        (a driver that steps one by one calls this a thousand times a second: one allocation and one address instead of nine)."""
         S, R = self.S, max(self.R, 0)
-        out = dict(T_sv=np.zeros((nsteps, S)), E_sv=np.zeros((nsteps, S)), E_raw=np.zeros((nsteps, S)),
-                   N_sv=np.zeros((nsteps, S)), flux_raw=np.zeros((nsteps, S, 3)),
-                   N_leaving=np.zeros((nsteps, R)), res_energy=np.zeros((nsteps, R)),
-                   res_flux=np.zeros((nsteps, R, 3)), N_emitted=np.zeros(nsteps))
-        t = nk_tally()
-        for k in out:
-            setattr(t, k, _p(out[k]))
+        shapes = (('T_sv', (nsteps, S)), ('E_sv', (nsteps, S)), ('E_raw', (nsteps, S)), ('N_sv', (nsteps, S)), ('flux_raw', (nsteps, S, 3)),
+                  ('N_leaving', (nsteps, R)), ('res_energy', (nsteps, R)), ('res_flux', (nsteps, R, 3)), ('N_emitted', (nsteps,)))
+        total = nsteps * (7 * S + 5 * R + 1)
+        block = np.zeros(total if total > 0 else 1)
+        base = block.ctypes.data
+        out, t, off = {}, nk_tally(), 0
+        for k, shp in shapes:
+            n = int(np.prod(shp))
+            out[k] = block[off:off + n].reshape(shp)
+            setattr(t, k, C.cast(base + 8 * off, c_dp))
+            off += n
         self._ck(self.L.nk_step(self.h, int(nsteps), C.byref(t)), 'nk_step')
         return out
 

@@ -646,10 +646,13 @@ class Population(Constants):
             chunk = min(nsteps - done, 100 - (self.current_timestep % 100))
             # the reference grows its arrays as the ensemble grows; here the particle store is re-laid out with head room
             # before it can fill up (this rank's share of N_p against the engine's slots)
-            tm = self.engine.timing()
+            # (the engine's slot count only changes when the store grows: asked for again after every 100 steps and after a reserve)
             local = self.N_p / max(self.nranks, 1)
-            if tm['slots'] > 0 and local > 0.8 * tm['slots']:
+            if getattr(self, '_slots', None) is None or (self.current_timestep % 100) == 0:
+                self._slots = self.engine.timing()['slots']
+            if self._slots > 0 and local > 0.8 * self._slots:
                 self.engine.reserve(int(2.0 * local) + 65536)
+                self._slots = None
             t = self.engine.step(chunk)
             s0 = 0
             while s0 < chunk:
