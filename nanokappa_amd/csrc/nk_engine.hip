@@ -419,7 +419,7 @@ void nk_destroy(nk_ctx *ctx) {
     if (ctx->acc) hipFree(ctx->acc);
     if (ctx->racc) hipFree(ctx->racc);
     if (ctx->pin) hipHostFree(ctx->pin);
-    if (ctx->hist) hipFree(ctx->hist);
+    if (ctx->hist) hipHostFree(ctx->hist);
     if (ctx->modetab_p) hipFree(ctx->modetab_p);
     if (ctx->m2s_dev) hipFree(ctx->m2s_dev);
     if (ctx->s2m_dev) hipFree(ctx->s2m_dev);
@@ -909,7 +909,7 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     NkDev &d = ctx->d;
     d.NB = 5 * d.S + 5 * d.R + 1;
     if (ctx->acc) { hipFree(ctx->acc); ctx->acc = nullptr; }
-    if (ctx->hist) { hipFree(ctx->hist); ctx->hist = nullptr; }      // the history rows follow NB
+    if (ctx->hist) { hipHostFree(ctx->hist); ctx->hist = nullptr; }      // the history rows follow NB
     ctx->hist_cap = 0;
     NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)(d.NB + 2) * sizeof(double)));
     NK_HIP(hipMemset(ctx->acc, 0, (size_t)(d.NB + 2) * sizeof(double)));
@@ -1812,16 +1812,19 @@ static int nk_flush_relax(nk_ctx *ctx, int honor_halt) {
 static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, int32_t *done) {
     NkDev &d = ctx->d;
     const int S = d.S, R = d.R, NB = d.NB;
-    const int HROW = NB + 2 * S + 4;
+    const int HROW = NB + 2 * S + 8;
     if (nsteps > ctx->hist_cap) {
-        if (ctx->hist) hipFree(ctx->hist);
+        if (ctx->hist) hipHostFree(ctx->hist);
         ctx->hist = nullptr;
         const int rows_alloc = nsteps < 1024 ? 1024 : nsteps;   // generous: a later, longer call must not pay a realloc
-        NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)rows_alloc * HROW * sizeof(double)));
+        // The history rows live in pinned HOST memory that the device writes directly (1.1 KB per step over PCIe by the one
+        // workgroup of the update): no copy back, no fill kernel -- a driver that steps one by one pays for every operation of a
+        // call (round 3: fill + two copies = a tenth of such a call).
+        NK_HIP(hipHostMalloc((void **)&ctx->hist, (size_t)rows_alloc * HROW * sizeof(double), hipHostMallocMapped));
         ctx->hist_cap = rows_alloc;
     }
     ctx->timing.batches += 1;
-    NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));   // row_valid = 0
+    memset(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double));   // row_valid = 0 (host memory; the stream is idle between calls)
     const size_t lds_g = nk_lds(ctx, true), lds_w = nk_lds(ctx, true, d.pid ? 3 : 2), lds_e = nk_lds(ctx, true, 1);
     const int gm_ = nk_geom_mode(ctx);
     const bool rough_ = d.Fr > 0, rbf_ = d.sv_interp == 3, pid_ = (bool)d.pid, split_ = d.qx != nullptr;
@@ -1906,22 +1909,18 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     // the history rows and the halt words come back through pinned memory, enqueued behind the steps: ONE wait per call (a
     // Population.run_timestep is one such call per step -- the reference driver's granularity, nanokappa.py:91-98)
     const size_t hbytes = (size_t)nsteps * HROW * sizeof(double);
-    if (hbytes + 64 > ctx->pin_bytes) {
-        if (ctx->pin) hipHostFree(ctx->pin);
-        ctx->pin = nullptr; ctx->pin_bytes = 0;
-        const size_t want = ((size_t)(nsteps < 1024 ? 1024 : nsteps)) * HROW * sizeof(double) + 64;
-        NK_HIP(hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
-        ctx->pin_bytes = want;
-    }
-    NK_HIP(hipMemcpyAsync(ctx->pin, ctx->hist, hbytes, hipMemcpyDeviceToHost, ctx->stream));
-    NK_HIP(hipMemcpyAsync((char *)ctx->pin + ctx->pin_bytes - 64, d.halt, 16, hipMemcpyDeviceToHost, ctx->stream));
     // a call of a few steps (a driver that steps one by one) is over in a fraction of a millisecond: poll instead of sleeping on the
     // stream -- the wake-up of a blocked wait is a tenth of such a call
     if (nsteps <= 4) { hipError_t q_; while ((q_ = hipStreamQuery(ctx->stream)) == hipErrorNotReady) { } if (q_ != hipSuccess) { ctx->err = std::string("hipStreamQuery: ") + hipGetErrorString(q_); return NK_ERR_HIP; } }
     NK_HIP(hipStreamSynchronize(ctx->stream));
     h.resize((size_t)nsteps * HROW);
-    memcpy(h.data(), ctx->pin, hbytes);
-    memcpy(ctx->halt_words, (char *)ctx->pin + ctx->pin_bytes - 64, 16);
+    memcpy(h.data(), ctx->hist, hbytes);
+    {   // the halt words as the last step that ran left them (its update wrote them behind the row); no row: ask the device
+        int last_ = -1;
+        for (int q_ = 0; q_ < nsteps && h[(size_t)q_ * HROW + NB + 2 * S + 1] != 0.0; ++q_) last_ = q_;
+        if (last_ >= 0) for (int k_ = 0; k_ < 4; ++k_) ctx->halt_words[k_] = (int32_t)h[(size_t)last_ * HROW + NB + 2 * S + 4 + k_];
+        else NK_HIP(hipMemcpy(ctx->halt_words, d.halt, 16, hipMemcpyDeviceToHost));
+    }
 #ifdef NK_STAMPS
     if (d.stamps) {                                     // developer build: section shares of the LAST sweep of the batch
         std::vector<unsigned long long> st((size_t)d.nseg * 16);
@@ -2070,17 +2069,17 @@ static inline bool nk_want_resident(const nk_ctx *ctx) {
 static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, int32_t *done) {
     NkDev &d = ctx->d;
     const int S = d.S, NB = d.NB;
-    const int HROW = NB + 2 * S + 4;
+    const int HROW = NB + 2 * S + 8;
     if (nsteps > ctx->hist_cap) {
-        if (ctx->hist) hipFree(ctx->hist);
+        if (ctx->hist) hipHostFree(ctx->hist);
         ctx->hist = nullptr;
         const int rows_alloc = nsteps < 1024 ? 1024 : nsteps;
-        NK_HIP(hipMalloc((void **)&ctx->hist, (size_t)rows_alloc * HROW * sizeof(double)));
+        NK_HIP(hipHostMalloc((void **)&ctx->hist, (size_t)rows_alloc * HROW * sizeof(double), hipHostMallocMapped));
         ctx->hist_cap = rows_alloc;
     }
     ctx->timing.batches += 1;
     ctx->emitted_for = -1;
-    NK_HIP(hipMemsetAsync(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double), ctx->stream));
+    memset(ctx->hist, 0, (size_t)nsteps * HROW * sizeof(double));
     (void)nk_sweep_blocks(ctx);
     const bool pid_ = (bool)d.pid, lrec_ = nk_want_lrec(ctx), box_ = d.box != 0;
     const size_t lds = nk_lds(ctx, true, pid_ ? 5 : 4);
@@ -2131,19 +2130,15 @@ static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h,
     }
     NK_HIP(hipEventRecord(t1, ctx->stream));
     const size_t hbytes = (size_t)nsteps * HROW * sizeof(double);
-    if (hbytes + 64 > ctx->pin_bytes) {
-        if (ctx->pin) hipHostFree(ctx->pin);
-        ctx->pin = nullptr; ctx->pin_bytes = 0;
-        const size_t want = ((size_t)(nsteps < 1024 ? 1024 : nsteps)) * HROW * sizeof(double) + 64;
-        NK_HIP(hipHostMalloc(&ctx->pin, want, hipHostMallocDefault));
-        ctx->pin_bytes = want;
-    }
-    NK_HIP(hipMemcpyAsync(ctx->pin, ctx->hist, hbytes, hipMemcpyDeviceToHost, ctx->stream));
-    NK_HIP(hipMemcpyAsync((char *)ctx->pin + ctx->pin_bytes - 64, d.halt, 16, hipMemcpyDeviceToHost, ctx->stream));
     NK_HIP(hipStreamSynchronize(ctx->stream));
     h.resize((size_t)nsteps * HROW);
-    memcpy(h.data(), ctx->pin, hbytes);
-    memcpy(ctx->halt_words, (char *)ctx->pin + ctx->pin_bytes - 64, 16);
+    memcpy(h.data(), ctx->hist, hbytes);
+    {   // the halt words as the last step that ran left them (its update wrote them behind the row); no row: ask the device
+        int last_ = -1;
+        for (int q_ = 0; q_ < nsteps && h[(size_t)q_ * HROW + NB + 2 * S + 1] != 0.0; ++q_) last_ = q_;
+        if (last_ >= 0) for (int k_ = 0; k_ < 4; ++k_) ctx->halt_words[k_] = (int32_t)h[(size_t)last_ * HROW + NB + 2 * S + 4 + k_];
+        else NK_HIP(hipMemcpy(ctx->halt_words, d.halt, 16, hipMemcpyDeviceToHost));
+    }
     int32_t nd = 0;
     while (nd < nsteps && h[(size_t)nd * HROW + NB + 2 * S + 1] != 0.0) ++nd;
     *done = nd;
@@ -2171,7 +2166,7 @@ int nk_step(nk_ctx *ctx, int32_t nsteps, nk_tally *out) {
     if ((rc = nk_ensure_migration(ctx, 0))) return rc;
     NkDev &d = ctx->d;
     const int S = d.S, R = d.R, NB = d.NB;
-    const int HROW = NB + 2 * S + 4;
+    const int HROW = NB + 2 * S + 8;
     ctx->stepped = true;
     int32_t s_out = 0;                 // rows delivered so far
     int overflow = 0;      // reason mask: 2 / 4 a segment filled up (tile commit / event survivors), 8 one_to_one inbox full,

@@ -1445,7 +1445,7 @@ __device__ __forceinline__ void nk_update_sv(const NkDev &d, double Eraw, double
 }
 // Normalise, invert E(T), publish the new subvolume temperatures, history row: calculate_energy (Population.py:719-728)
 // + refresh_temperatures (:692), run by ONE workgroup.
-// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, row_valid, halt, overflow
+// History row: acc[NB] | T_sv[S] | E_sv[S] | flux_valid, row_valid, halt, overflow | the four halt words after this step
 // acc[NB] / acc[NB + 1] (summed over the ranks like the tallies) > 0: some segment could overflow at the next step / cannot
 // take its migrants -> raise the halt word,
 // on every rank at the same step.
@@ -1483,6 +1483,11 @@ __device__ __forceinline__ void nk_update_body(const NkDev &d, const double *acc
         hist_row[NB + 2 * S + 3] = (double)*d.overflow;
         if (hreq) d.halt[0] = 1;
         if (hdel) d.halt[2] = 1;
+        // the four halt words as this step leaves them, behind the row (the host reads them there: no copy of their own)
+        hist_row[NB + 2 * S + 4] = hreq ? 1.0 : 0.0;
+        hist_row[NB + 2 * S + 5] = (double)d.halt[1];
+        hist_row[NB + 2 * S + 6] = (hdel || d.halt[2]) ? 1.0 : 0.0;
+        hist_row[NB + 2 * S + 7] = (double)d.halt[3];
     }
 }
 
@@ -1651,6 +1656,10 @@ __global__ __launch_bounds__(NK_WG, 2) void k_resident(NkDev d, uint32_t step0, 
                 hrowp[NB + 2 * S + 1] = 1.0;
                 hrowp[NB + 2 * S + 2] = hreq ? 1.0 : 0.0;
                 hrowp[NB + 2 * S + 3] = (double)*d.overflow;
+                hrowp[NB + 2 * S + 4] = hreq ? 1.0 : 0.0;
+                hrowp[NB + 2 * S + 5] = (double)hreq;
+                hrowp[NB + 2 * S + 6] = (double)d.halt[2];
+                hrowp[NB + 2 * S + 7] = (double)d.halt[3];
                 if (hreq) d.halt[0] = 1;
             }
         }
