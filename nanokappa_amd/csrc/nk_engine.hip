@@ -1523,7 +1523,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
         if (d.part && d.M > nseg) d.nlmax += d.nlmax / 6 + 2;
         // the segments' mode records in LDS where a segment's share fits and the LDS they take costs no resident workgroup
         d.nlrec = 0;
-        if (d.part && d.nlmax <= NK_LREC) {
+        if (d.part && d.nlmax <= NK_LREC && !getenv("NK_NO_LREC")) {
             const int without = nk_sweep_blocks(ctx);
             d.nlrec = d.nlmax;
             if (nk_sweep_blocks(ctx) < without) d.nlrec = 0;

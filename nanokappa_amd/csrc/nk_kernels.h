@@ -1139,7 +1139,7 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
 // one concatenated list (prefix sums by k_events_begin) that all waves draw from through a ticket counter; a finished
 // particle takes its slot in its segment with an atomic on the segment's count.  k_events_end closes the step per segment.
 #ifndef NK_EVENTS_LOW
-#define NK_EVENTS_LOW 8
+#define NK_EVENTS_LOW 16         // (round 4, wire at 5e7: 8 -> 3.636 ms per step, 16 -> 3.577, 24 -> 3.573; NK_EVENTS_LEAVES 16 / 32 / 48: 3.69 / 3.64 / 3.66)
 #endif
 #ifndef NK_EVENTS_LEAVES
 #define NK_EVENTS_LEAVES 32      // lanes waiting at a leaf that make a faces pass worth its instructions

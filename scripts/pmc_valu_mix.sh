@@ -10,7 +10,7 @@ G3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_V
 i=0
 for G in "$G1" "$G2" "$G3"; do
   i=$((i+1))
-  timeout -k 5 200 rocprofv3 --kernel-trace --pmc $G -d $O/g$i -o p --output-format csv -- python3 $R/bench.py --config $c --steps 10 --warmup 5 --repeats 1 --no-cpu-baseline --sustained 0 --per-call 0 > /dev/null 2> $O/g$i.log
+  timeout -k 5 400 rocprofv3 --kernel-trace --pmc $G -d $O/g$i -o p --output-format csv -- python3 $R/bench.py --config $c --steps 10 --warmup 5 --repeats 1 --no-cpu-baseline --sustained 0 --per-call 0 > /dev/null 2> $O/g$i.log
   echo "group $i rc $?"
 done
 python3 - <<PY | tee $O/mix.txt
@@ -21,7 +21,7 @@ for g in sorted(glob.glob('$O/g*/**/*counter_collection.csv', recursive=True)):
         k = r['Kernel_Name'].split('(')[0].replace('void ', '')[:10]
         acc[k][r['Counter_Name']].append(float(r['Counter_Value']))
 for k in sorted(acc):
-    if not (k.startswith('k_sweep') or k.startswith('k_tail') or k.startswith('k_emit<')): continue
+    if not (k.startswith("k_sweep") or k.startswith("k_tail") or k.startswith("k_emit<") or k.startswith("k_events")): continue
     print(k)
     for cn in sorted(acc[k]):
         v = acc[k][cn][-5:]
