@@ -126,6 +126,9 @@ struct NkDev {
     const double *tree_faces;         // [tree_leaves * 4 * NK_TREE_FACE_DOUBLES] leaf face records (padded with null faces)
     int32_t tree_base[8];             // first node of each level in tree_boxes
     int32_t tree_top, tree_leaves;
+    // k_events: the families from index tree_lds_fam0 up (whole levels from the top of the tree; the levels are stored bottom-up, so these
+    // are the array's tail) are copied to LDS at byte offset tree_lds_off of the workgroup's dynamic area (set per launch, nk_step_batch)
+    int32_t tree_nfam, tree_lds_fam0, tree_lds_off;
     int32_t NG;                       // 1: walk the face tree, 0: sweep all planes
     const double *planes;             // [NP*NK_PLANE_DOUBLES]
     const double *faces;              // [F*NK_FACE_DOUBLES], grouped by plane
@@ -712,71 +715,103 @@ __device__ __forceinline__ void nk_box_first_hit(const NkBoxWalls &b, double inv
 // lowest face index, whatever the visiting order).  The previous structure (two levels of wave-uniform groups of 16
 // planes) made a wave visit the union of its 64 rays' groups -- on a 5000-face wire nearly the whole mesh per batch.
 #define NK_TREE_LEVELS 8            // 4^8 leaves x 4 faces: meshes up to 262 144 faces
-#define NK_TREE_FACE_DOUBLES 20     // n(3) k | lo(3) hi(3) | o(3) iu(3) iw(3) {face, facet}
+#define NK_TREE_FACE_DOUBLES 20     // per face: n(3) k | lo(3) hi(3) | o(3) iu(3) iw(3) {face, facet}.  A LEAF's 80 doubles are laid out by cache
+                                    // line (128 B): the four planes (n, k) first -- the part every ray at the leaf reads -- then one line
+                                    // per face with the rest, read only by a ray that meets the face's plane in front of its best hit
+                                    // (face by face as 160-byte records a leaf's planes lay on four or five lines: the faces do not fit
+                                    // an L1, every line is a trip to the L2)
 #define NK_TREE_FAMILY_FLOATS 24    // four sibling boxes (6 floats each); their facet tags sit in tree_tags (int4 per family)
 // The boxes are single precision, rounded outwards on the host: a family of four is 96 bytes instead of 192 and the slab
 // test runs at twice the FP64 rate.  The test stays conservative: a slab's entry and exit distances are widened by a bound
 // of their rounding error, e = (|x| + B) 2^-20 |1 / v| per axis (B = largest box coordinate; the error proper is below
 // (|x| + B) 2^-21 |1 / v|: conversion of x and 1 / v, one subtraction, one product).  A box that is entered although the
 // exact ray misses it costs time, never a hit: the faces themselves are tested in FP64 as before.
-struct NkRayF { float x, y, z, ix, iy, iz, ex, ey, ez; };
+// A ray for the slab test: 1 / v per axis and, per axis, the two constants that turn a slab distance into ONE fused multiply-add,
+//   (w - x) / v -+ e  =  fma(w, 1 / v, -x / v -+ e)      (n.: towards the entry, f.: towards the exit)
+// e = the widening above.  The roundings (conversion of x and of 1 / v, the product x / v, the constant's sum, the FMA's result;
+// the product inside the FMA is exact) add up to less than 5 x 2^-24 (|x| + B) |1 / v| -- a third of e.
+typedef float nk_f2 __attribute__((ext_vector_type(2)));
+struct NkRayF { float ix, iy, iz, nx, ny, nz, fx, fy, fz; };
 // A ray parallel to an axis (v_a == 0 exactly) gets a huge FINITE 1 / v_a instead of +-inf: the slab's entry / exit distances
 // (lo - x) 1e30 and (hi - x) 1e30 are then -huge / +huge when x lies strictly inside the slab, both > tmax when it lies outside by
 // more than the rounding margin c, and the widening e = c |1 / v| = c 1e30 makes every position in between pass -- the same
-// answers as the explicit "parallel and outside?" test of round 3 (six compares, six selects and a dozen mask operations per
-// box), with no special case.  |lo - x| < 1e5 keeps every product finite.  Conservative like before: a box that is entered
-// although the exact ray misses it costs time, never a hit.
+// answers as an explicit "parallel and outside?" test, with no special case.  |lo - x| < 1e5 keeps every product finite.
+// Conservative like before: a box that is entered although the exact ray misses it costs time, never a hit.
 #define NK_RAY_BIG 1.0e30f
 __device__ __forceinline__ NkRayF nk_ray_f32(double x, double y, double z, double vx, double vy, double vz, double B) {
     NkRayF r;
-    r.x = (float)x; r.y = (float)y; r.z = (float)z;
+    const float fx = (float)x, fy = (float)y, fz = (float)z;
     r.ix = vx != 0.0 ? (float)(1.0 / vx) : NK_RAY_BIG; r.iy = vy != 0.0 ? (float)(1.0 / vy) : NK_RAY_BIG; r.iz = vz != 0.0 ? (float)(1.0 / vz) : NK_RAY_BIG;
     // (a component so small that 1 / v overflows a float is as good as parallel)
     r.ix = fminf(fmaxf(r.ix, -NK_RAY_BIG), NK_RAY_BIG); r.iy = fminf(fmaxf(r.iy, -NK_RAY_BIG), NK_RAY_BIG); r.iz = fminf(fmaxf(r.iz, -NK_RAY_BIG), NK_RAY_BIG);
     const float k = 9.5367431640625e-07f;                                               // 2^-20
-    r.ex = ((float)fabs(x) + (float)B) * k * fabsf(r.ix); r.ey = ((float)fabs(y) + (float)B) * k * fabsf(r.iy); r.ez = ((float)fabs(z) + (float)B) * k * fabsf(r.iz);
+    const float ex = (fabsf(fx) + (float)B) * k * fabsf(r.ix), ey = (fabsf(fy) + (float)B) * k * fabsf(r.iy), ez = (fabsf(fz) + (float)B) * k * fabsf(r.iz);
+    const float px = fx * r.ix, py = fy * r.iy, pz = fz * r.iz;
+    r.nx = -px - ex; r.ny = -py - ey; r.nz = -pz - ez;
+    r.fx = ex - px; r.fy = ey - py; r.fz = ez - pz;
     return r;
 }
-// Does the ray cross the box lo = (lx, ly, lz), hi = (hx, hy, hz) before tmax ?  No branches, no special cases (see above).
+// Does the ray cross the box lo = (lx, ly, lz), hi = (hx, hy, hz) before tmax ?  No branches, no special cases: per axis the wall
+// the ray meets first is the low one when it flies upwards (a select on the sign of 1 / v, the same for every box of the walk),
+// one FMA per wall, three-operand max / min over the axes.  A padding box (lo = +3e38, hi = -3e38) fails for every ray: its entry
+// distance is +huge or +inf, its exit distance -huge or -inf (never NaN: the constants are finite).
 __device__ __forceinline__ bool nk_ray_box(float lx, float ly, float lz, float hx, float hy, float hz, const NkRayF &r, float tmax) {
-    const float ax = (lx - r.x) * r.ix, bx = (hx - r.x) * r.ix;
-    const float ay = (ly - r.y) * r.iy, by = (hy - r.y) * r.iy;
-    const float az = (lz - r.z) * r.iz, bz = (hz - r.z) * r.iz;
-    const float nx = fminf(ax, bx) - r.ex, fx = fmaxf(ax, bx) + r.ex;
-    const float ny = fminf(ay, by) - r.ey, fy = fmaxf(ay, by) + r.ey;
-    const float nz = fminf(az, bz) - r.ez, fz = fmaxf(az, bz) + r.ez;
-    const float t0 = fmaxf(fmaxf(0.0f, nx), fmaxf(ny, nz)), t1 = fminf(fminf(tmax, fx), fminf(fy, fz));
+    const bool ux = r.ix >= 0.0f, uy = r.iy >= 0.0f, uz = r.iz >= 0.0f;
+    // (entry, exit) of an axis as one packed FMA (v_pk_fma_f32: two single-precision FMAs per lane and instruction)
+    const nk_f2 tx = __builtin_elementwise_fma(nk_f2{ux ? lx : hx, ux ? hx : lx}, nk_f2{r.ix, r.ix}, nk_f2{r.nx, r.fx});
+    const nk_f2 ty = __builtin_elementwise_fma(nk_f2{uy ? ly : hy, uy ? hy : ly}, nk_f2{r.iy, r.iy}, nk_f2{r.ny, r.fy});
+    const nk_f2 tz = __builtin_elementwise_fma(nk_f2{uz ? lz : hz, uz ? hz : lz}, nk_f2{r.iz, r.iz}, nk_f2{r.nz, r.fz});
+    const float ax = tx.x, bx = tx.y, ay = ty.x, by = ty.y, az = tz.x, bz = tz.y;
+    const float t0 = fmaxf(fmaxf(ax, ay), fmaxf(az, 0.0f)), t1 = fminf(fminf(bx, by), fminf(bz, tmax));
     return t0 <= t1;
 }
 // The four faces of one leaf against one ray (same arithmetic and the same rounding as nk_fb_planes).
+// Two rounds of loads, not nine: the leaf's plane line for all four faces; then, while any lane of the wave has a face left whose plane
+// it meets in front of its best hit, every lane takes ITS next such face and reads that face's whole line at once (box, origin,
+// barycentric rows, ids).  The faces do not fit the L2 of a large mesh: each dependent round is a trip to the memory side.  Face by
+// face in order, with the box read before the rest, a leaf took up to 1 + 2 x 4 rounds (17 000 cycles per pass of k_events on the
+// 5000-triangle wire).  The result does not depend on the order: earliest hit, lowest face index among equals.
 __device__ __forceinline__ void nk_tree_leaf(const double *tree_faces, int leaf, double tol, double x, double y, double z,
                                              double vx, double vy, double vz, NkHit &h) {
 #pragma clang fp contract(off)
     const double2 *Q = reinterpret_cast<const double2 *>(tree_faces + (size_t)leaf * 4 * NK_TREE_FACE_DOUBLES);
     double2 pn[4], pk[4];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { pn[c] = Q[10 * c]; pk[c] = Q[10 * c + 1]; }      // the plane parts, requested together
+    for (int c = 0; c < 4; ++c) { pn[c] = Q[2 * c]; pk[c] = Q[2 * c + 1]; }        // the plane parts: one line, requested together
+    double nm[4], dn[4];
+    unsigned mask = 0u;
 #pragma unroll
     for (int c = 0; c < 4; ++c) {
-        const double num = x * pn[c].x + y * pn[c].y + z * pk[c].x + pk[c].y;
-        const double den = vx * pn[c].x + vy * pn[c].y + vz * pk[c].x;
-        if (!((num < 0.0 && den > 0.0) || (num > 0.0 && den < 0.0))) continue;     // padding faces have n = k = 0
-        const double t = -num / den;
-        if (!(t >= tol) || isinf(t) || t > h.t) continue;
-        const double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
-        const double2 *q = Q + 10 * c + 2;
-        const double2 q0 = q[0], q1 = q[1], q2 = q[2];              // lo.x lo.y | lo.z hi.x | hi.y hi.z
-        const bool inside = (cx >= q0.x - tol) & (cy >= q0.y - tol) & (cz >= q1.x - tol) & (cx <= q1.y + tol) &
-                            (cy <= q2.x + tol) & (cz <= q2.y + tol);
-        if (!inside) continue;
-        const double2 q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];   // o(3) iu(3) iw(3) {face, facet}
-        const double bx = cx - q3.x, by = cy - q3.y, bz = cz - q4.x;
-        const double u = q4.y * bx + q5.x * by + q5.y * bz;
-        const double w = q6.x * bx + q6.y * by + q7.x * bz;
-        const double r = 1.0 - (u + w);
-        if (!(u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol)) continue;
-        const int idf = __double2loint(q7.y), idc = __double2hiint(q7.y);
-        if (t < h.t || idf < h.face) { h.t = t; h.face = idf; h.facet = idc; }
+        nm[c] = x * pn[c].x + y * pn[c].y + z * pk[c].x + pk[c].y;
+        dn[c] = vx * pn[c].x + vy * pn[c].y + vz * pk[c].x;
+        bool ok = (nm[c] < 0.0 && dn[c] > 0.0) || (nm[c] > 0.0 && dn[c] < 0.0);     // padding faces have n = k = 0
+        // a plane met CERTAINLY behind the best hit so far (by far more than the division's rounding) changes nothing: no division
+        ok = ok && !(fabs(nm[c]) > (h.t * fabs(dn[c])) * (1.0 + 1e-9));
+        mask |= (ok ? 1u : 0u) << c;
+    }
+    while (__ballot(mask != 0u) != 0ull) {
+        if (mask != 0u) {
+            const int c = __builtin_ctz(mask);
+            mask &= mask - 1u;
+            const double num = c == 0 ? nm[0] : (c == 1 ? nm[1] : (c == 2 ? nm[2] : nm[3]));
+            const double den = c == 0 ? dn[0] : (c == 1 ? dn[1] : (c == 2 ? dn[2] : dn[3]));
+            const double t = -num / den;
+            if ((t >= tol) && !isinf(t) && !(t > h.t)) {
+                const double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
+                const double2 *q = Q + 8 + 8 * c;                           // the face's own line
+                const double2 q0 = q[0], q1 = q[1], q2 = q[2];              // lo.x lo.y | lo.z hi.x | hi.y hi.z
+                const double2 q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];   // o(3) iu(3) iw(3) {face, facet}
+                const bool inside = (cx >= q0.x - tol) & (cy >= q0.y - tol) & (cz >= q1.x - tol) & (cx <= q1.y + tol) &
+                                    (cy <= q2.x + tol) & (cz <= q2.y + tol);
+                const double bx = cx - q3.x, by = cy - q3.y, bz = cz - q4.x;
+                const double u = q4.y * bx + q5.x * by + q5.y * bz;
+                const double w = q6.x * bx + q6.y * by + q7.x * bz;
+                const double r = 1.0 - (u + w);
+                const bool in_tri = u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol;
+                const int idf = __double2loint(q7.y), idc = __double2hiint(q7.y);
+                if (inside && in_tri && (t < h.t || idf < h.face)) { h.t = t; h.face = idf; h.facet = idc; }
+            }
+        }
     }
 }
 // A ray that starts ON a planar facet (an entering particle on its reservoir, a reflected one on the wall it just met)
@@ -823,8 +858,8 @@ __device__ __forceinline__ void nk_walk_begin(const NkDev &d, NkWalk &w, double 
 }
 // the boxes of the family the walk stands at (if it has just entered it), then the next node; true when the walk is over
 // (w.h holds the hit).  Not to be called while w.leaf >= 0.
-__device__ __forceinline__ bool nk_walk_boxes(const NkDev &d, int skip, NkWalk &w) {
-    const int NL = d.tree_leaves;
+// lds / lds_fam0: the families from lds_fam0 up in LDS (k_events), the others -- all of them for the other callers -- in global memory
+__device__ __forceinline__ bool nk_walk_boxes(const NkDev &d, int skip, NkWalk &w, const float4 *lds = nullptr, int lds_fam0 = 0x7fffffff) {
     int l = w.l;
     if (w.enter) {                      // the four boxes of family `fam` of level l, requested together
 #ifdef NK_TREE_STATS
@@ -833,21 +868,27 @@ __device__ __forceinline__ bool nk_walk_boxes(const NkDev &d, int skip, NkWalk &
         int base = d.tree_base[0];
 #pragma unroll
         for (int k = 1; k < NK_TREE_LEVELS; ++k) base = (l == k) ? d.tree_base[k] : base;
-        const int cnt = (NL + (1 << (2 * l)) - 1) >> (2 * l);
-        const float4 *B = reinterpret_cast<const float4 *>(d.tree_boxes + (size_t)((base >> 2) + w.fam) * NK_TREE_FAMILY_FLOATS);
+        const int fi = (base >> 2) + w.fam;
         float4 b[6];
+        if (fi >= lds_fam0) {
+            const float4 *B = lds + (size_t)(fi - lds_fam0) * (NK_TREE_FAMILY_FLOATS / 4);
 #pragma unroll
-        for (int k = 0; k < 6; ++k) b[k] = B[k];
+            for (int k = 0; k < 6; ++k) b[k] = B[k];
+        } else {
+            const float4 *B = reinterpret_cast<const float4 *>(d.tree_boxes + (size_t)fi * NK_TREE_FAMILY_FLOATS);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) b[k] = B[k];
+        }
         int4 tg = make_int4(-1, -1, -1, -1);             // facet tags, read only by a ray that starts on a large facet
         if (skip != NK_TREE_NO_SKIP) tg = reinterpret_cast<const int4 *>(d.tree_tags)[(base >> 2) + w.fam];
         // the best hit so far as a float that is not below it
         float tmax = (float)w.h.t;                       // inf stays inf
         tmax += tmax * 1.1920929e-07f;
-        const int f4 = 4 * w.fam;
-        const uint32_t m = ((uint32_t)((f4 + 0 < cnt) & (tg.x != skip) & nk_ray_box(b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, w.rf, tmax))) |
-                           ((uint32_t)((f4 + 1 < cnt) & (tg.y != skip) & nk_ray_box(b[1].z, b[1].w, b[2].x, b[2].y, b[2].z, b[2].w, w.rf, tmax)) << 1) |
-                           ((uint32_t)((f4 + 2 < cnt) & (tg.z != skip) & nk_ray_box(b[3].x, b[3].y, b[3].z, b[3].w, b[4].x, b[4].y, w.rf, tmax)) << 2) |
-                           ((uint32_t)((f4 + 3 < cnt) & (tg.w != skip) & nk_ray_box(b[4].z, b[4].w, b[5].x, b[5].y, b[5].z, b[5].w, w.rf, tmax)) << 3);
+        // (nodes beyond a level's count exist only as padding boxes, which no ray enters: no index test)
+        const uint32_t m = ((uint32_t)((tg.x != skip) & nk_ray_box(b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, w.rf, tmax))) |
+                           ((uint32_t)((tg.y != skip) & nk_ray_box(b[1].z, b[1].w, b[2].x, b[2].y, b[2].z, b[2].w, w.rf, tmax)) << 1) |
+                           ((uint32_t)((tg.z != skip) & nk_ray_box(b[3].x, b[3].y, b[3].z, b[3].w, b[4].x, b[4].y, w.rf, tmax)) << 2) |
+                           ((uint32_t)((tg.w != skip) & nk_ray_box(b[4].z, b[4].w, b[5].x, b[5].y, b[5].z, b[5].w, w.rf, tmax)) << 3);
         w.todo = (w.todo & ~(0xFu << (4 * l))) | (m << (4 * l));
         w.enter = false;
     }

@@ -96,6 +96,7 @@ struct nk_ctx {
     std::vector<double> h_vg;         // host copy of the group velocities (the mode map deals the modes by their event rate)
     std::vector<int32_t> h_m2s, h_s2m;  // host copies of the mode map (NkDev::m2s / s2m), built with the segmentation
     int32_t *m2s_dev = nullptr, *s2m_dev = nullptr, *nl_dev = nullptr;
+    int64_t ev_lds_set = -1;          // dynamic LDS k_events was last allowed (hipFuncSetAttribute)
     int map_nseg = 0;                 // segmentation the map was dealt for
     NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
     int64_t modetab_p_len = 0;
@@ -563,6 +564,7 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
     // centres, leaves of 4, every level the unions of 4 consecutive nodes of the level below.
     d.NG = 0;
     d.tree_top = 0; d.tree_leaves = 0;
+    d.tree_nfam = 0; d.tree_lds_fam0 = 0; d.tree_lds_off = 0;
     for (int k = 0; k < NK_TREE_LEVELS; ++k) d.tree_base[k] = 0;
     bool use_tree = !(m->F <= NK_LDS_FACES && m->Fc <= NK_LDS_FACES) && !getenv("NK_NO_TREE");   // env: developer probe
     std::vector<NkFaceRef> refs;
@@ -635,10 +637,13 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
         for (size_t i = 0; i < slot.size(); ++i) {
             if (slot[i] < 0) continue;
             const int f = refs[slot[i]].face;
-            double *q = &tf[i * NK_TREE_FACE_DOUBLES];
+            // (leaf layout by cache line, NK_TREE_FACE_DOUBLES in nk_device.h: the four planes, then one line per face)
+            double *leaf = &tf[(i / 4) * 4 * NK_TREE_FACE_DOUBLES];
+            const int c = (int)(i % 4);
             const double *src = &faces[(size_t)face_pos[f] * NK_FACE_DOUBLES];
+            double *q = leaf + 4 * c;
             q[0] = m->normals[3 * f]; q[1] = m->normals[3 * f + 1]; q[2] = m->normals[3 * f + 2]; q[3] = m->k[f];
-            memcpy(q + 4, src, NK_FACE_DOUBLES * sizeof(double));
+            memcpy(leaf + 16 + 16 * c, src, NK_FACE_DOUBLES * sizeof(double));
         }
         // boxes: union of the member faces' boxes, inflated by far more than any rounding in the slab test
         double big = 0.0;
@@ -691,6 +696,8 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
             ++level;
         }
         d.tree_top = level;
+        d.tree_nfam = (int32_t)(boxes.size() / 24);
+        d.tree_lds_fam0 = d.tree_nfam; d.tree_lds_off = 0;
         auto tree_base_of = [&](int lv) { return (int)d.tree_base[lv]; };
         d.tree_leaves = NL;
         d.NG = 1;
@@ -1832,7 +1839,23 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     (void)nk_sweep_blocks(ctx);
     const int g_sweep = ctx->g_sweep < (d.nseg + 3) / 4 ? ctx->g_sweep : (d.nseg + 3) / 4;
     const int g_emit = ctx->num_cu * 8 < (d.nseg + 3) / 4 ? ctx->num_cu * 8 : (d.nseg + 3) / 4;
-    const int g_ev = split_ ? ctx->num_cu * NK_EVENTS_OCC : 0;   // k_events: resident waves drawing from all queues
+    const int g_ev = split_ ? ctx->num_cu * NK_EV_PER_CU : 0;    // k_events: resident waves drawing from all queues
+    // k_events keeps the top of the face tree in LDS: as many whole levels as fit beside its tables at NK_EVENTS_OCC workgroups per CU
+    // (160 KB per CU; NK_EVENTS_TREE_LDS = bytes to use at most, 0 = none: developer probe)
+    size_t lds_ev = lds_g;
+    d.tree_lds_fam0 = d.tree_nfam; d.tree_lds_off = 0;
+    if (split_ && gm_ == 2 && d.NG > 0 && d.tree_nfam > 0) {
+        const size_t off = (lds_g + 15) & ~(size_t)15, fixed = off + (size_t)NK_EVENTS_PEND * NK_EV_WG * 4 + 1024;
+        size_t budget = (size_t)160 * 1024 / NK_EV_PER_CU > fixed ? (size_t)160 * 1024 / NK_EV_PER_CU - fixed : 0;
+        if (const char *e = getenv("NK_EVENTS_TREE_LDS")) { const size_t v = (size_t)atol(e); if (v < budget) budget = v; }
+        for (int l = 0; l <= d.tree_top; ++l) {
+            const int fam0 = d.tree_base[l] >> 2;
+            const size_t bytes = (size_t)(d.tree_nfam - fam0) * NK_TREE_FAMILY_FLOATS * 4;
+            if (bytes <= budget) { d.tree_lds_fam0 = fam0; d.tree_lds_off = (int32_t)off; lds_ev = off + bytes; break; }
+        }
+        if (getenv("NK_VERBOSE") && ctx->timing.batches <= 1)
+            fprintf(stderr, "[nanokappa_hip] k_events: families %d .. %d of the face tree in LDS (%zu B of %zu B per workgroup)\n", d.tree_lds_fam0, d.tree_nfam, lds_ev - off, lds_ev);
+    }
     const int rows = g_sweep + g_ev;
     // per-kernel timing on the first 4 steps of a batch; none for the short calls of a driver that steps one by one (six event
     // records are a tenth of such a call).  Every record is a marker packet between two dependent kernels: measured ~2 us each
@@ -1878,7 +1901,14 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
             NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, lrec_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux)));
             if (split_) {
                 k_events_begin<<<1, 1024, 0, ctx->stream>>>(d);
-                NK_EVENTS_DISPATCH(gm_, rough_, rbf_, pid_, (KERNEL<<<g_ev, NK_WG, lds_g, ctx->stream>>>(d, step, do_flux, g_sweep)));
+                const int64_t ev_key = (int64_t)lds_ev * 64 + (gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4));
+                if (ctx->ev_lds_set != ev_key) {        // more than the default 64 KB of dynamic LDS has to be asked for, per kernel
+                    hipError_t ea_ = hipSuccess;
+                    NK_EVENTS_DISPATCH(gm_, rough_, rbf_, pid_, (ea_ = hipFuncSetAttribute((const void *)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ev)));
+                    NK_HIP(ea_);
+                    ctx->ev_lds_set = ev_key;
+                }
+                NK_EVENTS_DISPATCH(gm_, rough_, rbf_, pid_, (KERNEL<<<g_ev, NK_EV_WG, lds_ev, ctx->stream>>>(d, step, do_flux, g_sweep)));
                 k_events_end<<<(d.nseg + 255) / 256, 256, 0, ctx->stream>>>(d);
             }
         }
@@ -2014,6 +2044,9 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
                 fprintf(stderr, "[stamps] k_events per segment %s: min %.0f  median %.0f  mean %.0f  p99 %.0f  max %.0f\n", nm, v.front(), v[v.size() / 2], sm / v.size(), v[(size_t)(v.size() * 0.99)], v.back());
             };
             stat(cyc, "cycles"); stat(wk, "cycles in walks"); stat(qq, "queue entries"); stat(ps, "walk passes");
+            std::vector<double> lc, ln;
+            for (int sgm = 0; sgm < d.nseg; ++sgm) { lc.push_back((double)(st[(size_t)sgm * 8 + 6] & ((1ull << 40) - 1))); ln.push_back((double)(st[(size_t)sgm * 8 + 6] >> 40)); }
+            stat(lc, "cycles in faces passes"); stat(ln, "faces passes");
         }
     }
 #endif

@@ -1138,11 +1138,23 @@ __global__ __launch_bounds__(NK_WG, NK_SWEEP_BOUND(GEOM, ROUGH, RBF, SPLIT)) voi
 // (5e7 particles in 4096 segments: 353 to 1181 queue entries, mean 668), so waves do not own segments here: the queues are
 // one concatenated list (prefix sums by k_events_begin) that all waves draw from through a ticket counter; a finished
 // particle takes its slot in its segment with an atomic on the segment's count.  k_events_end closes the step per segment.
+// One workgroup of NK_EV_WG threads per NK_EV_WG / (64 x 4 x NK_EVENTS_OCC) of a CU: the larger the workgroup, the more LDS it has for the face
+// tree's boxes (1024 threads at four waves per SIMD: the CU's whole 160 KB).
+#ifndef NK_EV_WG
+#define NK_EV_WG 1024
+#endif
+#define NK_EV_PER_CU ((NK_EVENTS_OCC * 256) / NK_EV_WG)
 #ifndef NK_EVENTS_LOW
 #define NK_EVENTS_LOW 16         // (round 4, wire at 5e7: 8 -> 3.636 ms per step, 16 -> 3.577, 24 -> 3.573; NK_EVENTS_LEAVES 16 / 32 / 48: 3.69 / 3.64 / 3.66)
 #endif
 #ifndef NK_EVENTS_LEAVES
-#define NK_EVENTS_LEAVES 32      // lanes waiting at a leaf that make a faces pass worth its instructions
+#define NK_EVENTS_LEAVES 32      // lanes holding a noted leaf that make a faces pass worth its instructions
+#endif
+#ifndef NK_EVENTS_PEND
+#define NK_EVENTS_PEND 4         // leaves a lane may note before it has to wait for a faces pass
+#endif
+#ifndef NK_EVENTS_STUCK
+#define NK_EVENTS_STUCK 16       // ... or that many walking lanes unable to go on through the boxes
 #endif
 #define NK_PH_NEED 0
 #define NK_PH_PRE 1
@@ -1180,7 +1192,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_events_end(NkDev d) {
     if (d.R > 0 && (int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
 }
 template <int GEOM, bool ROUGH, bool RBF, bool PID>
-__global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32_t step, int flags, int row0) {
+__global__ __launch_bounds__(NK_EV_WG, NK_EV_PER_CU) void k_events(NkDev d, uint32_t step, int flags, int row0) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (d.halt[0]) return;
     NkLds L;
@@ -1202,10 +1214,24 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
     int idx0 = 0, seg = 0;
     bool first = false;                               // the lane holds an entering particle before its first ray cast (k_emit)
     int skipl = NK_TREE_NO_SKIP;                      // facet whose nodes this lane's walk skips (nk_tree_skip)
+    __shared__ int pend[NK_EVENTS_PEND * NK_EV_WG];      // the leaves a lane has noted and not tested yet
+    int npend = 0;
+    bool wdone = false;                               // the lane's walk is through the boxes (noted leaves may be left)
     p.x = p.y = p.z = p.occ = p.nts = p.omega = p.E0 = p.vx = p.vy = p.vz = 0.0; p.mode = 0; p.facet = -1;
     nk_walk_begin(d, W, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0);
+    // the top levels of the face tree's boxes into LDS (as many whole levels as the host found room for): two thirds of a walk's
+    // visits, and every one of them a dependent load that the L1 serves in turn with the leaves' misses
+    const float4 *tl = reinterpret_cast<const float4 *>(smem + d.tree_lds_off);
+    const int tl_fam0 = tree ? d.tree_lds_fam0 : 0x7fffffff;
+    if (tree && d.tree_lds_fam0 < d.tree_nfam) {
+        float4 *dst = reinterpret_cast<float4 *>(smem + d.tree_lds_off);
+        const float4 *src = reinterpret_cast<const float4 *>(d.tree_boxes + (size_t)d.tree_lds_fam0 * NK_TREE_FAMILY_FLOATS);
+        const int n4 = (d.tree_nfam - d.tree_lds_fam0) * (NK_TREE_FAMILY_FLOATS / 4);
+        for (int i = tid; i < n4; i += NK_EV_WG) dst[i] = src[i];
+        __syncthreads();
+    }
 #ifdef NK_STAMPS
-    unsigned long long st_t0, st_walk = 0, st_pass = 0, st_got = 0;
+    unsigned long long st_t0, st_walk = 0, st_pass = 0, st_got = 0, st_leaf = 0, st_nleaf = 0;
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_t0)::"memory");
 #endif
     for (;;) {
@@ -1246,6 +1272,7 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
                         // the facet its walk may skip): its first ray cast is this walk; nk_newborn_place follows in the POST block
                         skipl = p.facet >= 0 ? p.facet : NK_TREE_NO_SKIP;
                         nk_walk_begin(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz);
+                        npend = 0; wdone = false;
                         phase = NK_PH_WALK;
                     }
 #ifdef NK_STAMPS
@@ -1258,13 +1285,19 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
         if (phase == NK_PH_PRE) {
             const int st = nk_event_pre<ROUGH, RBF>(d, L.facets, L.tb, L.resT, L.bins, p, cts, evc, pid, step);
             if (st == NK_EV_DEAD) phase = NK_PH_NEED;
-            else if (tree) { nk_walk_begin(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz); skipl = NK_TREE_NO_SKIP; phase = NK_PH_WALK; }
+            else if (tree) { nk_walk_begin(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz); npend = 0; wdone = false; skipl = NK_TREE_NO_SKIP; phase = NK_PH_WALK; }
             else {
                 nk_find_boundary(L.planes, L.faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, W.h.t, W.h.facet);
                 phase = NK_PH_POST;
             }
         }
         // ---- the walks, until few enough lanes are left in one (all of them, once no entries are left)
+        // A lane that reaches a leaf does not wait for a faces pass: it notes the leaf (up to NK_EVENTS_PEND of them, in LDS) and goes on
+        // through the boxes; the faces pass runs when enough lanes hold a leaf or cannot go on (list full, or boxes done), every lane
+        // taking the leaf it noted last.  A noted leaf is tested later than it would be in the walk proper, so the hits that would
+        // have shortened the ray come later and a few more boxes are entered -- the result is the same (earliest hit, lowest face
+        // index among equals, whatever the order).  Before: at most one leaf per lane, and up to NK_EVENTS_LEAVES - 1 lanes idle at
+        // theirs during every boxes pass (22 of 64 lanes active in the boxes passes of the 5000-triangle wire).
         {
             const int low = more ? NK_EVENTS_LOW : 0;
 #ifdef NK_STAMPS
@@ -1272,15 +1305,37 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
             asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_a)::"memory");
 #endif
             for (;;) {
-                const unsigned long long mW = __ballot(phase == NK_PH_WALK), mL = __ballot(phase == NK_PH_WALK && W.leaf >= 0);
-                const int nw = __popcll(mW), nl = __popcll(mL);
+                const bool walking = phase == NK_PH_WALK;
+                const bool boxes = walking && !wdone && npend < NK_EVENTS_PEND;
+                const unsigned long long mW = __ballot(walking), mB = __ballot(boxes), mL = __ballot(walking && npend > 0);
+                const int nw = __popcll(mW), nb = __popcll(mB), nl = __popcll(mL);
                 if (nw <= low) break;
-                // the faces once enough lanes wait at a leaf (or none has boxes to do), else the boxes
-                if (nl >= NK_EVENTS_LEAVES || nl == nw) { if (phase == NK_PH_WALK && W.leaf >= 0) nk_walk_leaf(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz); }
-                // (the entering particles sit together at the head of every segment's queue, so few passes hold a lane whose walk
-                // skips a facet: those passes alone pay for the facet tags)
-                else if (__ballot(phase == NK_PH_WALK && skipl != NK_TREE_NO_SKIP) != 0ull) { if (phase == NK_PH_WALK && W.leaf < 0 && nk_walk_boxes(d, skipl, W)) phase = NK_PH_POST; }
-                else if (phase == NK_PH_WALK && W.leaf < 0 && nk_walk_boxes(d, NK_TREE_NO_SKIP, W)) phase = NK_PH_POST;
+                if (nb == 0 || nl >= NK_EVENTS_LEAVES || nw - nb >= NK_EVENTS_STUCK) {        // the faces of one noted leaf per lane
+#ifdef NK_STAMPS
+                    unsigned long long st_c, st_d;
+                    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c)::"memory");
+#endif
+                    if (walking && npend > 0) {
+                        --npend;
+                        W.leaf = pend[npend * NK_EV_WG + tid];
+                        nk_walk_leaf(d, W, p.x, p.y, p.z, p.vx, p.vy, p.vz);
+                        if (wdone && npend == 0) phase = NK_PH_POST;
+                    }
+#ifdef NK_STAMPS
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_d)::"memory");
+                    st_leaf += st_d - st_c; st_nleaf += 1;
+#endif
+                } else {
+                    // (the entering particles sit together at the head of every segment's queue, so few passes hold a lane whose walk
+                    // skips a facet: those passes alone pay for the facet tags)
+                    bool over = false;
+                    if (__ballot(boxes && skipl != NK_TREE_NO_SKIP) != 0ull) { if (boxes) over = nk_walk_boxes(d, skipl, W, tl, tl_fam0); }
+                    else if (boxes) over = nk_walk_boxes(d, NK_TREE_NO_SKIP, W, tl, tl_fam0);
+                    if (boxes) {
+                        if (W.leaf >= 0) { pend[npend * NK_EV_WG + tid] = W.leaf; ++npend; W.leaf = -1; }
+                        if (over) { wdone = true; if (npend == 0) phase = NK_PH_POST; }
+                    }
+                }
 #ifdef NK_STAMPS
                 st_pass += 1;
 #endif
@@ -1343,7 +1398,7 @@ __global__ __launch_bounds__(NK_WG, NK_EVENTS_OCC) void k_events(NkDev d, uint32
         const int wv = blockIdx.x * (blockDim.x >> 6) + (tid >> 6);
         if (wv < d.nseg) {
             unsigned long long *o = d.stamps + (int64_t)wv * 8;
-            o[3] = t1 - st_t0; o[4] = st_walk; o[5] = (st_got << 32) | st_pass;
+            o[3] = t1 - st_t0; o[4] = st_walk; o[5] = (st_got << 32) | st_pass; o[6] = (st_nleaf << 40) | st_leaf;
         }
     }
 #endif
