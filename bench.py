@@ -284,6 +284,9 @@ def main():
     ap.add_argument('--per-call', type=int, default=None,
                     help='Population.run_timestep calls of the `per_call` leg (the reference driver\'s granularity); '
                          'default 500 for the default line, 0 otherwise')
+    ap.add_argument('--small', type=int, default=None,
+                    help='steps per region of the `small_ensemble` leg (BASELINE config 1 at its own 1e5 particles, launch-per-step path '
+                         'and resident kernel); default 500 for the default line, else 0')
     ap.add_argument('--calibrate', action='store_true',
                     help='after the timed region run 3 known-traffic sweeps (k_cal_stream) for PMC calibration')
     a = ap.parse_args()
@@ -331,6 +334,7 @@ def main():
     default_line = world == 1 and a.config == 'c2' and a.particles is None
     n_sustained = a.sustained if a.sustained is not None else (10000 if default_line else 0)
     n_per_call = a.per_call if a.per_call is not None else (500 if default_line else 0)
+    n_small = a.small if a.small is not None else (500 if default_line else 0)
     cpu_legs = world == 1 and not a.no_cpu_baseline
     rough_cfg = a.config in ('c1b', 'c4')
     all_cores = None
@@ -417,6 +421,35 @@ def main():
                          what='Population.run(%d) in one go (100-step library calls, every tenth step a convergence row); kappa over '
                               'the rows of the second half' % n_sustained)
 
+    # ---- BASELINE config 1 at its own size (1e5 particles): the launch-per-step path and the resident kernel (NK_RESIDENT=1), same box
+    small = None
+    if n_small > 0:
+        argv_s, _, desc_s = config_argv('c2', 100000, a.box)
+        args_s = initialise_parser().parse_args(argv_s + ['--seed', '2025', '--device', str(args.device[0])])
+        args_s.results_folder = ''
+        geo_s = quiet(Geometry, args_s)
+        small = dict(particles=100000, steps=n_small, unit='phonon-steps/s',
+                     what='%d^3x6 modes, %s, 1e5 particles (BASELINE config 1); median of 3 regions of %d steps after %d warm-up steps; '
+                          'resident_kernel: one launch per library call (k_resident, opt-in NK_RESIDENT=1)' % (a.mesh_n, desc_s, n_small, n_small))
+        for leg, env in (('launch_per_step', None), ('resident_kernel', '1')):
+            if env is None:
+                os.environ.pop('NK_RESIDENT', None)
+            else:
+                os.environ['NK_RESIDENT'] = env
+            pop_s = quiet(Population, args_s, geo_s, ph, None, None)
+            es = pop_s.engine
+            es.step(n_small)
+            reg = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ts = es.step(n_small)
+                reg.append((time.perf_counter() - t0, float(ts['N_sv'].sum())))
+            reg.sort()
+            dt_r, ps_r = reg[1]
+            small[leg] = dict(ms_per_step=1e3 * dt_r / n_small, value=ps_r / dt_r, emit_fused=int(es.timing().get('emit_fused', 0)))
+            es.close()
+        os.environ.pop('NK_RESIDENT', None)
+
     if rank == 0:
         live_rank = tm['live'] / world if world > 1 else tm['live']
         k_ms = float(np.median([r['tm']['step_kernel_ms'] for r in runs]))
@@ -473,6 +506,8 @@ def main():
             raise SystemExit('bench.py: RCCL reports %d ranks, the launcher %d' % (ranks[0]['comm_nranks'], world))
         if per_call is not None:
             out['per_call'] = per_call
+        if small is not None:
+            out['small_ensemble'] = small
         if sustained is not None:
             out['sustained'] = sustained
             # kappa is half of BASELINE's metric: a line whose sustained leg recorded convergence rows but no finite kappa

@@ -96,6 +96,7 @@ struct nk_ctx {
     std::vector<double> h_vg;         // host copy of the group velocities (the mode map deals the modes by their event rate)
     std::vector<int32_t> h_m2s, h_s2m;  // host copies of the mode map (NkDev::m2s / s2m), built with the segmentation
     int32_t *m2s_dev = nullptr, *s2m_dev = nullptr, *nl_dev = nullptr;
+    unsigned int *rbar = nullptr;     // k_resident: step word, halt word, one flag per workgroup
     int64_t ev_lds_set = -1;          // dynamic LDS k_events was last allowed (hipFuncSetAttribute)
     int map_nseg = 0;                 // segmentation the map was dealt for
     NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
@@ -107,7 +108,6 @@ struct nk_ctx {
     void *pin = nullptr;           // pinned host staging of the history rows + the halt words of a batch
     size_t pin_bytes = 0;
     int32_t halt_words[4] = {0, 0, 0, 0};
-    double *racc = nullptr;        // [3][384]: the resident kernel's rotating tally accumulators (k_resident)
     double *acc = nullptr;         // [NB + 2]: tally columns, then the two halt requests that travel with them
     double *hist = nullptr;        // [hist_cap][HROW]
     int hist_cap = 0;
@@ -418,7 +418,7 @@ void nk_destroy(nk_ctx *ctx) {
     for (void *p : ctx->allocs) hipFree(p);
     for (void *p : ctx->pallocs) hipFree(p);
     if (ctx->acc) hipFree(ctx->acc);
-    if (ctx->racc) hipFree(ctx->racc);
+    if (ctx->rbar) hipFree(ctx->rbar);
     if (ctx->pin) hipHostFree(ctx->pin);
     if (ctx->hist) hipHostFree(ctx->hist);
     if (ctx->modetab_p) hipFree(ctx->modetab_p);
@@ -920,8 +920,6 @@ static int nk_alloc_tally(nk_ctx *ctx) {
     ctx->hist_cap = 0;
     NK_HIP(hipMalloc((void **)&ctx->acc, (size_t)(d.NB + 2) * sizeof(double)));
     NK_HIP(hipMemset(ctx->acc, 0, (size_t)(d.NB + 2) * sizeof(double)));
-    if (!ctx->racc) NK_HIP(hipMalloc((void **)&ctx->racc, 3 * 384 * sizeof(double)));
-    NK_HIP(hipMemset(ctx->racc, 0, 3 * 384 * sizeof(double)));
     const double *p;
     NK_UP((const double *)nullptr, (size_t)(ctx->num_cu * 16) * d.NB, &p);     // >= the sweep's and k_events' persistent grids
     d.partials = (double *)p;
@@ -2089,7 +2087,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
 static inline bool nk_want_resident(const nk_ctx *ctx) {
     const NkDev &d = ctx->d;
     if (!getenv("NK_RESIDENT") || getenv("NK_NO_RESIDENT") || ctx->comm || d.nranks != 1 || d.Fr > 0 || d.mig_buf || d.qx || nk_geom_mode(ctx) != 1) return false;
-    if (d.res_gen == 2 || d.sv_interp == 3 || d.NB > 384 || d.nseg <= 0) return false;
+    if (d.res_gen == 2 || d.sv_interp == 3 || d.NB > 254 || d.nseg <= 0) return false;
     const int64_t lim = getenv("NK_RESIDENT_MAX") ? atoll(getenv("NK_RESIDENT_MAX")) : 1200000;
     return d.cap <= lim && nk_lds(ctx, true, 5) <= 160 * 1024;
 }
@@ -2138,7 +2136,7 @@ static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h,
     const bool relax0 = ctx->pending_relax;
     bool pending = ctx->pending_relax, flushed_first = false;
     ctx->timing.emit_fused = 2;                                   // (2: emission inside the resident kernel)
-    NK_HIP(hipMemsetAsync(ctx->racc, 0, 3 * 384 * sizeof(double), ctx->stream));     // (a halted launch leaves sums behind)
+    if (!ctx->rbar) NK_HIP(hipMalloc((void **)&ctx->rbar, (32 + 4096) * sizeof(unsigned int)));
     NK_HIP(hipEventRecord(t0, ctx->stream));
     const int ce = ctx->params.contains_every;
     int launches = 0;
@@ -2154,8 +2152,9 @@ static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h,
         }
         int n = nsteps - k;
         if (ce > 0 && d.nS > 0) n = std::min<int64_t>(n, ce - (stepno % ce));
+        NK_HIP(hipMemsetAsync(ctx->rbar, 0, (32 + (size_t)G) * sizeof(unsigned int), ctx->stream));      // flags and step word count from 1 in every launch
         NK_RESIDENT_DISPATCH(box_, pid_, lrec_, (KERNEL<<<G, NK_WG, lds, ctx->stream>>>(d, (uint32_t)stepno, n, pending ? 1 : 0, ctx->params.flux_every,
-                                                                                       ctx->hist + (size_t)k * HROW, HROW, (unsigned int *)ctx->anomalies + 1, ctx->racc)));
+                                                                                       ctx->hist + (size_t)k * HROW, HROW, ctx->rbar)));
         NK_HIP(hipGetLastError());
         pending = true;
         k += n;
@@ -2175,6 +2174,14 @@ static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h,
     int32_t nd = 0;
     while (nd < nsteps && h[(size_t)nd * HROW + NB + 2 * S + 1] != 0.0) ++nd;
     *done = nd;
+    if (getenv("NK_VERBOSE") && ctx->timing.batches % 8 == 2) {   // developer probe: the clock marks of the launch's last step (10 ns ticks)
+        unsigned long long m[12];
+        NK_HIP(hipMemcpy(m, ctx->rbar + 8, sizeof(m), hipMemcpyDeviceToHost));
+        if (m[0] && m[6] >= m[0])
+            fprintf(stderr, "[nanokappa_hip] resident step, workgroup 0 [us]: sweep %.2f  row + flag %.2f  emission %.2f  all flags seen %.2f  rows summed %.2f  update published %.2f | workgroup G/2: sweep %.2f  row + emission %.2f  update seen %.2f\n",
+                    (m[1] - m[0]) * 0.01, (m[2] - m[1]) * 0.01, (m[3] - m[2]) * 0.01, (m[4] - m[3]) * 0.01, (m[5] - m[4]) * 0.01, (m[6] - m[5]) * 0.01,
+                    (m[9] - m[8]) * 0.01, (m[10] - m[9]) * 0.01, (m[11] - m[10]) * 0.01);
+    }
     if (nd > 0) ctx->pending_relax = true;
     else ctx->pending_relax = relax0 && !flushed_first;
     float ms = 0.f;

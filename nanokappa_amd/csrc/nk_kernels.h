@@ -1610,47 +1610,38 @@ __global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int
 
 // =============================================================================== small ensembles: the resident kernel
 // Config 1's own size (1e5 particles: 3.6 MB of state) spends a step in launches and latency chains -- k_sweep 22 us + k_tail
-// 24 us for a few microseconds of arithmetic (round 3).  Here ONE launch runs many steps: the workgroups stay resident, the
-// read-only tables are staged in LDS once, and a step is  emission -> sweep -> the workgroup's tally sums added to a global
-// accumulator (FP64 atomics) -> grid barrier -> every workgroup reads the totals and inverts E -> T itself (redundantly: no
-// second barrier, no broadcast) -> next step.  (First version: every workgroup wrote its row and summed all G rows itself, in a
-// fixed order: G x G x NB coherent loads per step -- 0.100 ms per step at 1e5 particles, slower than the launches it replaced.)
-// The accumulator rotates over three copies: step s adds to copy s % 3, everybody reads it after the barrier, and workgroup 0
-// clears copy (s + 2) % 3, which nobody touches until step s + 2 has passed the next barrier.
-// The only data that crosses workgroups is the tally rows (the S-vector coupling of refresh_temperatures, Population.py:685-702);
-// a segment is swept by the same wave at every step.  Same device functions as the launch-per-step path (nk_emit_segments,
-// nk_sweep_body, nk_update_sv); only the order in which the workgroups' tally sums are added differs from the launch-per-step
-// path's -- and from run to run (atomics): subvolume energies agree to the last bits, not bit for bit.
+// 10 us + the gaps between them for a few microseconds of arithmetic.  Here ONE launch runs many steps: the workgroups stay
+// resident, the read-only tables are staged in LDS once, a segment is swept by the same wave at every step (so its particles stay
+// in that XCD's L2), and a step is
+//     sweep -> the workgroup's tally row to global memory, its flag raised -> the NEXT step's emission (depends on nothing of this
+//     step's update, like in k_tail) -> workgroup 0: waits for all flags, sums the rows column by column in a fixed order, inverts
+//     E -> T (nk_update_sv), writes the history row, publishes T and the step's number; the others: wait for that number, read T.
+// What crosses workgroups is the tally rows and the S temperatures (the S-vector coupling of refresh_temperatures,
+// Population.py:685-702) -- all of it through agent-scope atomic loads and stores (write-through / read-through at the level where
+// the eight XCDs agree), ordered by "my stores have completed" (a workgroup-scope fence = s_waitcnt) before the flag goes up.
+// No __threadfence(): an agent-scope release writes back, an acquire invalidates, the XCD's WHOLE L2 -- the particles with it.
+// (Round 4's first version added every workgroup's 111 sums to one accumulator with FP64 atomics and met at a counter: 28 000
+// atomics on 111 addresses + 256 on one, every one of them serialised where the XCDs agree, plus those fences: a floor of 75 us
+// per step whatever the ensemble.  The version before that: every workgroup summing all G rows itself.)
+// Same device functions as the launch-per-step path (nk_emit_segments, nk_sweep_body, nk_update_sv); the rows are summed in a
+// fixed order (deterministic), though not in k_reduce's: subvolume energies agree with the launch path to the last bits, not bit
+// for bit.
 // Conditions (host, nk_step_resident): one rank, no rough facets (their migrants cross segments), small mesh, not 'one_to_one',
-// no RBF temperatures; contains_check steps start a new launch.
-// The barrier: arrival counter + generation word in device memory, agent-scope atomics; a release fence before and an acquire
-// fence after it make the rows visible across the XCDs' L2s.  Every workgroup must be resident: the grid is at most one
-// workgroup per CU.  A barrier that is not met within ~2 s gives up (overflow bit 256) instead of hanging the device.
-__device__ __forceinline__ bool nk_grid_barrier(unsigned int *bar, int G) {
-    __syncthreads();
-    int ok = 1;
-    if (threadIdx.x == 0) {
-        __threadfence();
-        const unsigned int gen = __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__hip_atomic_fetch_add(bar, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == (unsigned int)G - 1u) {
-            __hip_atomic_store(bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(bar + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            int spins = 0;
-            while (__hip_atomic_load(bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > 2000000) { ok = 0; break; }
-            }
-        }
-        __threadfence();
+// no RBF temperatures; contains_check steps start a new launch.  Every workgroup must be resident: the grid is at most what the
+// occupancy query allows.  A wait that is not met within ~2 s gives up (overflow bit 256) instead of hanging the device.
+// bar[0]: steps of this launch whose update is published; bar[1]: that update asked for a halt; bar[32 + g]: steps of this launch
+// whose row workgroup g has written.  Zeroed by the host before every launch.
+__device__ __forceinline__ bool nk_wait_word(const unsigned int *w, unsigned int atleast) {
+    int spins = 0;
+    while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < atleast) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > 1000000) return false;
     }
-    ok = __syncthreads_and(ok);
-    __threadfence();                                  // every wave: its own acquire
-    return ok != 0;
+    return true;
 }
 template <bool BOX, bool PID, bool LREC>
 __global__ __launch_bounds__(NK_WG, 2) void k_resident(NkDev d, uint32_t step0, int nsteps, int relax0, int flux_every, double *hist, int hrow,
-                                                       unsigned int *bar, double *racc) {
+                                                       unsigned int *bar) {
     extern __shared__ __align__(16) unsigned char smem[];
     if (d.halt[0]) return;
     NkLds L;
@@ -1661,65 +1652,143 @@ __global__ __launch_bounds__(NK_WG, 2) void k_resident(NkDev d, uint32_t step0, 
     NkSv *sv = const_cast<NkSv *>(L.tb.sv);
     const int nE = d.nE;
     const double Ta = d.Tarr[0], Tb = d.Tarr[1], Tz = d.Tarr[nE - 1], Ea = d.Earr[0], Ez = d.Earr[nE - 1];
+    unsigned int *flags = bar + 32;
+    unsigned long long *rows = reinterpret_cast<unsigned long long *>(d.partials);
+    unsigned long long *Tpub = reinterpret_cast<unsigned long long *>(d.T_sv);
+    const int NBP = (NB + 1) & ~1;                                // a row's length in memory (even: pairs of columns, 16-byte loads)
+    double *tot = L.colsum + 512;                                 // the column sums of the step (workgroup 0); L.colsum[0 .. 511]: the quarters' partial sums
+    unsigned long long *dbg = reinterpret_cast<unsigned long long *>(bar + 8);   // developer probe: 100 MHz clock marks of the launch's last step
+#ifdef NK_STAMPS
+    if (R > 0) nk_emit_segments<1, BOX>(d, L, step0, wg, G, false, 0ull, 0ull);
+#else
+    if (R > 0) nk_emit_segments<1, BOX>(d, L, step0, wg, G, false);
+#endif
     for (int s = 0; s < nsteps; ++s) {
         const uint32_t step = step0 + (uint32_t)s;
         const int do_flux = (flux_every > 0 && ((step + 1u) % (uint32_t)flux_every) == 0u) ? 1 : 0;
+        const bool mark = s == nsteps - 1 && tid == 0 && (wg == 0 || wg == G / 2);
+        unsigned long long *mk = dbg + (wg == 0 ? 0 : 8);
+        if (mark) mk[0] = __builtin_amdgcn_s_memrealtime();
 #ifdef NK_STAMPS
-        if (R > 0) nk_emit_segments<1, BOX>(d, L, step, wg, G, false, 0ull, 0ull);
         nk_sweep_body<1, false, false, PID, false, LREC, 0, BOX>(d, L, step, s == 0 ? relax0 : 1, do_flux, wg, G, 0ull);
 #else
-        if (R > 0) nk_emit_segments<1, BOX>(d, L, step, wg, G, false);
         nk_sweep_body<1, false, false, PID, false, LREC, 0, BOX>(d, L, step, s == 0 ? relax0 : 1, do_flux, wg, G);
 #endif
-        // this workgroup's tally sums (the row of nk_lds_flush) -> the step's accumulator
+        // ---- this workgroup's tally sums (the row of nk_lds_flush), then its flag
         __syncthreads();
-        {
-            double *acc = racc + (size_t)(step % 3u) * 384;
-            for (int b = tid; b < NB; b += NK_WG) {
-                double v = 0.0;
-                if (b < S) { for (int r = 0; r < NK_NREP; ++r) v += L.bins.E[r * S + b]; }
-                else if (b < 2 * S) { unsigned int c = 0; for (int r = 0; r < NK_NREP; ++r) c += L.bins.N[r * S + (b - S)]; v = (double)c; }
-                else if (b < 5 * S) { const int k = b - 2 * S; for (int r = 0; r < NK_NREP; ++r) v += L.bins.flux[r * 3 * S + k]; }
-                else if (b < 5 * S + R) v = (double)L.bins.nleave[b - 5 * S];
-                else if (b < 5 * S + 2 * R) v = L.bins.resb[4 * (b - 5 * S - R)];
-                else if (b < 5 * S + 5 * R) { const int k = b - 5 * S - 2 * R; v = L.bins.resb[4 * (k / 3) + 1 + (k % 3)]; }
-                else v = (double)L.bins.misc[0];
-                if (v != 0.0) atomicAdd(acc + b, v);
-            }
+        if (mark) mk[1] = __builtin_amdgcn_s_memrealtime();
+        for (int b = tid; b < NB; b += NK_WG) {
+            double v = 0.0;
+            if (b < S) { for (int r = 0; r < NK_NREP; ++r) v += L.bins.E[r * S + b]; }
+            else if (b < 2 * S) { unsigned int c = 0; for (int r = 0; r < NK_NREP; ++r) c += L.bins.N[r * S + (b - S)]; v = (double)c; }
+            else if (b < 5 * S) { const int k = b - 2 * S; for (int r = 0; r < NK_NREP; ++r) v += L.bins.flux[r * 3 * S + k]; }
+            else if (b < 5 * S + R) v = (double)L.bins.nleave[b - 5 * S];
+            else if (b < 5 * S + 2 * R) v = L.bins.resb[4 * (b - 5 * S - R)];
+            else if (b < 5 * S + 5 * R) { const int k = b - 5 * S - 2 * R; v = L.bins.resb[4 * (k / 3) + 1 + (k % 3)]; }
+            else v = (double)L.bins.misc[0];
+            __hip_atomic_store(rows + (size_t)wg * NBP + b, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (!nk_grid_barrier(bar, G)) { if (tid == 0) atomicOr(d.overflow, 256); return; }
-        __builtin_amdgcn_s_dcache_inv();                      // (nothing uniform that this kernel writes should sit in the scalar cache; belt and braces)
-        {
-            const unsigned long long *acc = reinterpret_cast<const unsigned long long *>(racc + (size_t)(step % 3u) * 384);
-            for (int b = tid; b < NB; b += NK_WG) L.colsum[b] = __longlong_as_double((long long)__hip_atomic_load(acc + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (wg == 0) { double *z = racc + (size_t)((step + 2u) % 3u) * 384; for (int b = tid; b < NB; b += NK_WG) z[b] = 0.0; }
-        }
-        const int hreq = __hip_atomic_load(d.halt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a sweep of this step asked for head room
+        if (tid == 0 && NBP > NB) __hip_atomic_store(rows + (size_t)wg * NBP + NB, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // the row's stores have completed (no cache is written back)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
-        // ---- update (every workgroup, for its own LDS copy of the temperatures; workgroup 0 also publishes)
-        double *hrowp = hist + (size_t)s * hrow;
-        for (int t = tid; t < S; t += NK_WG) {
-            double Tnew, E;
-            nk_update_sv(d, L.colsum[t], L.colsum[S + t], d.T_ref_local ? Tsv[t] : d.T_ref, t, Ta, Tb, Tz, Ea, Ez, Tnew, E);
-            Tsv[t] = Tnew;
-            if (wg == 0) { hrowp[NB + t] = Tnew; hrowp[NB + S + t] = E; d.T_sv[t] = Tnew; }
-        }
+        if (tid == 0) __hip_atomic_store(flags + wg, (unsigned int)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // bins back to zero (what nk_lds_setup does at a launch's start): the next step's emission tallies into them
+        for (int i = tid; i < NK_NREP * S; i += NK_WG) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
+        for (int i = tid; i < NK_NREP * 3 * S; i += NK_WG) L.bins.flux[i] = 0.0;
+        for (int i = tid; i < 4 * R; i += NK_WG) L.bins.resb[i] = 0.0;
+        for (int i = tid; i < R; i += NK_WG) L.bins.nleave[i] = 0u;
+        if (tid == 0) L.bins.misc[0] = 0u;
+        __syncthreads();
+        if (mark && wg == 0) mk[2] = __builtin_amdgcn_s_memrealtime();
+        // ---- the next step's emission, while the rows travel (ahead of this step's update: it may run again after a halt)
+#ifdef NK_STAMPS
+        if (R > 0 && s + 1 < nsteps) nk_emit_segments<1, BOX>(d, L, step + 1u, wg, G, true, 0ull, 0ull);
+#else
+        if (R > 0 && s + 1 < nsteps) nk_emit_segments<1, BOX>(d, L, step + 1u, wg, G, true);
+#endif
+        int ok = 1, hreq = 0;
+        if (mark) mk[wg == 0 ? 3 : 2] = __builtin_amdgcn_s_memrealtime();
         if (wg == 0) {
-            for (int b = tid; b < NB; b += NK_WG) hrowp[b] = L.colsum[b];
+            for (int g = tid; g < G; g += NK_WG) if (!nk_wait_word(flags + g, (unsigned int)(s + 1))) ok = 0;
+            ok = __syncthreads_and(ok);
+            if (!ok) { if (tid == 0) { atomicOr(d.overflow, 256); __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(bar, (unsigned int)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
+            if (mark) mk[4] = __builtin_amdgcn_s_memrealtime();
+            // column sums over the G rows, rows in order within a thread, threads in order: a thread takes a PAIR of columns (one
+            // 16-byte load per row) over a quarter of the rows, sixteen loads in flight (the loads bypass the caches: each is a
+            // trip to where the XCDs agree, ~2 us, and only as many of them overlap as the code has in flight)
+            {
+                const int npair = NBP / 2, q4 = tid >> 6, ln = tid & 63;
+                const int gq = (G + 3) / 4, g0 = q4 * gq, g1 = g0 + gq < G ? g0 + gq : G;
+                for (int p0 = 0; p0 < npair; p0 += 64) {
+                    const int pr = p0 + ln;
+                    double2 sum = make_double2(0.0, 0.0);
+                    if (pr < npair) {
+                        for (int g = g0; g < g1; g += 16) {
+                            typedef double nk_d2 __attribute__((ext_vector_type(2)));
+                            nk_d2 v[16];
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) {
+                                const int gg = g + k < g1 ? g + k : g1 - 1;
+                                const unsigned long long *src = rows + (size_t)gg * NBP + 2 * pr;
+                                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(src) : "memory");
+                            }
+                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
+                                         "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : : "memory");
+#pragma unroll
+                            for (int k = 0; k < 16; ++k) if (g + k < g1) { sum.x += v[k].x; sum.y += v[k].y; }
+                        }
+                        double *part = L.colsum + (size_t)q4 * 64 * 2 + 2 * ln;          // [4][64][2] of the 4 x 128 doubles
+                        part[0] = sum.x; part[1] = sum.y;
+                    }
+                    __syncthreads();
+                    if (q4 == 0 && pr < npair) {
+                        const double *part = L.colsum + 2 * ln;
+                        const double sx = ((part[0] + part[128]) + part[256]) + part[384], sy = ((part[1] + part[129]) + part[257]) + part[385];
+                        tot[2 * pr] = sx; tot[2 * pr + 1] = sy;
+                    }
+                    __syncthreads();
+                }
+            }
+            if (mark) mk[5] = __builtin_amdgcn_s_memrealtime();
+            hreq = __hip_atomic_load(d.halt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a sweep of this step asked for head room
+            // ---- update
+            double *hrowp = hist + (size_t)s * hrow;
+            for (int t = tid; t < S; t += NK_WG) {
+                double Tnew, E;
+                nk_update_sv(d, tot[t], tot[S + t], d.T_ref_local ? Tsv[t] : d.T_ref, t, Ta, Tb, Tz, Ea, Ez, Tnew, E);
+                Tsv[t] = Tnew;
+                hrowp[NB + t] = Tnew; hrowp[NB + S + t] = E;
+                __hip_atomic_store(Tpub + t, (unsigned long long)__double_as_longlong(Tnew), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            for (int b = tid; b < NB; b += NK_WG) hrowp[b] = tot[b];
             if (tid == 0) {
                 hrowp[NB + 2 * S + 0] = (double)do_flux;
                 hrowp[NB + 2 * S + 1] = 1.0;
                 hrowp[NB + 2 * S + 2] = hreq ? 1.0 : 0.0;
-                hrowp[NB + 2 * S + 3] = (double)*d.overflow;
+                hrowp[NB + 2 * S + 3] = (double)__hip_atomic_load(d.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 hrowp[NB + 2 * S + 4] = hreq ? 1.0 : 0.0;
                 hrowp[NB + 2 * S + 5] = (double)hreq;
                 hrowp[NB + 2 * S + 6] = (double)d.halt[2];
                 hrowp[NB + 2 * S + 7] = (double)d.halt[3];
-                if (hreq) d.halt[0] = 1;
+                if (hreq) { d.halt[0] = 1; __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
             }
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(bar, (unsigned int)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mark) mk[6] = __builtin_amdgcn_s_memrealtime();
+        } else {
+            if (tid == 0) ok = nk_wait_word(bar, (unsigned int)(s + 1)) ? 1 : 0;
+            ok = __syncthreads_and(ok);
+            if (!ok) { if (tid == 0) atomicOr(d.overflow, 256); return; }
+            for (int t = tid; t < S; t += NK_WG) Tsv[t] = __longlong_as_double((long long)__hip_atomic_load(Tpub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            hreq = (int)__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (mark) mk[3] = __builtin_amdgcn_s_memrealtime();
         }
+        __builtin_amdgcn_s_dcache_inv();                      // (nothing uniform that this kernel writes should sit in the scalar cache; belt and braces)
         __syncthreads();
-        // per-subvolume records of the new temperatures, bins back to zero (what nk_lds_setup does at a launch's start)
+        // per-subvolume records of the new temperatures
         for (int t = tid; t < S; t += NK_WG) {
             const int jn = t + 1 < S ? t + 1 : t;
             NkSv q;
@@ -1728,11 +1797,6 @@ __global__ __launch_bounds__(NK_WG, 2) void k_resident(NkDev d, uint32_t step0, 
             q.invT = 1.0 / Tsv[t];
             sv[t] = q;
         }
-        for (int i = tid; i < NK_NREP * S; i += NK_WG) { L.bins.E[i] = 0.0; L.bins.N[i] = 0u; }
-        for (int i = tid; i < NK_NREP * 3 * S; i += NK_WG) L.bins.flux[i] = 0.0;
-        for (int i = tid; i < 4 * R; i += NK_WG) L.bins.resb[i] = 0.0;
-        for (int i = tid; i < R; i += NK_WG) L.bins.nleave[i] = 0u;
-        if (tid == 0) L.bins.misc[0] = 0u;
         __syncthreads();
         if (hreq) return;                                     // the host grows the store and carries on
     }

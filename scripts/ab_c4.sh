@@ -5,7 +5,7 @@ for spec in "$@"; do
   lib=${spec%%:*}; envs=""; [[ "$spec" == *:* ]] && envs=${spec#*:}
   name=$(echo "$spec" | tr ':=/' '___')
   ( [[ "$lib" != "-" ]] && export NK_LIBNAME=$lib; [[ -n "$envs" ]] && export $envs
-    NK_VERBOSE=1 timeout -k 10 400 python3 $R/bench.py --config c4 --steps 20 --warmup 10 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 > $O/$name.json 2> $O/$name.err )
+    NK_VERBOSE=1 timeout -k 10 400 python3 $R/bench.py --config c4 --steps 20 --warmup 10 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > $O/$name.json 2> $O/$name.err )
   echo "$spec rc $?"
 done
 grep -h "k_events:" $O/*.err | sort | uniq -c

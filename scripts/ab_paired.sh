@@ -5,7 +5,7 @@ tag=$1; libs=$2; cfgs=$3; rounds=${4:-3}
 out=gpurun_out/$tag; mkdir -p $out
 for r in $(seq 1 $rounds); do for c in $cfgs; do for lib in $libs; do
   f=$out/${lib}_${c}_$r
-  NK_LIBNAME=$lib timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 20 --config $c --sustained 0 --per-call 0 > $f.json 2> $f.err || { echo "FAILED $lib $c"; tail -5 $f.err; exit 1; }
+  NK_LIBNAME=$lib timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 20 --config $c --sustained 0 --per-call 0 --small 0 > $f.json 2> $f.err || { echo "FAILED $lib $c"; tail -5 $f.err; exit 1; }
   python - "$f.json" "$lib" "$c" <<'PY'
 import json,sys
 j=json.load(open(sys.argv[1])); r=j['roofline']

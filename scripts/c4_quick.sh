@@ -2,7 +2,7 @@
 # config 4, two bench runs of the current build (plus kernel stats under rocprofv3 with "kt" as first argument)
 out=gpurun_out/c4q; mkdir -p $out
 for i in 0 1; do
-  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 20 --config c4 --sustained 0 --per-call 0 > $out/r$i.json 2> $out/r$i.err || { tail -5 $out/r$i.err; exit 1; }
+  timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 20 --config c4 --sustained 0 --per-call 0 --small 0 > $out/r$i.json 2> $out/r$i.err || { tail -5 $out/r$i.err; exit 1; }
   python - $out/r$i.json <<'PY'
 import json,sys
 j=json.load(open(sys.argv[1])); r=j['roofline']

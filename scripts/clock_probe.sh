@@ -3,7 +3,7 @@
 tag=$1; c=$2
 out=gpurun_out/$tag; mkdir -p $out
 for n in 3 2 1; do
-  NK_SWEEP_PER_CU=$n NK_LIBNAME=libnanokappa_hip_stamps.so NK_STAMPS=1 timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 200 --repeats 3 --config $c --sustained 0 --per-call 0 > $out/clk$n.json 2> $out/clk$n.err
+  NK_SWEEP_PER_CU=$n NK_LIBNAME=libnanokappa_hip_stamps.so NK_STAMPS=1 timeout -k 10 300 python bench.py --no-cpu-baseline --steps 20 --warmup 200 --repeats 3 --config $c --sustained 0 --per-call 0 --small 0 > $out/clk$n.json 2> $out/clk$n.err
   echo "== per_cu $n"; grep stamps $out/clk$n.err | tail -2
   python - $out/clk$n.json <<'PY'
 import json,sys

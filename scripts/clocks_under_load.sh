@@ -3,7 +3,7 @@
 out=gpurun_out/clk; mkdir -p $out
 ( for i in $(seq 1 60); do echo "t=$i $(rocm-smi --showclocks --showpower 2>/dev/null | grep -E 'fclk|mclk|sclk|Power' | sed 's/GPU\[0\][^:]*: //' | tr '\n' ' ')"; sleep 0.5; done ) > $out/samples.log &
 S=$!
-NK_VERBOSE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --per-call 0 --sustained 30000 > $out/bench.json 2> $out/bench.err
+NK_VERBOSE=1 timeout -k 10 300 python bench.py --no-cpu-baseline --per-call 0 --small 0 --sustained 30000 > $out/bench.json 2> $out/bench.err
 kill $S 2>/dev/null
 grep -h "store placement" $out/bench.err
 python3 -c "

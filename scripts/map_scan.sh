@@ -4,7 +4,7 @@
 R=$GRAFT_REPO_ROOT; tag=$1; O=$R/gpurun_out/$tag; mkdir -p $O
 for w in 0.0 0.2 0.45 0.7 1.0; do for k in 0.1 0.2 0.3; do
   ( export NK_EVENT_WEIGHT=$w NK_AGE_SKEW=$k
-    timeout -k 5 200 python3 $R/bench.py --steps 40 --warmup 20 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 > $O/w${w}_k$k.json 2> $O/w${w}_k$k.err )
+    timeout -k 5 200 python3 $R/bench.py --steps 40 --warmup 20 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > $O/w${w}_k$k.json 2> $O/w${w}_k$k.err )
 done; done
 python3 - <<PY | tee $O/summary.txt
 import json, glob, os

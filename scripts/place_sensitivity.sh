@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; tag=$1; n=${2:-6}; shift 2
 O=$R/gpurun_out/$tag; mkdir -p $O
 for i in $(seq 1 $n); do
   ( export NK_PLACE_TRIES=1; for e in "$@"; do export $e; done
-    timeout -k 5 200 python3 $R/bench.py --steps 40 --warmup 20 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 > $O/run$i.json 2> $O/run$i.err )
+    timeout -k 5 200 python3 $R/bench.py --steps 40 --warmup 20 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > $O/run$i.json 2> $O/run$i.err )
   echo "run $i rc $?"
 done
 python3 - <<PY | tee $O/summary.txt

@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for G in "TCC_REQ_sum TCC_READ_sum" "TCC_HIT_sum TCC_MISS_sum" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum" "TCC_TAG_STALL_sum TCC_BUSY_sum"; do
   i=$((i+1))
-  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $G -d $O/g$i -o p --output-format csv -- python3 $R/bench.py --config $c --steps 6 --warmup 3 --repeats 1 --no-cpu-baseline --sustained 0 --per-call 0 > /dev/null 2> $O/g$i.log
+  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $G -d $O/g$i -o p --output-format csv -- python3 $R/bench.py --config $c --steps 6 --warmup 3 --repeats 1 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > /dev/null 2> $O/g$i.log
   echo "pass $i rc $?"
 done
 python3 - <<PY | tee $O/l2.txt

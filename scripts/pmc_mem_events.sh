@@ -13,7 +13,7 @@ P5="TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum SQ_INST_LEVEL_VMEM SQ_LEVEL
 i=0
 for G in "$P1" "$P2" "$P3" "$P4" "$P5"; do
   i=$((i+1))
-  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $G -d $O/g$i -o p --output-format csv -- python3 $R/bench.py --config $c --steps 6 --warmup 3 --repeats 1 --no-cpu-baseline --sustained 0 --per-call 0 > /dev/null 2> $O/g$i.log
+  timeout -k 5 300 rocprofv3 --kernel-trace --pmc $G -d $O/g$i -o p --output-format csv -- python3 $R/bench.py --config $c --steps 6 --warmup 3 --repeats 1 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > /dev/null 2> $O/g$i.log
   echo "pass $i rc $?"
 done
 python3 - <<PY | tee $O/mem.txt

@@ -10,7 +10,7 @@ G3="SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_V
 i=0
 for G in "$G1" "$G2" "$G3"; do
   i=$((i+1))
-  timeout -k 5 400 rocprofv3 --kernel-trace --pmc $G -d $O/g$i -o p --output-format csv -- python3 $R/bench.py --config $c --steps 10 --warmup 5 --repeats 1 --no-cpu-baseline --sustained 0 --per-call 0 > /dev/null 2> $O/g$i.log
+  timeout -k 5 400 rocprofv3 --kernel-trace --pmc $G -d $O/g$i -o p --output-format csv -- python3 $R/bench.py --config $c --steps 10 --warmup 5 --repeats 1 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > /dev/null 2> $O/g$i.log
   echo "group $i rc $?"
 done
 python3 - <<PY | tee $O/mix.txt

@@ -7,9 +7,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 # every rocprofv3 pass under its own timeout (an abort inside the tool otherwise holds the box until the silence limit); bench.py
 # directly behind `--`; SQ takes 8 counters per pass, TCC: FETCH_SIZE and WRITE_SIZE each need a pass of their own
-B="python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --calibrate --sustained 0 --per-call 0"
+B="python3 $R/bench.py --steps 10 --warmup 5 --no-cpu-baseline --calibrate --sustained 0 --per-call 0 --small 0"
 T="timeout -k 5 240"
-$T rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --sustained 0 --per-call 0 > $O/bench_under_rocprof.json 2> $O/kt.log
+$T rocprofv3 --kernel-trace --stats -d $O/kt -o kt --output-format csv -- python3 $R/bench.py --steps 50 --warmup 10 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > $O/bench_under_rocprof.json 2> $O/kt.log
 echo "kernel trace done"
 $T rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY -d $O/sq -o p --output-format csv -- $B > /dev/null 2> $O/sq.log
 echo "sq pass done"

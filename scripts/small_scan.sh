@@ -3,7 +3,7 @@
 R=$GRAFT_REPO_ROOT; tag=$1; O=$R/gpurun_out/$tag; mkdir -p $O
 for N in 100000 300000 1000000; do for v in lrec nolrec; do
   ( [[ $v == nolrec ]] && export NK_NO_LREC=1
-    timeout -k 10 200 python3 $R/bench.py --particles $N --steps 200 --warmup 100 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 --ramp 0 > $O/n${N}_$v.json 2> $O/n${N}_$v.err )
+    timeout -k 10 200 python3 $R/bench.py --particles $N --steps 200 --warmup 100 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 --ramp 0 > $O/n${N}_$v.json 2> $O/n${N}_$v.err )
 done; done
 python3 - <<PY | tee $O/summary.txt
 import json, glob, os
