@@ -706,6 +706,38 @@ __device__ __forceinline__ void nk_box_first_hit(const NkBoxWalls &b, double inv
     nts = -(nb * nk_rcp(db)) * inv_dt;
     facet = wb < 0 ? -1 : (int)((ids >> (8 * wb)) & 15u);
 }
+// The NEXT wall of a particle inside the box (after a boundary event: it stands on a wall, or in the body after a periodic
+// crossing, and flies inwards): what Mesh.find_boundary returns for it -- per wall it flies towards t = -(x.n + k) / (v.n) with
+// the same x.n + k and v.n as above (one rounding / none), admissible when x.n + k < 0 < v.n and t >= tol (Mesh.py:820), the
+// smallest wins, the lowest face index among equals; its hit point lies on the wall's two triangles (the nearest wall of a
+// convex body always passes the face tests, Mesh.py:828-843).  The smallest is chosen on cross products, the winner divided
+// exactly: tc is the very quotient the general search (nk_find_boundary over the LDS planes: six planes, up to three
+// divisions, the winner's two triangles through box and barycentric tests -- a chain of ~30 dependent LDS reads) returns,
+// unless two walls' quotients differ by less than a rounding (a ray through an edge).
+__device__ __forceinline__ void nk_box_next_axis(double xa, double va, double lo, double hi, int wlo, uint64_t ids, double tol,
+                                                 double &mb, double &db, int &wb) {
+#pragma clang fp contract(off)
+    const bool fwd = va > 0.0;
+    const double num = fwd ? xa - hi : lo - xa;          // x.n + k of the wall the particle flies towards: negative inside
+    const double den = fabs(va), m = -num;
+    const int w = wlo + (fwd ? 1 : 0);
+    const double l = m * db, r = mb * den;               // t < t_best  <=>  m / den < mb / db
+    const unsigned f0w = (unsigned)(ids >> (8 * w + 4)) & 15u, f0b = wb < 0 ? 16u : ((unsigned)(ids >> (8 * wb + 4)) & 15u);
+    if ((num < 0.0) & (den > 0.0) & (m >= tol * den) & ((wb < 0) | (l < r) | ((l == r) & (f0w < f0b)))) { mb = m; db = den; wb = w; }
+}
+__device__ __forceinline__ void nk_box_next_hit(const NkBoxWalls &b, double tol, double x, double y, double z, double vx, double vy,
+                                                double vz, double &tc, int &facet) {
+    const uint64_t ids = ((uint64_t)b.ids_hi << 32) | b.ids_lo;
+    double mb = 0.0, db = 1.0;
+    int wb = -1;
+    nk_box_next_axis(x, vx, b.lx, b.hx, 0, ids, tol, mb, db, wb);
+    nk_box_next_axis(y, vy, b.ly, b.hy, 2, ids, tol, mb, db, wb);
+    nk_box_next_axis(z, vz, b.lz, b.hz, 4, ids, tol, mb, db, wb);
+    const double t = mb / db;
+    const bool hit = wb >= 0 && !isinf(t);
+    tc = hit ? t : __builtin_inf();
+    facet = hit ? (int)((ids >> (8 * wb)) & 15u) : -1;
+}
 // Large meshes (tables in global memory): a 4-ary tree of bounding boxes over the FACES, walked by every lane on its own.
 // The faces are sorted along a space-filling curve; a leaf is 4 consecutive faces, node i of level l + 1 the union of
 // nodes 4i .. 4i + 3 of level l, so the tree is implicit (no child pointers) and the walk needs no stack: the only state
@@ -1082,10 +1114,12 @@ __device__ __forceinline__ int nk_event_post(const NkDev &d, NkParticle &p, doub
 template <bool ROUGH, bool RBF = true>
 __device__ __forceinline__ int nk_event_one(const NkDev &d, int NG, const double *planes, const double *faces,
                                             const NkFacet *facets, const NkSvTab &tb, const double *resT, NkBins &b,
-                                            NkParticle &p, double &cts, uint32_t &ev, uint64_t pid, uint32_t step) {
+                                            NkParticle &p, double &cts, uint32_t &ev, uint64_t pid, uint32_t step,
+                                            const NkBoxWalls *bw = nullptr) {
     if (nk_event_pre<ROUGH, RBF>(d, facets, tb, resT, b, p, cts, ev, pid, step) == NK_EV_DEAD) return NK_EV_DEAD;
     double tc; int fcn;
-    if (NG > 0) nk_find_boundary_tree(d, NK_TREE_NO_SKIP, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);   // (walls are small facets)
+    if (bw) nk_box_next_hit(*bw, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);                      // box store: the six walls, in registers
+    else if (NG > 0) nk_find_boundary_tree(d, NK_TREE_NO_SKIP, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);   // (walls are small facets)
     else nk_find_boundary(planes, faces, d.NP, d.tol, p.x, p.y, p.z, p.vx, p.vy, p.vz, tc, fcn);
     return nk_event_post(d, p, cts, ev, tc, fcn);
 }

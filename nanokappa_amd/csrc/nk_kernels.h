@@ -108,6 +108,9 @@ struct NkLds {
 #define NK_ORING (NK_OUT_RING ? 128 : 0)
 // doubles of one wave's carry: x y z occ nts cts (64 each), w0 + evc (64 words each); with ids: + pid (64), gm and slot (64 words each)
 #define NK_CARRY_DOUBLES(kind) (((kind) == 3 || (kind) == 5) ? 576 : 448)
+#ifndef NK_BOX_GENERAL_CAST
+#define NK_BOX_GENERAL_CAST 0    // 1: the box store's event pass casts its rays through the general search over the LDS planes (developer probe)
+#endif
 #define NK_COLSUM_DOUBLES 768   // k_resident: column sums of the tally rows, two halves (NB <= 384)
 __host__ __device__ inline size_t nk_lds_bytes(int S, int R, int F, int NP, int Fc, int geom, int kind, int nrf, int rbfP, int nlrec = 0, int carry = 0) {
     const bool emit = kind == 1 || kind >= 4;
@@ -1026,7 +1029,8 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
                 p.facet = (int)(cw0 >> d.lb) - 1;
                 // box store: a particle's FIRST event of the step is the wall it lies beyond (the carry holds no hit for it yet)
                 if (BOX && eact && evc == 0u) nk_box_first_hit(bw, d.inv_dt, p.x, p.y, p.z, p.vx, p.vy, p.vz, p.nts, p.facet);
-                if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, cpid, step);
+                if (eact) st = nk_event_one<ROUGH, RBF>(d, GEOM == 2 ? d.NG : 0, L.planes, L.faces, L.facets, L.tb, L.resT, L.bins, p, cts, evc, cpid, step,
+                                                        (BOX && !NK_BOX_GENERAL_CAST) ? &bw : nullptr);
                 const bool alive = eact && st == NK_EV_DONE, more = eact && st == NK_EV_MORE;
 #ifdef NK_STAMPS
                 { const double fence_ = p.x + p.nts; asm volatile("" ::"v"(fence_)); }
