@@ -97,6 +97,7 @@ struct nk_ctx {
     std::vector<int32_t> h_m2s, h_s2m;  // host copies of the mode map (NkDev::m2s / s2m), built with the segmentation
     int32_t *m2s_dev = nullptr, *s2m_dev = nullptr, *nl_dev = nullptr;
     unsigned int *rbar = nullptr;     // k_resident: step word, halt word, one flag per workgroup
+    bool walked = false;              // box store: sweeps have alternated since the segments were last moved down (NkDev::seg_lo may be > 0)
     int64_t ev_lds_set = -1;          // dynamic LDS k_events was last allowed (hipFuncSetAttribute)
     int map_nseg = 0;                 // segmentation the map was dealt for
     NkMode *modetab_p = nullptr;      // permuted mode table (own allocation: its size follows nseg)
@@ -1116,9 +1117,22 @@ struct NkHostParticles {
     std::vector<int32_t> mode, facet;
     std::vector<uint64_t> pid;
 };
+// Every kernel but the sweep and the emission expects a segment's particles from slot 0 of its range (NkDev::seg_lo): move them
+// down after alternating sweeps, before anything else reads the store.  Needed once per download, regrow, contains_check step
+// (every 100th) or flush of the deferred relaxation; the kernel moves only what is not there already.
+static int nk_normalize(nk_ctx *ctx, int honor_halt = 0) {
+    NkDev &d = ctx->d;
+    d.down = 0;
+    if (!ctx->walked || !d.seg_lo) return NK_OK;
+    k_anchor<<<ctx->num_cu * 8, NK_WG, 0, ctx->stream>>>(d, honor_halt);
+    NK_HIP(hipGetLastError());
+    if (!honor_halt) ctx->walked = false;             // (inside a batch the launch may have been skipped by a halt: stay cautious)
+    return NK_OK;
+}
 static int nk_gather_live(nk_ctx *ctx, NkHostParticles &h, bool want_all) {
     NkDev &d = ctx->d;
     if (d.cap == 0) return NK_OK;
+    { int rcn_ = nk_normalize(ctx); if (rcn_) return rcn_; }
     NK_HIP(hipStreamSynchronize(ctx->stream));
     std::vector<int32_t> cnt((size_t)d.nseg);
     NK_HIP(hipMemcpy(cnt.data(), d.seg_count, (size_t)d.nseg * 4, hipMemcpyDeviceToHost));
@@ -1568,6 +1582,8 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
+    d.seg_lo = nullptr; d.down = 0; ctx->walked = false;
+    if (d.box) NK_PALLOC(int32_t, seg_lo, pi, d.nseg);      // (zeroed: the particles start at slot 0 of their segments)
     d.qx = d.qy = d.qz = d.qocc = d.qnts = nullptr; d.qw0 = nullptr; d.qpid = nullptr; d.seg_evq = nullptr;
     if (nk_want_split(ctx)) {
         NK_PALLOC(double, qx, pd, d.cap); NK_PALLOC(double, qy, pd, d.cap); NK_PALLOC(double, qz, pd, d.cap);
@@ -1625,6 +1641,7 @@ static int nk_ensure_inbox(nk_ctx *ctx) {
 // Grow every segment to `segcap_new` slots on the device (same segmentation: the particles keep their segments).
 static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     if (ctx) ctx->emitted_for = -1;
+    { int rcn_ = nk_normalize(ctx); if (rcn_) return rcn_; }
     NkDev &d = ctx->d;
     NK_HIP(hipStreamSynchronize(ctx->stream));
     const NkDev old = d;
@@ -1643,6 +1660,7 @@ static int nk_regrow(nk_ctx *ctx, int64_t segcap_new) {
     NK_PALLOC(int32_t, seg_count, pi, d.nseg);
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
+    if (old.seg_lo) NK_PALLOC(int32_t, seg_lo, pi, d.nseg);   // (the old store was moved down above; k_regrow copies from slot 0)
     if (old.qx) {                                       // the event queues are empty between steps: new ones, nothing to copy
         NK_PALLOC(double, qx, pd, d.cap); NK_PALLOC(double, qy, pd, d.cap); NK_PALLOC(double, qz, pd, d.cap);
         NK_PALLOC(double, qocc, pd, d.cap); NK_PALLOC(double, qnts, pd, d.cap);
@@ -1786,6 +1804,7 @@ int nk_init_boundaries(nk_ctx *ctx) {
     int rc = nk_check_ready(ctx);
     if (rc) return rc;
     NK_HIP(hipSetDevice(ctx->device));
+    if ((rc = nk_normalize(ctx))) return rc;
     for (int pass = 0; pass < 2; ++pass) {
         NK_HIP(hipMemsetAsync(ctx->anomalies, 0, 4, ctx->stream));
         NK_GEOM_LAUNCH(k_init_boundaries, nk_sweep_grid(ctx), nk_lds(ctx, true), ctx->d, ctx->anomalies);
@@ -1805,6 +1824,7 @@ int nk_init_boundaries(nk_ctx *ctx) {
 
 static int nk_flush_relax(nk_ctx *ctx, int honor_halt) {
     if (!ctx->pending_relax) return NK_OK;
+    { int rcn_ = nk_normalize(ctx); if (rcn_) return rcn_; }
     k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(ctx->d, honor_halt);
     NK_HIP(hipGetLastError());
     ctx->pending_relax = false;
@@ -1877,10 +1897,16 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     bool emitted_ahead = tail_emit && ctx->emitted_for == ctx->step;   // this step's emission already ran in the previous step's k_tail (maybe of the call before)
     ctx->emitted_for = -1;
     ctx->timing.emit_fused = tail_emit ? 1 : 0;
+    // box store: the sweeps alternate between walking their segments upwards and downwards (NkDev::down; nk_device.h) -- not with
+    // rough facets (k_deliver appends from slot seg_count) nor on more than one rank (untested there).  NK_NO_ALTERNATE=1: never.
+    const bool alt = d.box && d.seg_lo && !rough_ && !split_ && gm_ == 1 && !ctx->comm && !getenv("NK_NO_ALTERNATE");
+    if (!alt) { int rcn_ = nk_normalize(ctx); if (rcn_) return rcn_; }
+    d.down = 0;
     for (int s = 0; s < nsteps; ++s) {
         const int64_t stepno = ctx->step + s;
         const uint32_t step = (uint32_t)stepno;
         if (ctx->params.contains_every > 0 && (stepno % ctx->params.contains_every) == 0 && d.nS > 0) {
+            { int rcn_ = nk_normalize(ctx, 1); if (rcn_) return rcn_; }       // (k_relax, k_contains: particles from slot 0)
             if (pending) {
                 k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(d, 1);
                 pending = false;
@@ -1896,7 +1922,9 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
         if (s < nev) NK_HIP(hipEventRecord(ev[4 * s + 1], ctx->stream));
         {
             const int rl = pending ? 1 : 0;
+            if (alt) { d.down = (int32_t)(stepno & 1); ctx->walked = true; }
             NK_SWEEP_DISPATCH(gm_, rough_, rbf_, pid_, split_, lrec_, (KERNEL<<<g_sweep, NK_WG, lds_w, ctx->stream>>>(d, step, rl, do_flux)));
+            d.down = 0;
             if (split_) {
                 k_events_begin<<<1, 1024, 0, ctx->stream>>>(d);
                 const int64_t ev_key = (int64_t)lds_ev * 64 + (gm_ | (rough_ << 2) | (rbf_ << 3) | (pid_ << 4));
@@ -2099,6 +2127,7 @@ static inline bool nk_want_resident(const nk_ctx *ctx) {
     } while (0)
 static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, int32_t *done) {
     NkDev &d = ctx->d;
+    { int rcn_ = nk_normalize(ctx); if (rcn_) return rcn_; }
     const int S = d.S, NB = d.NB;
     const int HROW = NB + 2 * S + 8;
     if (nsteps > ctx->hist_cap) {
@@ -2538,6 +2567,7 @@ int nk_tally_state(nk_ctx *ctx, double *E_raw, double *N_sv, double *flux_raw) {
     if (rc) return rc;
     NK_HIP(hipSetDevice(ctx->device));
     NkDev &d = ctx->d;
+    if ((rc = nk_normalize(ctx))) return rc;
     if (ctx->pending_relax) {                          // the state the caller means includes the deferred relaxation
         k_relax<<<nk_sweep_grid(ctx), NK_WG, nk_lds(ctx, false), ctx->stream>>>(d, 0);
         ctx->pending_relax = false;

@@ -417,7 +417,8 @@ __device__ __forceinline__ int nk_emit_one(const NkDev &d, const NkLds &L, uint3
                                            , unsigned long long em_t0, unsigned long long em_t1, unsigned long long &em_t2
 #endif
 ) {
-    const int64_t base = (int64_t)seg * d.segcap;
+    const int plo = (BOX && d.seg_lo) ? d.seg_lo[seg] : 0;        // (box store: the live particles begin at slot seg_lo, NkDev)
+    const int64_t base = (int64_t)seg * d.segcap + plo;
     const int count = d.seg_count[seg];
     const NkSegModes sm = nk_seg_modes(d, seg);
     const int nent = d.res_gen != 2 ? d.R * sm.nl : 0;
@@ -544,7 +545,7 @@ __device__ __forceinline__ int nk_emit_one(const NkDev &d, const NkLds &L, uint3
             }
             if (!BOX) NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
             const int o = count + made + j;
-            if (o < d.segcap) {
+            if (plo + o < d.segcap) {
                 const int64_t i = base + o;
                 const NkSlot q = nk_slot(d, i);
                 double xa, ya, za, na;
@@ -561,7 +562,7 @@ __device__ __forceinline__ int nk_emit_one(const NkDev &d, const NkLds &L, uint3
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) sp_bound += __shfl_xor(sp_bound, o, 64);
-    const int room = d.segcap - count;
+    const int room = d.segcap - plo - count;
     const int put = (GEOM == 2 && to_queue) ? 0 : (made < room ? made : (room > 0 ? room : 0));   // entering particles behind the segment's live ones
     if (lane == 0) {
         if (GEOM == 2 && to_queue) { d.seg_new[seg] = 0; d.seg_evq[seg] = made < d.segcap ? made : d.segcap; }
@@ -631,6 +632,8 @@ struct NkOut {
     double *x, *y, *z, *occ, *nts, *pid;
     unsigned int *w0;
     int on, ob, wout;            // staged particles, ring position of the oldest, particles already in HBM
+    int64_t m0; int ms, mroom;   // box store: the o-th finished particle goes to slot m0 + ms * o (ms = -1: a DOWN sweep), o < mroom
+    __device__ __forceinline__ void place(int64_t first, int sign, int room) { m0 = first; ms = sign; mroom = room; }
     __device__ __forceinline__ void init(const NkLds &L, int wave) {
         double *p = L.oring + wave * NK_ORING * (PID ? 6 : 5);
         x = p; y = p + NK_ORING; z = p + 2 * NK_ORING; occ = p + 3 * NK_ORING; nts = p + 4 * NK_ORING; pid = PID ? p + 5 * NK_ORING : nullptr;
@@ -654,7 +657,8 @@ struct NkOut {
     __device__ __forceinline__ void store(const NkDev &d, int64_t base, bool put, int o, double px, double py, double pz, double pocc,
                                           double pnts, uint32_t pw0, unsigned long long ppid) {
         if (put) {
-            if (o < d.segcap) put_slot<BOX>(d, base + o, px, py, pz, pocc, pnts, pw0, ppid);
+            if (BOX) { if (o < mroom) put_slot<BOX>(d, m0 + ms * (int64_t)o, px, py, pz, pocc, pnts, pw0, ppid); else atomicOr(d.overflow, 2); }
+            else if (o < d.segcap) put_slot<BOX>(d, base + o, px, py, pz, pocc, pnts, pw0, ppid);
             else atomicOr(d.overflow, 2);     // segment full
         }
     }
@@ -665,7 +669,8 @@ struct NkOut {
         if (!NK_OUT_RING) {                           // straight to the write cursor
             if (put) {
                 const int o = wout + rank;
-                if (o < d.segcap) put_slot<BOX>(d, base + o, px, py, pz, pocc, pnts, pw0, ppid);
+                if (BOX) { if (o < mroom) put_slot<BOX>(d, m0 + ms * (int64_t)o, px, py, pz, pocc, pnts, pw0, ppid); else atomicOr(d.overflow, 2); }
+                else if (o < d.segcap) put_slot<BOX>(d, base + o, px, py, pz, pocc, pnts, pw0, ppid);
                 else atomicOr(d.overflow, 2);     // segment full
             }
             wout += n;
@@ -805,9 +810,17 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
             if (use_lrec && NK_LREC_STRIDE > 4) return *(const __attribute__((address_space(3))) int *)(const void *)(lrec + i * NK_LREC_STRIDE + 4);
             return sm.mode(i);
         };
-        const int nA = (count + NK_TILE - 1) / NK_TILE;
+        // the slots that hold the segment's particles, [lo, hi) of its range, and the order of the walk (NkDev::seg_lo / down): tiles
+        // = aligned blocks of 64 slots, from the one with the first particle up or from the one with the last particle down
+        const bool down = BOX && d.down != 0;
+        const int lo = (BOX && d.seg_lo) ? d.seg_lo[seg] : 0, hi = lo + count;
+        const int blo = lo & ~(NK_TILE - 1), bhi = count > 0 ? ((hi - 1) & ~(NK_TILE - 1)) : blo;
+        const int nA = count > 0 ? (bhi - blo) / NK_TILE + 1 : 0;
+        // an UP sweep packs upwards from lo -- from 0 once lo has used up half of the head room; a DOWN sweep downwards from hi - 1
+        const int wlo = (!down && lo > (d.segcap - count) / 2) ? 0 : lo;
         NkOut<PID> O;                                 // finished particles on their way back to the segment
         O.init(L, wave);
+        O.place(down ? base + hi - 1 : base + wlo, down ? -1 : 1, down ? count : d.segcap - wlo);
         int qn = SPLIT ? d.seg_evq[seg] : 0;          // SPLIT: entries in the segment's event queue (k_emit may have put the entering particles there:
         if (SPLIT && lane == 0 && qn > 0) atomicAdd(&L.bins.misc[0], (unsigned int)qn);     //  they count as "emitted" here)
         int cn = 0;                                   // particles in the carry (lanes [0, cn))
@@ -828,7 +841,8 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
         struct NkTileBuf { uint32_t w0; double x, y, z, occ, nts; unsigned long long pid; };
         NkTileBuf bA = {0u, 0, 0, 0, 0, 0, 0ull}, bB = bA;
         auto fetch = [&](NkTileBuf &b, int r) {
-            int rr = r < d.segcap - NK_TILE ? r : d.segcap - NK_TILE;
+            int rr = BOX ? (down ? bhi - r : blo + r) : r;        // r = 64 x the tile's number in the walk
+            rr = rr < 0 ? 0 : (rr < d.segcap - NK_TILE ? rr : d.segcap - NK_TILE);
             const int64_t i0 = base + rr;
             if (PF2) {
                 // Loads the compiler does not know to be loads: it keeps the memory counter itself, and with the event pass's loops
@@ -849,7 +863,7 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
                 if (PID) { const double *pp = px + B::O_PID; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.pid) : "v"(pp) : "memory"); }
                 return;
             }
-            if (r + lane < count) {                       // (one tile ahead, the compiler's own counting: only what will be used)
+            if (BOX ? (rr + lane >= lo && rr + lane < hi && r < nA * NK_TILE) : (r + lane < count)) {   // (one tile ahead, the compiler's own counting: only what will be used)
                 typedef NkBlock<!BOX, PID> B;
                 const double *q = B::tile(d.x.p, i0, lane);     // ONE address; the fields at immediate offsets
                 b.w0 = NK_LD(B::word(d.x.p, i0) + lane); b.x = NK_LD(q); b.y = NK_LD(q + B::O_Y); b.z = NK_LD(q + B::O_Z); b.occ = NK_LD(q + B::O_OCC);
@@ -902,7 +916,8 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
             if (!flush) {
                 // ---- relax (deferred from the previous step), drift
                 const int r = t * NK_TILE;
-                act = r + lane < count;
+                if (BOX) { const int rr = down ? bhi - r : blo + r; act = rr + lane >= lo && rr + lane < hi; }
+                else act = r + lane < count;
                 w0 = buf.w0; x = buf.x; y = buf.y; z = buf.z; occ = buf.occ; nts = buf.nts; pid = buf.pid;
             }
             if (DEFER) {                                // the previous tile's finished particles leave now
@@ -1092,12 +1107,14 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
         if (O.on > 0) O.flush(d, base, lane, O.on);
         const int w = O.wout;
         if (SPLIT && lane == 0) d.seg_evq[seg] = qn < d.segcap ? qn : d.segcap;
+        const int nlo = BOX ? (down ? hi - (w < count ? w : count) : wlo) : 0;      // where the live particles begin now
         if (lane == 0) {
             d.seg_count[seg] = w < d.segcap ? w : d.segcap;
+            if (BOX && d.seg_lo) d.seg_lo[seg] = nlo;
             // could the next step overflow this segment?  then nothing after this step runs until the host has grown the store
             if (d.R > 0) {
                 d.seg_new[seg] = 0;
-                if (!SPLIT && (int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+                if (!SPLIT && (int64_t)nlo + w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
             }
         }
     }
@@ -1407,6 +1424,43 @@ __global__ __launch_bounds__(NK_EV_WG, NK_EV_PER_CU) void k_events(NkDev d, uint
     }
 #endif
     nk_lds_flush(d, L, row0 + blockIdx.x);
+}
+
+// Box store after alternating sweeps: every segment's particles (and the entering ones appended above them, if the emission has
+// run ahead) down to slot 0 of its range (NkDev::seg_lo), which is where every kernel but the sweep and the emission expects them.
+// One wave per segment, 64 slots at a time upwards: the destination lies below the source, a chunk is read before it is written.
+NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_anchor(NkDev d, int honor_halt) {
+    if (!d.seg_lo || (honor_halt && d.halt[0])) return;       // (inside a batch: a halted batch's remaining launches do nothing)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nwaves = gridDim.x * (NK_WG / 64);
+    for (int seg = blockIdx.x * (NK_WG / 64) + wave; seg < d.nseg; seg += nwaves) {
+        const int lo = d.seg_lo[seg];
+        if (lo <= 0) continue;
+        const int64_t base = (int64_t)seg * d.segcap;
+        int n = d.seg_count[seg] + (d.R > 0 ? d.seg_new[seg] : 0);
+        n = lo + n <= d.segcap ? n : d.segcap - lo;
+        for (int j0 = 0; j0 < n; j0 += 64) {
+            const bool on = j0 + lane < n;
+            const NkSlot qs = nk_slot(d, base + lo + j0 + (on ? lane : 0)), qd = nk_slot(d, base + j0 + (on ? lane : 0));
+            double vx = 0, vy = 0, vz = 0, vo = 0, vn = 0;
+            uint32_t vw = 0u;
+            uint64_t vp = 0;
+            if (on) {
+                vx = d.x.p[qs.od]; vy = d.y.p[qs.od]; vz = d.z.p[qs.od]; vo = d.occ.p[qs.od]; vw = d.w0.p[qs.ow];
+                if (d.nts.p) vn = d.nts.p[qs.od];
+                if (d.pid.p) vp = d.pid.p[qs.od];
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            if (on) {
+                d.x.p[qd.od] = vx; d.y.p[qd.od] = vy; d.z.p[qd.od] = vz; d.occ.p[qd.od] = vo; d.w0.p[qd.ow] = vw;
+                if (d.nts.p) d.nts.p[qd.od] = vn;
+                if (d.pid.p) d.pid.p[qd.od] = vp;
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        if (lane == 0) d.seg_lo[seg] = 0;
+    }
 }
 
 // nk_reserve with an unchanged number of segments: every segment's particles move to the start of its longer successor.
