@@ -1257,6 +1257,8 @@ static int nk_scatter(nk_ctx *ctx, int64_t N, const double *x, const double *y, 
         }
     }
     NK_HIP(hipMemcpy(d.seg_count, cnt.data(), (size_t)d.nseg * 4, hipMemcpyHostToDevice));
+    if (d.seg_lo) NK_HIP(hipMemset(d.seg_lo, 0, (size_t)d.nseg * 4));      // (the particles were dealt from slot 0 of their segments)
+    ctx->walked = false;
     ctx->h_seg_count = cnt;
     return NK_OK;
 }

@@ -354,3 +354,44 @@ def test_stepping_one_by_one_equals_one_call():
     oa, ob = np.argsort(pa['pid']), np.argsort(pb['pid'])
     assert np.array_equal(pa['pid'][oa], pb['pid'][ob])
     assert np.array_equal(pa['positions'][oa], pb['positions'][ob]) and rel_err(pa['occupation'][oa], pb['occupation'][ob]) < TOL_OCC
+
+
+@pytest.mark.gpu
+def test_alternating_walk_equals_walking_upwards_only(monkeypatch):
+    """Box store: the sweeps alternate between walking their segments upwards and downwards (NkDev::seg_lo / down, nk_device.h), so
+    that a sweep starts with what the one before wrote last.  The order in which a wave meets its particles decides nothing: the
+    same run with NK_NO_ALTERNATE=1 (every sweep upwards from slot 0) has the same counts step by step and the same particles at
+    the end.  160 steps in calls of 1, 7 and 50 steps: the lower end of the segments wanders up and is brought back (an UP sweep
+    that starts its output at slot 0 again, k_anchor before the contains_check step at 100 and before the download in between), and
+    a second population uploaded into the same store starts from slot 0 again."""
+    ct = case_tables('ttp')
+    pos, mode, occ, counter = random_population(ct, 30000, seed=5)
+    a = make_engine(ct, pos, mode, occ, counter, seed=42)
+    monkeypatch.setenv('NK_NO_ALTERNATE', '1')
+    b = make_engine(ct, pos, mode, occ, counter, seed=42)
+    tb = b.step(160)
+    monkeypatch.delenv('NK_NO_ALTERNATE')
+    rows, done = [], 0
+    for n in [1, 1, 7, 50, 1, 50, 50]:
+        rows.append(a.step(n))
+        done += n
+        if done == 60:
+            a.download()
+    assert done == 160
+    for k in ('N_sv', 'N_emitted', 'N_leaving'):
+        assert np.array_equal(tb[k], np.concatenate([r[k] for r in rows])), k
+    assert allclose(tb['T_sv'], np.concatenate([r['T_sv'] for r in rows]), rtol=0, atol=TOL_T)
+    pa, pb = a.download(), b.download()
+    oa, ob = np.argsort(pa['pid']), np.argsort(pb['pid'])
+    assert np.array_equal(pa['pid'][oa], pb['pid'][ob]) and np.array_equal(pa['mode'][oa], pb['mode'][ob])
+    assert allclose(pa['positions'][oa], pb['positions'][ob], rtol=0, atol=TOL_X) and rel_err(pa['occupation'][oa], pb['occupation'][ob]) < TOL_OCC
+    # the same stores, a new population (it fits: no new allocation), both ways again
+    pos2, mode2, occ2, _ = random_population(ct, 28000, seed=9)
+    a.upload(pos2, mode2, occ2)
+    a.init_boundaries()
+    t2a = a.step(12)
+    monkeypatch.setenv('NK_NO_ALTERNATE', '1')
+    b.upload(pos2, mode2, occ2)
+    b.init_boundaries()
+    t2b = b.step(12)
+    assert np.array_equal(t2a['N_sv'], t2b['N_sv']) and allclose(t2a['T_sv'], t2b['T_sv'], rtol=0, atol=TOL_T)
