@@ -1493,10 +1493,11 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d, in
         if (n <= 0) continue;
         if (n > d.mig_cap) n = d.mig_cap;
         const int count = d.seg_count[seg];
+        const int lo = d.seg_lo ? d.seg_lo[seg] : 0;          // (box store: the live particles begin at slot seg_lo, NkDev)
         // no room: the migrants stay in the inbox.  In a step k_reduce sees that before the tallies are summed over the ranks, so
         // halt[0] and halt[2] go up on EVERY rank (nk_update_body) and all of them stop after this step
-        if (count + n > d.segcap) { if (lane == 0 && !in_step) { atomicOr(d.halt + 2, 1); atomicOr(d.halt, 1); } continue; }
-        const int64_t base = (int64_t)seg * d.segcap + count;
+        if (lo + count + n > d.segcap) { if (lane == 0 && !in_step) { atomicOr(d.halt + 2, 1); atomicOr(d.halt, 1); } continue; }
+        const int64_t base = (int64_t)seg * d.segcap + lo + count;
         for (int j = lane; j < n; j += 64) {
             const double2 *r = d.mig_buf + ((int64_t)seg * d.mig_cap + j) * 4;
             const double2 a = r[0], b = r[1], c = r[2], e = r[3];
@@ -1510,7 +1511,7 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(NK_WG) void k_deliver(NkDev d, in
             // room for the next TWO steps (emission and about as many migrants again): the request travels with this step's
             // tally vector, so that every rank halts at the same step
             const int bound = d.R > 0 ? d.seg_bound[seg] : 0;
-            if ((int64_t)count + n + 2 * (bound + 2 * n) + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+            if ((int64_t)lo + count + n + 2 * (bound + 2 * n) + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
             if (2 * n > d.mig_cap) atomicOr(d.halt + 3, 1);
         }
     }
