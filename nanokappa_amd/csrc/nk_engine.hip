@@ -1899,9 +1899,9 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     bool emitted_ahead = tail_emit && ctx->emitted_for == ctx->step;   // this step's emission already ran in the previous step's k_tail (maybe of the call before)
     ctx->emitted_for = -1;
     ctx->timing.emit_fused = tail_emit ? 1 : 0;
-    // box store: the sweeps alternate between walking their segments upwards and downwards (NkDev::down; nk_device.h) -- not on
-    // more than one rank (untested there).  NK_NO_ALTERNATE=1: never.
-    const bool alt = d.box && d.seg_lo && !split_ && gm_ == 1 && !ctx->comm && !getenv("NK_NO_ALTERNATE");
+    // box store: the sweeps alternate between walking their segments upwards and downwards (NkDev::down; nk_device.h), on every rank
+    // alike (the direction follows the step's parity).  NK_NO_ALTERNATE=1: never.
+    const bool alt = d.box && d.seg_lo && !split_ && gm_ == 1 && !getenv("NK_NO_ALTERNATE");
     if (!alt) { int rcn_ = nk_normalize(ctx); if (rcn_) return rcn_; }
     d.down = 0;
     for (int s = 0; s < nsteps; ++s) {
