@@ -1309,7 +1309,7 @@ static inline int nk_mode_seg(const nk_ctx *ctx, int m, int nseg) {
 // an event weighing NK_EVENT_WEIGHT (0.45: from the stamps' cycles per tile) of a mean particle-step.  In the order of their
 // event rate every mode goes to the segment that is furthest behind its SHARE of the work (longest-processing-time greedy).
 // The shares follow the dispatch order: the SIMD issues the oldest wave first, so the k-th workgroup a CU received runs ahead
-// of the (k+1)-th; share = 1 + NK_AGE_SKEW (0.20) x (1 - 2 k / (per_cu - 1)) -- speed only: if workgroups were dispatched in
+// of the (k+1)-th; share = 1 + NK_AGE_SKEW (0.14; 0.20 until the box sweep lost its general ray cast, profiles/r04_notes.txt (21)) x (1 - 2 k / (per_cu - 1)) -- speed only: if workgroups were dispatched in
 // another order the sweep would merely be as uneven as with equal shares.  Modes that cannot move (never populated) fill up
 // the shortest segments.  d.nlmax is the capacity of a segment's slot range (set by the caller).
 static int nk_build_mode_map(nk_ctx *ctx) {
@@ -1352,7 +1352,7 @@ static int nk_build_mode_map(nk_ctx *ctx) {
         // shares by dispatch age: only when every resident wave of the sweep has exactly one segment
         std::vector<double> share((size_t)nseg, 1.0);
         const int g = ctx->g_sweep, per_cu = ctx->num_cu > 0 ? g / ctx->num_cu : 0;
-        const double skew = getenv("NK_AGE_SKEW") ? atof(getenv("NK_AGE_SKEW")) : 0.20;
+        const double skew = getenv("NK_AGE_SKEW") ? atof(getenv("NK_AGE_SKEW")) : 0.14;
         if (per_cu > 1 && g == per_cu * ctx->num_cu && nseg == g * (NK_WG / 64) && skew != 0.0)
             for (int sg = 0; sg < nseg; ++sg) {
                 const int k = (sg / (NK_WG / 64)) / ctx->num_cu;
