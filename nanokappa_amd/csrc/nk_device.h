@@ -123,7 +123,7 @@ struct NkDev {
     double tree_bound;                // largest |coordinate| of a box (error bound of the single-precision slab test)
     const int32_t *tree_tags;         // [nodes] facet of a node whose faces all belong to one facet, else -1
     const double *facet_skip;         // [2*Fc] per facet: largest |n_face - n_facet|, largest |plane_face(centroid)| (nk_tree_skip)
-    const double *tree_faces;         // [tree_leaves * 4 * NK_TREE_FACE_DOUBLES] leaf face records (padded with null faces)
+    const double *tree_faces;         // [tree_leaves * NK_TREE_LEAF_DOUBLES] leaf records: the four faces' boxes, then the faces (padded with null faces)
     int32_t tree_base[8];             // first node of each level in tree_boxes
     int32_t tree_top, tree_leaves;
     // k_events: the families from index tree_lds_fam0 up (whole levels from the top of the tree; the levels are stored bottom-up, so these
@@ -758,11 +758,7 @@ __device__ __forceinline__ void nk_box_next_hit(const NkBoxWalls &b, double tol,
 // lowest face index, whatever the visiting order).  The previous structure (two levels of wave-uniform groups of 16
 // planes) made a wave visit the union of its 64 rays' groups -- on a 5000-face wire nearly the whole mesh per batch.
 #define NK_TREE_LEVELS 8            // 4^8 leaves x 4 faces: meshes up to 262 144 faces
-#define NK_TREE_FACE_DOUBLES 20     // per face: n(3) k | lo(3) hi(3) | o(3) iu(3) iw(3) {face, facet}.  A LEAF's 80 doubles are laid out by cache
-                                    // line (128 B): the four planes (n, k) first -- the part every ray at the leaf reads -- then one line
-                                    // per face with the rest, read only by a ray that meets the face's plane in front of its best hit
-                                    // (face by face as 160-byte records a leaf's planes lay on four or five lines: the faces do not fit
-                                    // an L1, every line is a trip to the L2)
+#define NK_TREE_FACE_DOUBLES 20     // per face: n(3) k | lo(3) hi(3) | o(3) iu(3) iw(3) {face, facet}; a leaf's record: NK_TREE_LEAF_DOUBLES below
 #define NK_TREE_FAMILY_FLOATS 24    // four sibling boxes (6 floats each); their facet tags sit in tree_tags (int4 per family)
 // The boxes are single precision, rounded outwards on the host: a family of four is 96 bytes instead of 192 and the slab
 // test runs at twice the FP64 rate.  The test stays conservative: a slab's entry and exit distances are widened by a bound
@@ -809,50 +805,55 @@ __device__ __forceinline__ bool nk_ray_box(float lx, float ly, float lz, float h
     return t0 <= t1;
 }
 // The four faces of one leaf against one ray (same arithmetic and the same rounding as nk_fb_planes).
-// Two rounds of loads, not nine: the leaf's plane line for all four faces; then, while any lane of the wave has a face left whose plane
-// it meets in front of its best hit, every lane takes ITS next such face and reads that face's whole line at once (box, origin,
-// barycentric rows, ids).  The faces do not fit the L2 of a large mesh: each dependent round is a trip to the memory side.  Face by
-// face in order, with the box read before the rest, a leaf took up to 1 + 2 x 4 rounds (17 000 cycles per pass of k_events on the
-// 5000-triangle wire).  The result does not depend on the order: earliest hit, lowest face index among equals.
+// A leaf's record (NK_TREE_LEAF_DOUBLES = 96 doubles) by cache line: first the BOXES of its four faces (single precision, rounded
+// outwards like the tree's: 4 x 6 floats, one line), then per face 20 doubles: the plane (n, k) and the face's box, origin,
+// barycentric rows and ids.  Two rounds of loads: the boxes; then -- while any lane of the wave has a face left whose box its ray
+// pierces in front of its best hit -- every lane ITS next such face, plane and rest at once.  The leaf records of a large mesh
+// do not fit the L2: every dependent round is a trip to the memory side.  (Round 3: face by face, plane -> box -> barycentric
+// rows, up to nine rounds per leaf: 17 000 cycles per faces pass of k_events on the 5000-triangle wire.  Round 4 first: the four
+// planes in one line, then the faces whose PLANE is met in front of the best hit -- most of a leaf's four, their planes being
+// nearly the same: 13 600.)  The boxes reject what the planes cannot: a face the ray passes beside.  Conservative like the tree's
+// boxes (a face whose hit point lies inside its box is never rejected), so the result is the plain search's: earliest hit, lowest
+// face index among equals, whatever the order.
+#define NK_TREE_LEAF_DOUBLES 96
 __device__ __forceinline__ void nk_tree_leaf(const double *tree_faces, int leaf, double tol, double x, double y, double z,
-                                             double vx, double vy, double vz, NkHit &h) {
+                                             double vx, double vy, double vz, const NkRayF &rf, NkHit &h) {
 #pragma clang fp contract(off)
-    const double2 *Q = reinterpret_cast<const double2 *>(tree_faces + (size_t)leaf * 4 * NK_TREE_FACE_DOUBLES);
-    double2 pn[4], pk[4];
+    const double *L = tree_faces + (size_t)leaf * NK_TREE_LEAF_DOUBLES;
+    const float4 *B = reinterpret_cast<const float4 *>(L);
+    float4 b[6];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) { pn[c] = Q[2 * c]; pk[c] = Q[2 * c + 1]; }        // the plane parts: one line, requested together
-    double nm[4], dn[4];
-    unsigned mask = 0u;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        nm[c] = x * pn[c].x + y * pn[c].y + z * pk[c].x + pk[c].y;
-        dn[c] = vx * pn[c].x + vy * pn[c].y + vz * pk[c].x;
-        bool ok = (nm[c] < 0.0 && dn[c] > 0.0) || (nm[c] > 0.0 && dn[c] < 0.0);     // padding faces have n = k = 0
-        // a plane met CERTAINLY behind the best hit so far (by far more than the division's rounding) changes nothing: no division
-        ok = ok && !(fabs(nm[c]) > (h.t * fabs(dn[c])) * (1.0 + 1e-9));
-        mask |= (ok ? 1u : 0u) << c;
-    }
+    for (int k = 0; k < 6; ++k) b[k] = B[k];
+    float tmax = (float)h.t;                             // the best hit so far as a float that is not below it (inf stays inf)
+    tmax += tmax * 1.1920929e-07f;
+    unsigned mask = ((unsigned)nk_ray_box(b[0].x, b[0].y, b[0].z, b[0].w, b[1].x, b[1].y, rf, tmax)) |
+                    ((unsigned)nk_ray_box(b[1].z, b[1].w, b[2].x, b[2].y, b[2].z, b[2].w, rf, tmax) << 1) |
+                    ((unsigned)nk_ray_box(b[3].x, b[3].y, b[3].z, b[3].w, b[4].x, b[4].y, rf, tmax) << 2) |
+                    ((unsigned)nk_ray_box(b[4].z, b[4].w, b[5].x, b[5].y, b[5].z, b[5].w, rf, tmax) << 3);
     while (__ballot(mask != 0u) != 0ull) {
         if (mask != 0u) {
             const int c = __builtin_ctz(mask);
             mask &= mask - 1u;
-            const double num = c == 0 ? nm[0] : (c == 1 ? nm[1] : (c == 2 ? nm[2] : nm[3]));
-            const double den = c == 0 ? dn[0] : (c == 1 ? dn[1] : (c == 2 ? dn[2] : dn[3]));
-            const double t = -num / den;
-            if ((t >= tol) && !isinf(t) && !(t > h.t)) {
-                const double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
-                const double2 *q = Q + 8 + 8 * c;                           // the face's own line
-                const double2 q0 = q[0], q1 = q[1], q2 = q[2];              // lo.x lo.y | lo.z hi.x | hi.y hi.z
-                const double2 q3 = q[3], q4 = q[4], q5 = q[5], q6 = q[6], q7 = q[7];   // o(3) iu(3) iw(3) {face, facet}
-                const bool inside = (cx >= q0.x - tol) & (cy >= q0.y - tol) & (cz >= q1.x - tol) & (cx <= q1.y + tol) &
-                                    (cy <= q2.x + tol) & (cz <= q2.y + tol);
-                const double bx = cx - q3.x, by = cy - q3.y, bz = cz - q4.x;
-                const double u = q4.y * bx + q5.x * by + q5.y * bz;
-                const double w = q6.x * bx + q6.y * by + q7.x * bz;
-                const double r = 1.0 - (u + w);
-                const bool in_tri = u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol;
-                const int idf = __double2loint(q7.y), idc = __double2hiint(q7.y);
-                if (inside && in_tri && (t < h.t || idf < h.face)) { h.t = t; h.face = idf; h.facet = idc; }
+            const double2 *q = reinterpret_cast<const double2 *>(L + 16 + 20 * c);
+            const double2 p01 = q[0], p23 = q[1];                       // n.x n.y | n.z k     (padding faces have n = k = 0)
+            const double2 q0 = q[2], q1 = q[3], q2 = q[4];              // lo.x lo.y | lo.z hi.x | hi.y hi.z
+            const double2 q3 = q[5], q4 = q[6], q5 = q[7], q6 = q[8], q7 = q[9];   // o(3) iu(3) iw(3) {face, facet}
+            const double num = x * p01.x + y * p01.y + z * p23.x + p23.y;
+            const double den = vx * p01.x + vy * p01.y + vz * p23.x;
+            if ((num < 0.0 && den > 0.0) || (num > 0.0 && den < 0.0)) {
+                const double t = -num / den;
+                if ((t >= tol) && !isinf(t) && !(t > h.t)) {
+                    const double cx = x + t * vx, cy = y + t * vy, cz = z + t * vz;
+                    const bool inside = (cx >= q0.x - tol) & (cy >= q0.y - tol) & (cz >= q1.x - tol) & (cx <= q1.y + tol) &
+                                        (cy <= q2.x + tol) & (cz <= q2.y + tol);
+                    const double bx = cx - q3.x, by = cy - q3.y, bz = cz - q4.x;
+                    const double u = q4.y * bx + q5.x * by + q5.y * bz;
+                    const double w = q6.x * bx + q6.y * by + q7.x * bz;
+                    const double r = 1.0 - (u + w);
+                    const bool in_tri = u >= -tol && u <= 1.0 + tol && w >= -tol && w <= 1.0 + tol && r >= -tol && r <= 1.0 + tol;
+                    const int idf = __double2loint(q7.y), idc = __double2hiint(q7.y);
+                    if (inside && in_tri && (t < h.t || idf < h.face)) { h.t = t; h.face = idf; h.facet = idc; }
+                }
             }
         }
     }
@@ -952,7 +953,7 @@ __device__ __forceinline__ bool nk_walk_boxes(const NkDev &d, int skip, NkWalk &
 }
 // the faces of the leaf the walk stands at
 __device__ __forceinline__ void nk_walk_leaf(const NkDev &d, NkWalk &w, double x, double y, double z, double vx, double vy, double vz) {
-    nk_tree_leaf(d.tree_faces, w.leaf, d.tol, x, y, z, vx, vy, vz, w.h);
+    nk_tree_leaf(d.tree_faces, w.leaf, d.tol, x, y, z, vx, vy, vz, w.rf, w.h);
     w.leaf = -1;
 #ifdef NK_TREE_STATS
     ++w.n_leaf;

@@ -633,18 +633,16 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
             int pos = 0;
             for (int k = 0; k < c_top; ++k) { deal(pos, pos + sizes[k], top, k); pos += sizes[k]; }
         }
-        // leaf records: plane, box, barycentric rows; the padding faces keep n = k = 0 and can never be hit
-        std::vector<double> tf((size_t)NL * 4 * NK_TREE_FACE_DOUBLES, 0.0);
+        // leaf records (NK_TREE_LEAF_DOUBLES, nk_device.h): the four faces' boxes in single precision (filled in below, once the
+        // slack is known), then per face plane, box, barycentric rows; the padding faces keep n = k = 0 and can never be hit
+        std::vector<double> tf((size_t)NL * NK_TREE_LEAF_DOUBLES, 0.0);
         for (size_t i = 0; i < slot.size(); ++i) {
             if (slot[i] < 0) continue;
             const int f = refs[slot[i]].face;
-            // (leaf layout by cache line, NK_TREE_FACE_DOUBLES in nk_device.h: the four planes, then one line per face)
-            double *leaf = &tf[(i / 4) * 4 * NK_TREE_FACE_DOUBLES];
-            const int c = (int)(i % 4);
+            double *q = &tf[(i / 4) * NK_TREE_LEAF_DOUBLES + 16 + 20 * (i % 4)];
             const double *src = &faces[(size_t)face_pos[f] * NK_FACE_DOUBLES];
-            double *q = leaf + 4 * c;
             q[0] = m->normals[3 * f]; q[1] = m->normals[3 * f + 1]; q[2] = m->normals[3 * f + 2]; q[3] = m->k[f];
-            memcpy(leaf + 16 + 16 * c, src, NK_FACE_DOUBLES * sizeof(double));
+            memcpy(q + 4, src, NK_FACE_DOUBLES * sizeof(double));
         }
         // boxes: union of the member faces' boxes, inflated by far more than any rounding in the slab test
         double big = 0.0;
@@ -659,6 +657,15 @@ int nk_set_mesh(nk_ctx *ctx, const nk_mesh *m) {
             for (int a = 0; a < 3; ++a)
                 for (int k = 0; k < 3; ++k) e = std::max(e, fabs(V[3 * a + k] - V[3 * ((a + 1) % 3) + k]));
             slack[f] = margin + 8.0 * m->tol * e;
+        }
+        for (size_t i = 0; i < slot.size(); ++i) {           // the faces' own boxes, rounded outwards (padding: a box no ray enters)
+            float *fb = reinterpret_cast<float *>(&tf[(i / 4) * NK_TREE_LEAF_DOUBLES]) + 6 * (i % 4);
+            for (int k = 0; k < 3; ++k) {
+                if (slot[i] < 0) { fb[k] = 3.0e38f; fb[3 + k] = -3.0e38f; continue; }
+                const NkFaceRef &r = refs[slot[i]];
+                fb[k] = nextafterf((float)(r.lo[k] - slack[r.face]), -INFINITY);
+                fb[3 + k] = nextafterf((float)(r.hi[k] + slack[r.face]), INFINITY);
+            }
         }
         std::vector<double> boxes;
         int count = NL, level = 0, prev_base = 0;
