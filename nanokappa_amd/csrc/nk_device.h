@@ -202,7 +202,7 @@ struct NkDev {
     int32_t nseg, segcap;
     int32_t *seg_count;               // [nseg] live particles per segment (contiguous from the segment start)
     int32_t *seg_new;                 // [nseg] particles k_emit appended behind them at this step (the sweep takes them in)
-    // Box store, alternating walk.  The store is larger than the 256 MB memory-side cache, and a sweep that walks every segment
+    // Alternating walk (fused sweeps of small meshes, box store or cached store).  The store is larger than the 256 MB memory-side cache, and a sweep that walks every segment
     // front to back begins with the blocks the sweep before wrote FIRST -- the ones that cache has dropped again.  So the sweeps
     // take turns: an UP sweep reads its segment's particles from the lowest slot upwards and packs the survivors upwards from
     // there; a DOWN sweep (`down`, set per launch) reads from the highest slot downwards and packs the survivors downwards from
@@ -210,7 +210,7 @@ struct NkDev {
     // live particles of segment s then occupy slots [seg_lo[s], seg_lo[s] + seg_count[s]) of its range: a DOWN sweep moves the
     // lower end up by the particles that died, an UP sweep starts its output at 0 again once the lower end has used up half of the
     // segment's head room.  The emission appends above the live particles as ever.  Every other kernel expects seg_lo = 0: the
-    // host moves the segments down first (k_anchor).  seg_lo == null: no such store (seg_lo = 0, UP only).
+    // host moves the segments down first (k_anchor).  The split sweep and the fused sweep over a face tree always walk upwards from slot 0.
     int32_t *seg_lo;
     int32_t down;
     int32_t *seg_bound;               // [nseg] upper bound of the particles that can enter the segment in one step

@@ -1592,7 +1592,7 @@ static int nk_alloc_particles(nk_ctx *ctx, int64_t capacity, const int32_t *mode
     NK_PALLOC(int32_t, seg_new, pi, d.nseg);
     NK_PALLOC(int32_t, seg_bound, pi, d.nseg);
     d.seg_lo = nullptr; d.down = 0; ctx->walked = false;
-    if (d.box) NK_PALLOC(int32_t, seg_lo, pi, d.nseg);      // (zeroed: the particles start at slot 0 of their segments)
+    NK_PALLOC(int32_t, seg_lo, pi, d.nseg);                 // (zeroed: the particles start at slot 0 of their segments)
     d.qx = d.qy = d.qz = d.qocc = d.qnts = nullptr; d.qw0 = nullptr; d.qpid = nullptr; d.seg_evq = nullptr;
     if (nk_want_split(ctx)) {
         NK_PALLOC(double, qx, pd, d.cap); NK_PALLOC(double, qy, pd, d.cap); NK_PALLOC(double, qz, pd, d.cap);
@@ -1906,9 +1906,10 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
     bool emitted_ahead = tail_emit && ctx->emitted_for == ctx->step;   // this step's emission already ran in the previous step's k_tail (maybe of the call before)
     ctx->emitted_for = -1;
     ctx->timing.emit_fused = tail_emit ? 1 : 0;
-    // box store: the sweeps alternate between walking their segments upwards and downwards (NkDev::down; nk_device.h), on every rank
-    // alike (the direction follows the step's parity).  NK_NO_ALTERNATE=1: never.
-    const bool alt = d.box && d.seg_lo && !split_ && gm_ == 1 && !getenv("NK_NO_ALTERNATE");
+    // the fused sweeps of small meshes (box store or cached store) alternate between walking their segments upwards and downwards
+    // (NkDev::down; nk_device.h), on every rank alike (the direction follows the step's parity).  Not the split sweep of large meshes:
+    // measured no gain there (config 4's store is ten times the memory-side cache).  NK_NO_ALTERNATE=1: never.
+    const bool alt = d.seg_lo && gm_ == 1 && !split_ && !getenv("NK_NO_ALTERNATE");
     if (!alt) { int rcn_ = nk_normalize(ctx); if (rcn_) return rcn_; }
     d.down = 0;
     for (int s = 0; s < nsteps; ++s) {

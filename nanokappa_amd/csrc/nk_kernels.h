@@ -417,8 +417,8 @@ __device__ __forceinline__ int nk_emit_one(const NkDev &d, const NkLds &L, uint3
                                            , unsigned long long em_t0, unsigned long long em_t1, unsigned long long &em_t2
 #endif
 ) {
-    const int plo = (BOX && d.seg_lo) ? d.seg_lo[seg] : 0;        // (box store: the live particles begin at slot seg_lo, NkDev)
-    const int64_t base = (int64_t)seg * d.segcap + plo;
+    const int plo = d.seg_lo ? d.seg_lo[seg] : 0;                 // (the live particles begin at slot seg_lo of the segment's range, NkDev)
+    const int64_t base = (int64_t)seg * d.segcap;
     const int count = d.seg_count[seg];
     const NkSegModes sm = nk_seg_modes(d, seg);
     const int nent = d.res_gen != 2 ? d.R * sm.nl : 0;
@@ -546,7 +546,7 @@ __device__ __forceinline__ int nk_emit_one(const NkDev &d, const NkLds &L, uint3
             if (!BOX) NK_RAY(GEOM, d, L, skip, x0, y0, z0, vx, vy, vz, tc, facet);
             const int o = count + made + j;
             if (plo + o < d.segcap) {
-                const int64_t i = base + o;
+                const int64_t i = base + plo + o;
                 const NkSlot q = nk_slot(d, i);
                 double xa, ya, za, na;
                 nk_newborn_place(d, x0, y0, z0, vx, vy, vz, dt_in, tc, xa, ya, za, na);
@@ -632,7 +632,7 @@ struct NkOut {
     double *x, *y, *z, *occ, *nts, *pid;
     unsigned int *w0;
     int on, ob, wout;            // staged particles, ring position of the oldest, particles already in HBM
-    int64_t m0; int ms, mroom;   // box store: the o-th finished particle goes to slot m0 + ms * o (ms = -1: a DOWN sweep), o < mroom
+    int64_t m0; int ms, mroom;   // the o-th finished particle goes to slot m0 + ms * o (ms = -1: a DOWN sweep, NkDev::down), o < mroom
     __device__ __forceinline__ void place(int64_t first, int sign, int room) { m0 = first; ms = sign; mroom = room; }
     __device__ __forceinline__ void init(const NkLds &L, int wave) {
         double *p = L.oring + wave * NK_ORING * (PID ? 6 : 5);
@@ -657,8 +657,7 @@ struct NkOut {
     __device__ __forceinline__ void store(const NkDev &d, int64_t base, bool put, int o, double px, double py, double pz, double pocc,
                                           double pnts, uint32_t pw0, unsigned long long ppid) {
         if (put) {
-            if (BOX) { if (o < mroom) put_slot<BOX>(d, m0 + ms * (int64_t)o, px, py, pz, pocc, pnts, pw0, ppid); else atomicOr(d.overflow, 2); }
-            else if (o < d.segcap) put_slot<BOX>(d, base + o, px, py, pz, pocc, pnts, pw0, ppid);
+            if (o < mroom) put_slot<BOX>(d, m0 + ms * (int64_t)o, px, py, pz, pocc, pnts, pw0, ppid);
             else atomicOr(d.overflow, 2);     // segment full
         }
     }
@@ -669,8 +668,7 @@ struct NkOut {
         if (!NK_OUT_RING) {                           // straight to the write cursor
             if (put) {
                 const int o = wout + rank;
-                if (BOX) { if (o < mroom) put_slot<BOX>(d, m0 + ms * (int64_t)o, px, py, pz, pocc, pnts, pw0, ppid); else atomicOr(d.overflow, 2); }
-                else if (o < d.segcap) put_slot<BOX>(d, base + o, px, py, pz, pocc, pnts, pw0, ppid);
+                if (o < mroom) put_slot<BOX>(d, m0 + ms * (int64_t)o, px, py, pz, pocc, pnts, pw0, ppid);
                 else atomicOr(d.overflow, 2);     // segment full
             }
             wout += n;
@@ -812,8 +810,9 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
         };
         // the slots that hold the segment's particles, [lo, hi) of its range, and the order of the walk (NkDev::seg_lo / down): tiles
         // = aligned blocks of 64 slots, from the one with the first particle up or from the one with the last particle down
-        const bool down = BOX && d.down != 0;
-        const int lo = (BOX && d.seg_lo) ? d.seg_lo[seg] : 0, hi = lo + count;
+        constexpr bool ALT = GEOM == 1 || SPLIT;       // (the fused sweep over a face tree always walks upwards from slot 0)
+        const bool down = ALT && d.down != 0;
+        const int lo = (ALT && d.seg_lo) ? d.seg_lo[seg] : 0, hi = lo + count;
         const int blo = lo & ~(NK_TILE - 1), bhi = count > 0 ? ((hi - 1) & ~(NK_TILE - 1)) : blo;
         const int nA = count > 0 ? (bhi - blo) / NK_TILE + 1 : 0;
         // an UP sweep packs upwards from lo -- from 0 once lo has used up half of the head room; a DOWN sweep downwards from hi - 1
@@ -841,7 +840,7 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
         struct NkTileBuf { uint32_t w0; double x, y, z, occ, nts; unsigned long long pid; };
         NkTileBuf bA = {0u, 0, 0, 0, 0, 0, 0ull}, bB = bA;
         auto fetch = [&](NkTileBuf &b, int r) {
-            int rr = BOX ? (down ? bhi - r : blo + r) : r;        // r = 64 x the tile's number in the walk
+            int rr = down ? bhi - r : blo + r;                    // r = 64 x the tile's number in the walk
             rr = rr < 0 ? 0 : (rr < d.segcap - NK_TILE ? rr : d.segcap - NK_TILE);
             const int64_t i0 = base + rr;
             if (PF2) {
@@ -863,7 +862,7 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
                 if (PID) { const double *pp = px + B::O_PID; asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(b.pid) : "v"(pp) : "memory"); }
                 return;
             }
-            if (BOX ? (rr + lane >= lo && rr + lane < hi && r < nA * NK_TILE) : (r + lane < count)) {   // (one tile ahead, the compiler's own counting: only what will be used)
+            if (rr + lane >= lo && rr + lane < hi && r < nA * NK_TILE) {   // (one tile ahead, the compiler's own counting: only what will be used)
                 typedef NkBlock<!BOX, PID> B;
                 const double *q = B::tile(d.x.p, i0, lane);     // ONE address; the fields at immediate offsets
                 b.w0 = NK_LD(B::word(d.x.p, i0) + lane); b.x = NK_LD(q); b.y = NK_LD(q + B::O_Y); b.z = NK_LD(q + B::O_Z); b.occ = NK_LD(q + B::O_OCC);
@@ -916,8 +915,7 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
             if (!flush) {
                 // ---- relax (deferred from the previous step), drift
                 const int r = t * NK_TILE;
-                if (BOX) { const int rr = down ? bhi - r : blo + r; act = rr + lane >= lo && rr + lane < hi; }
-                else act = r + lane < count;
+                { const int rr = down ? bhi - r : blo + r; act = rr + lane >= lo && rr + lane < hi; }
                 w0 = buf.w0; x = buf.x; y = buf.y; z = buf.z; occ = buf.occ; nts = buf.nts; pid = buf.pid;
             }
             if (DEFER) {                                // the previous tile's finished particles leave now
@@ -1107,10 +1105,10 @@ __device__ __forceinline__ void nk_sweep_body(const NkDev &d, NkLds L, uint32_t 
         if (O.on > 0) O.flush(d, base, lane, O.on);
         const int w = O.wout;
         if (SPLIT && lane == 0) d.seg_evq[seg] = qn < d.segcap ? qn : d.segcap;
-        const int nlo = BOX ? (down ? hi - (w < count ? w : count) : wlo) : 0;      // where the live particles begin now
+        const int nlo = down ? hi - (w < count ? w : count) : wlo;                  // where the live particles begin now
         if (lane == 0) {
             d.seg_count[seg] = w < d.segcap ? w : d.segcap;
-            if (BOX && d.seg_lo) d.seg_lo[seg] = nlo;
+            if (ALT && d.seg_lo) d.seg_lo[seg] = nlo;
             // could the next step overflow this segment?  then nothing after this step runs until the host has grown the store
             if (d.R > 0) {
                 d.seg_new[seg] = 0;
@@ -1207,10 +1205,11 @@ NK_KERNEL_LINKAGE __global__ __launch_bounds__(256) void k_events_end(NkDev d) {
     const int seg = blockIdx.x * blockDim.x + threadIdx.x;
     if (seg >= d.nseg) return;
     int w = d.seg_count[seg];
-    if (w > d.segcap) { w = d.segcap; d.seg_count[seg] = w; }          // (the surplus was dropped and flagged by k_events)
+    const int slo = d.seg_lo ? d.seg_lo[seg] : 0;
+    if (slo + w > d.segcap) { w = d.segcap - slo; d.seg_count[seg] = w; }   // (the surplus was dropped and flagged by k_events)
     d.seg_evq[seg] = 0;
     // could the next step overflow this segment?  then nothing after this step runs until the host has grown the store
-    if (d.R > 0 && (int64_t)w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
+    if (d.R > 0 && (int64_t)slo + w + d.seg_bound[seg] + NK_TILE > (int64_t)d.segcap) atomicOr(d.halt + 1, 1);
 }
 template <int GEOM, bool ROUGH, bool RBF, bool PID>
 __global__ __launch_bounds__(NK_EV_WG, NK_EV_PER_CU) void k_events(NkDev d, uint32_t step, int flags, int row0) {
@@ -1391,10 +1390,11 @@ __global__ __launch_bounds__(NK_EV_WG, NK_EV_PER_CU) void k_events(NkDev d, uint
                 else idxe = (uint32_t)p.mode;
             }
             const uint32_t w0e = ((uint32_t)(p.facet + 1) << d.lb) | idxe;
-            if (stay) {                                   // its slot in its segment
+            if (stay) {                                   // its slot in its segment (above the particles the sweep left: NkDev::seg_lo)
+                const int slo = d.seg_lo ? d.seg_lo[seg] : 0;
                 const int o = atomicAdd(d.seg_count + seg, 1);
-                if (o < d.segcap) {
-                    const int64_t i = (int64_t)seg * d.segcap + o;
+                if (slo + o < d.segcap) {
+                    const int64_t i = (int64_t)seg * d.segcap + slo + o;
                     const NkSlot q = nk_slot(d, i);
                     d.x.p[q.od] = p.x; d.y.p[q.od] = p.y; d.z.p[q.od] = p.z; d.occ.p[q.od] = p.occ; d.nts.p[q.od] = p.nts; d.w0.p[q.ow] = w0e;
                     if (PID) d.pid.p[q.od] = pid;

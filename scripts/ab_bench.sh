@@ -8,7 +8,7 @@ for rep in 1 2; do
   for spec in "$@"; do
     lib=${spec%%:*}; envs=""; [[ "$spec" == *:* ]] && envs=${spec#*:}
     name=$(echo "$spec" | tr ':=/' '___')
-    ( [[ "$lib" != "-" ]] && export NK_LIBNAME=$lib; [[ -n "$envs" ]] && export $envs
+    ( [[ "$lib" != "-" ]] && export NK_LIBNAME=$lib; [[ -n "$envs" ]] && export ${envs//,/ }
       timeout -k 5 300 python3 $R/bench.py --config $cfg --steps 40 --warmup 20 --repeats 5 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > $O/$name.$rep.json 2> $O/$name.$rep.err )
     echo "$spec rep $rep rc $?"
   done

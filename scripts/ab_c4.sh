@@ -4,7 +4,7 @@ R=$GRAFT_REPO_ROOT; tag=$1; shift; O=$R/gpurun_out/$tag; mkdir -p $O
 for spec in "$@"; do
   lib=${spec%%:*}; envs=""; [[ "$spec" == *:* ]] && envs=${spec#*:}
   name=$(echo "$spec" | tr ':=/' '___')
-  ( [[ "$lib" != "-" ]] && export NK_LIBNAME=$lib; [[ -n "$envs" ]] && export $envs
+  ( [[ "$lib" != "-" ]] && export NK_LIBNAME=$lib; [[ -n "$envs" ]] && export ${envs//,/ }
     NK_VERBOSE=1 timeout -k 10 400 python3 $R/bench.py --config c4 --steps 20 --warmup 10 --repeats 3 --no-cpu-baseline --sustained 0 --per-call 0 --small 0 > $O/$name.json 2> $O/$name.err )
   echo "$spec rc $?"
 done
