@@ -357,16 +357,20 @@ def test_stepping_one_by_one_equals_one_call():
 
 
 @pytest.mark.gpu
-def test_alternating_walk_equals_walking_upwards_only(monkeypatch):
-    """Box store: the sweeps alternate between walking their segments upwards and downwards (NkDev::seg_lo / down, nk_device.h), so
+@pytest.mark.parametrize('store', ['box', 'cached'])
+def test_alternating_walk_equals_walking_upwards_only(monkeypatch, store):
+    """The fused sweeps of small meshes (box store, and the cached store that NK_NO_BOX=1 forces here): the sweeps alternate between walking their segments upwards and downwards (NkDev::seg_lo / down, nk_device.h), so
     that a sweep starts with what the one before wrote last.  The order in which a wave meets its particles decides nothing: the
     same run with NK_NO_ALTERNATE=1 (every sweep upwards from slot 0) has the same counts step by step and the same particles at
     the end.  160 steps in calls of 1, 7 and 50 steps: the lower end of the segments wanders up and is brought back (an UP sweep
     that starts its output at slot 0 again, k_anchor before the contains_check step at 100 and before the download in between), and
     a second population uploaded into the same store starts from slot 0 again."""
+    if store == 'cached':
+        monkeypatch.setenv('NK_NO_BOX', '1')
     ct = case_tables('ttp')
     pos, mode, occ, counter = random_population(ct, 30000, seed=5)
     a = make_engine(ct, pos, mode, occ, counter, seed=42)
+    assert a.timing()['box_store'] == (1 if store == 'box' else 0)
     monkeypatch.setenv('NK_NO_ALTERNATE', '1')
     b = make_engine(ct, pos, mode, occ, counter, seed=42)
     tb = b.step(160)
