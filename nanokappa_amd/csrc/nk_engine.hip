@@ -2125,7 +2125,7 @@ static int nk_step_batch(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h, in
 static inline bool nk_want_resident(const nk_ctx *ctx) {
     const NkDev &d = ctx->d;
     if (!getenv("NK_RESIDENT") || getenv("NK_NO_RESIDENT") || ctx->comm || d.nranks != 1 || d.Fr > 0 || d.mig_buf || d.qx || nk_geom_mode(ctx) != 1) return false;
-    if (d.res_gen == 2 || d.sv_interp == 3 || d.NB > 254 || d.nseg <= 0) return false;
+    if (d.res_gen == 2 || d.sv_interp == 3 || d.NB > 254 || d.S > 128 || d.nseg <= 0) return false;
     const int64_t lim = getenv("NK_RESIDENT_MAX") ? atoll(getenv("NK_RESIDENT_MAX")) : 1200000;
     return d.cap <= lim && nk_lds(ctx, true, 5) <= 160 * 1024;
 }
@@ -2191,7 +2191,7 @@ static int nk_step_resident(nk_ctx *ctx, int32_t nsteps, std::vector<double> &h,
         }
         int n = nsteps - k;
         if (ce > 0 && d.nS > 0) n = std::min<int64_t>(n, ce - (stepno % ce));
-        NK_HIP(hipMemsetAsync(ctx->rbar, 0, (32 + (size_t)G) * sizeof(unsigned int), ctx->stream));      // flags and step word count from 1 in every launch
+        NK_HIP(hipMemsetAsync(ctx->rbar, 0, (32 + 1024 + 128) * sizeof(unsigned int), ctx->stream));     // the flags count from 1 in every launch
         NK_RESIDENT_DISPATCH(box_, pid_, lrec_, (KERNEL<<<G, NK_WG, lds, ctx->stream>>>(d, (uint32_t)stepno, n, pending ? 1 : 0, ctx->params.flux_every,
                                                                                        ctx->hist + (size_t)k * HROW, HROW, ctx->rbar)));
         NK_HIP(hipGetLastError());

@@ -1688,8 +1688,8 @@ __global__ __launch_bounds__(NK_WG) void k_tail(NkDev d, uint32_t step_next, int
 // Conditions (host, nk_step_resident): one rank, no rough facets (their migrants cross segments), small mesh, not 'one_to_one',
 // no RBF temperatures; contains_check steps start a new launch.  Every workgroup must be resident: the grid is at most what the
 // occupancy query allows.  A wait that is not met within ~2 s gives up (overflow bit 256) instead of hanging the device.
-// bar[0]: steps of this launch whose update is published; bar[1]: that update asked for a halt; bar[32 + g]: steps of this launch
-// whose row workgroup g has written.  Zeroed by the host before every launch.
+// bar[1]: this launch's update asked for a halt; bar[32 + g]: steps of this launch whose row workgroup g has written; bar[1056 + t]:
+// steps of this launch whose temperature of subvolume t is published.  Zeroed by the host before every launch.
 __device__ __forceinline__ bool nk_wait_word(const unsigned int *w, unsigned int atleast) {
     int spins = 0;
     while (__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < atleast) {
@@ -1711,11 +1711,10 @@ __global__ __launch_bounds__(NK_WG, 2) void k_resident(NkDev d, uint32_t step0, 
     NkSv *sv = const_cast<NkSv *>(L.tb.sv);
     const int nE = d.nE;
     const double Ta = d.Tarr[0], Tb = d.Tarr[1], Tz = d.Tarr[nE - 1], Ea = d.Earr[0], Ez = d.Earr[nE - 1];
-    unsigned int *flags = bar + 32;
+    unsigned int *flags = bar + 32, *flagsT = bar + 32 + 1024;      // (G <= 1024 workgroups, S <= 128 subvolumes)
     unsigned long long *rows = reinterpret_cast<unsigned long long *>(d.partials);
     unsigned long long *Tpub = reinterpret_cast<unsigned long long *>(d.T_sv);
     const int NBP = (NB + 1) & ~1;                                // a row's length in memory (even: pairs of columns, 16-byte loads)
-    double *tot = L.colsum + 512;                                 // the column sums of the step (workgroup 0); L.colsum[0 .. 511]: the quarters' partial sums
     unsigned long long *dbg = reinterpret_cast<unsigned long long *>(bar + 8);   // developer probe: 100 MHz clock marks of the launch's last step
 #ifdef NK_STAMPS
     if (R > 0) nk_emit_segments<1, BOX>(d, L, step0, wg, G, false, 0ull, 0ull);
@@ -1768,83 +1767,73 @@ __global__ __launch_bounds__(NK_WG, 2) void k_resident(NkDev d, uint32_t step0, 
 #endif
         int ok = 1, hreq = 0;
         if (mark) mk[wg == 0 ? 3 : 2] = __builtin_amdgcn_s_memrealtime();
-        if (wg == 0) {
+        // ---- the update, dealt over the workgroups by COLUMN of the tally rows: task k < S = subvolume k (its energy and particle
+        // columns -> E -> T, nk_update_sv needs nothing else), task k >= S = one of the other columns (history row only); task k goes to
+        // workgroup k % G.  An owner waits for every workgroup's row, sums its column(s) -- one row per thread: ONE round of loads --
+        // in a fixed order, and publishes T_k behind its own flag; then everybody waits for the S flags and reads the S
+        // temperatures.  (One workgroup summing all 111 columns took four dependent rounds: 6.6 us of a 28 us step.)
+        double *hrowp = hist + (size_t)s * hrow;
+        const int ntask = S + (NB - 2 * S);
+        if (wg < ntask) {
             for (int g = tid; g < G; g += NK_WG) if (!nk_wait_word(flags + g, (unsigned int)(s + 1))) ok = 0;
             ok = __syncthreads_and(ok);
-            if (!ok) { if (tid == 0) { atomicOr(d.overflow, 256); __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(bar, (unsigned int)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }
+            if (!ok) {          // a workgroup never arrived: give up (everybody times out on the flags below)
+                if (tid == 0) atomicOr(d.overflow, 256);
+                return;
+            }
             if (mark) mk[4] = __builtin_amdgcn_s_memrealtime();
-            // column sums over the G rows, rows in order within a thread, threads in order: a thread takes a PAIR of columns (one
-            // 16-byte load per row) over a quarter of the rows, sixteen loads in flight (the loads bypass the caches: each is a
-            // trip to where the XCDs agree, ~2 us, and only as many of them overlap as the code has in flight)
-            {
-                const int npair = NBP / 2, q4 = tid >> 6, ln = tid & 63;
-                const int gq = (G + 3) / 4, g0 = q4 * gq, g1 = g0 + gq < G ? g0 + gq : G;
-                for (int p0 = 0; p0 < npair; p0 += 64) {
-                    const int pr = p0 + ln;
-                    double2 sum = make_double2(0.0, 0.0);
-                    if (pr < npair) {
-                        for (int g = g0; g < g1; g += 16) {
-                            typedef double nk_d2 __attribute__((ext_vector_type(2)));
-                            nk_d2 v[16];
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) {
-                                const int gg = g + k < g1 ? g + k : g1 - 1;
-                                const unsigned long long *src = rows + (size_t)gg * NBP + 2 * pr;
-                                asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[k]) : "v"(src) : "memory");
-                            }
-                            asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
-                                         "+v"(v[8]), "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]) : : "memory");
-#pragma unroll
-                            for (int k = 0; k < 16; ++k) if (g + k < g1) { sum.x += v[k].x; sum.y += v[k].y; }
-                        }
-                        double *part = L.colsum + (size_t)q4 * 64 * 2 + 2 * ln;          // [4][64][2] of the 4 x 128 doubles
-                        part[0] = sum.x; part[1] = sum.y;
-                    }
-                    __syncthreads();
-                    if (q4 == 0 && pr < npair) {
-                        const double *part = L.colsum + 2 * ln;
-                        const double sx = ((part[0] + part[128]) + part[256]) + part[384], sy = ((part[1] + part[129]) + part[257]) + part[385];
-                        tot[2 * pr] = sx; tot[2 * pr + 1] = sy;
-                    }
+            if (wg == 0) hreq = __hip_atomic_load(d.halt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a sweep of this step asked for head room
+            for (int k = wg; k < ntask; k += G) {
+                const int c0 = k < S ? k : 2 * S + (k - S), c1 = k < S ? S + k : -1;
+                double v0 = 0.0, v1 = 0.0;
+                for (int g = tid; g < G; g += NK_WG) {
+                    v0 += __longlong_as_double((long long)__hip_atomic_load(rows + (size_t)g * NBP + c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (c1 >= 0) v1 += __longlong_as_double((long long)__hip_atomic_load(rows + (size_t)g * NBP + c1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                }
+                // the workgroup's sum in a fixed order: a tree over the thread index
+                double *red = L.colsum;
+                red[tid] = v0; red[NK_WG + tid] = v1;
+                __syncthreads();
+                for (int o = NK_WG / 2; o > 0; o >>= 1) {
+                    if (tid < o) { red[tid] += red[tid + o]; red[NK_WG + tid] += red[NK_WG + tid + o]; }
                     __syncthreads();
                 }
+                if (tid == 0) {
+                    const double t0 = red[0], t1 = red[NK_WG];
+                    if (k < S) {
+                        double Tnew, E;
+                        nk_update_sv(d, t0, t1, d.T_ref_local ? Tsv[k] : d.T_ref, k, Ta, Tb, Tz, Ea, Ez, Tnew, E);
+                        __hip_atomic_store(Tpub + k, (unsigned long long)__double_as_longlong(Tnew), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (k == 0 && hreq) { d.halt[0] = 1; __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+                        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");      // T (and the halt word) are out before the flag
+                        __hip_atomic_store(flagsT + k, (unsigned int)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        // the history row (pinned host memory: slow writes) behind the flag, off everybody's path
+                        hrowp[k] = t0; hrowp[S + k] = t1; hrowp[NB + k] = Tnew; hrowp[NB + S + k] = E;
+                        if (k == 0) {                     // (workgroup 0: the step's control words)
+                            hrowp[NB + 2 * S + 0] = (double)do_flux;
+                            hrowp[NB + 2 * S + 1] = 1.0;
+                            hrowp[NB + 2 * S + 2] = hreq ? 1.0 : 0.0;
+                            hrowp[NB + 2 * S + 3] = (double)__hip_atomic_load(d.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            hrowp[NB + 2 * S + 4] = hreq ? 1.0 : 0.0;
+                            hrowp[NB + 2 * S + 5] = (double)hreq;
+                            hrowp[NB + 2 * S + 6] = (double)d.halt[2];
+                            hrowp[NB + 2 * S + 7] = (double)d.halt[3];
+                        }
+                    } else hrowp[c0] = t0;
+                }
+                __syncthreads();
             }
             if (mark) mk[5] = __builtin_amdgcn_s_memrealtime();
-            hreq = __hip_atomic_load(d.halt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a sweep of this step asked for head room
-            // ---- update
-            double *hrowp = hist + (size_t)s * hrow;
-            for (int t = tid; t < S; t += NK_WG) {
-                double Tnew, E;
-                nk_update_sv(d, tot[t], tot[S + t], d.T_ref_local ? Tsv[t] : d.T_ref, t, Ta, Tb, Tz, Ea, Ez, Tnew, E);
-                Tsv[t] = Tnew;
-                hrowp[NB + t] = Tnew; hrowp[NB + S + t] = E;
-                __hip_atomic_store(Tpub + t, (unsigned long long)__double_as_longlong(Tnew), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            for (int b = tid; b < NB; b += NK_WG) hrowp[b] = tot[b];
-            if (tid == 0) {
-                hrowp[NB + 2 * S + 0] = (double)do_flux;
-                hrowp[NB + 2 * S + 1] = 1.0;
-                hrowp[NB + 2 * S + 2] = hreq ? 1.0 : 0.0;
-                hrowp[NB + 2 * S + 3] = (double)__hip_atomic_load(d.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                hrowp[NB + 2 * S + 4] = hreq ? 1.0 : 0.0;
-                hrowp[NB + 2 * S + 5] = (double)hreq;
-                hrowp[NB + 2 * S + 6] = (double)d.halt[2];
-                hrowp[NB + 2 * S + 7] = (double)d.halt[3];
-                if (hreq) { d.halt[0] = 1; __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_store(bar, (unsigned int)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (mark) mk[6] = __builtin_amdgcn_s_memrealtime();
-        } else {
-            if (tid == 0) ok = nk_wait_word(bar, (unsigned int)(s + 1)) ? 1 : 0;
-            ok = __syncthreads_and(ok);
-            if (!ok) { if (tid == 0) atomicOr(d.overflow, 256); return; }
-            for (int t = tid; t < S; t += NK_WG) Tsv[t] = __longlong_as_double((long long)__hip_atomic_load(Tpub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            hreq = (int)__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (mark) mk[3] = __builtin_amdgcn_s_memrealtime();
         }
+        for (int t = tid; t < S; t += NK_WG) {
+            if (!nk_wait_word(flagsT + t, (unsigned int)(s + 1))) ok = 0;
+            else Tsv[t] = __longlong_as_double((long long)__hip_atomic_load(Tpub + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        }
+        ok = __syncthreads_and(ok);
+        if (!ok) { if (tid == 0) atomicOr(d.overflow, 256); return; }
+        if (wg != 0) hreq = (int)__hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        hreq = __syncthreads_or(hreq);
+        if (mark) mk[wg == 0 ? 6 : 3] = __builtin_amdgcn_s_memrealtime();
         __builtin_amdgcn_s_dcache_inv();                      // (nothing uniform that this kernel writes should sit in the scalar cache; belt and braces)
         __syncthreads();
         // per-subvolume records of the new temperatures
